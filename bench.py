@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py — Mray/s of the Chebyshev-ESS ray-march on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One *step* = one frame: every ray of the frame marched through the 1024x1024x795 uint8 synthetic volume
+(BASELINE.json configs[2], "C3") with the app-default transfer function, block size 4, Chebyshev distance-map
+empty-space skipping and early ray termination, from one of 8 fixed orbit cameras (step k uses view k mod 8).
+Inputs (volume, gradient map, TF texture, distance map) are resident in HBM before the timed region.
+
+N = 1: the frame is 1920x1080.  N > 1 (weak scaling): the frame is (1920*sx)x(1080*sy) with sx*sy = N sampling the
+SAME frustum, cut into 16x16 tiles dealt round-robin to the ranks (volume replicated); each rank renders its tiles into
+a compact RGBA8 buffer, the buffers are gathered to rank 0 over RCCL and de-interleaved there.  The gather of frame k
+overlaps the render of frame k+1.  value = rays of all ranks / max-over-ranks wall time.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the ray-march kernel by ALGORITHMIC bytes (SURVEY.md §8d:
+16 B per volume sample, 1 B per distance probe, 4 B per ray of RGBA8 output) over its HIP-event duration;
+`cpu_baseline` times the CPU oracle (a scalar port of the reference shaders) on a pixel-strided sample of the same frames.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from vkvolume_amd import abi, camera, lib, volume as V  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+WORKLOADS = {
+    # name: (extent WxHxD, seed, voxel size, axis-angle, frame, skipping type)
+    "c3": ((1024, 1024, 795), 0xC0FFEE03, (0.0003, 0.0003, 0.0007), (1.0, 0.0, 0.0, 90.0), (1920, 1080), abi.SKIP_DISTANCE),
+    "c2": ((512, 512, 512), 0xC0FFEE02, (1.0, 1.0, 1.0), (1.0, 0.0, 0.0, 0.0), (1920, 1080), abi.SKIP_BLOCK),
+    "small": ((128, 128, 100), 0xC0FFEE03, (0.0003, 0.0003, 0.0007), (1.0, 0.0, 0.0, 90.0), (320, 192), abi.SKIP_DISTANCE),
+}
+GRID = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
+TILE = 16
+N_VIEWS = 8
+
+
+def build_scene(ctx, name):
+    extent, seed, voxel, axis_angle, frame, skip = WORKLOADS[name]
+    v = V.Volume(ctx)
+    v.options = abi.VolumeOptions(intensity_min=0.1, intensity_max=1.0, gradient_min=0.0, gradient_max=0.2)  # volume_render.cpp:67-70
+    v.load_synthetic(extent, kind=1, seed=seed, distance_map_block_size=4)
+    V.default_scene(v, voxel, axis_angle)
+    tf = v.get_transfer_function_uniform()
+    V.ComputeGradientMap(ctx).compute(v, tf)
+    v.update_transfer_function_texture()
+    V.ComputeDistanceMap(ctx).compute(v, tf, skip)
+    torch.cuda.synchronize()
+    return v, tf, frame, skip
+
+
+def cameras(v, aspect):
+    """8 azimuths, elevation 20 deg, radius 1.5 x bounding-sphere radius of the scaled volume."""
+    m = (v.node_transform.astype(np.float64).T @ v.image_transform.astype(np.float64).T)[:3, :3]
+    half_diag = 0.5 * math.sqrt(sum(float(np.linalg.norm(m[:, i])) ** 2 for i in range(3)))
+    radius = 1.5 * half_diag
+    proj = camera.perspective_vulkan(60.0, aspect, 0.1, 1000.0)
+    return [(camera.orbit_camera(45.0 * i, 20.0, radius), proj) for i in range(N_VIEWS)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if world not in GRID:
+        raise SystemExit("--gpus must be 1, 2, 4 or 8")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    ctx = lib.Context(local_rank)  # raises if the HIP library is missing: there is no fallback path
+    v, tf, frame, skip = build_scene(ctx, args.workload)
+    sx, sy = GRID[world]
+    fw, fh = frame[0] * sx, frame[1] * sy
+    views = cameras(v, frame[0] / frame[1])  # the SAME frustum for every N
+    opts = abi.RenderOptions(skipping_type=skip, clip_distance=1.0, early_ray_termination=True)
+    sp = V.VolumeRenderSubpass(ctx, v, opts, (fw, fh))
+    tiles = abi.full_frame_tiles(fw, fh, TILE, TILE, rank, world, compact=(world > 1))
+    total_tiles = ((fw + TILE - 1) // TILE) * ((fh + TILE - 1) // TILE)
+    tiles_per_rank = (total_tiles + world - 1) // world
+    params = [sp.make_params(view, proj, tiles) for view, proj in views]
+    my_pixels = tiles.tile_count * TILE * TILE if world > 1 else fw * fh
+    rays_per_frame_all = fw * fh  # every pixel of the frame is a ray (covered or not), summed over ranks
+
+    # ---- pre-pass (untimed): frag counters per view -> algorithmic bytes per launch ------------------------------
+    counts = torch.zeros((my_pixels, 3), dtype=torch.int32, device="cuda")
+    n_vs, n_ds = [], []
+    for p in params:
+        counts.zero_()
+        sp.draw(p, counts=counts)
+        torch.cuda.synchronize()
+        s = counts.to(torch.int64).sum(0).cpu().numpy()
+        n_vs.append(int(s[0]))
+        n_ds.append(int(s[1]))
+    del counts
+    # rays this rank marches per frame = in-image pixels of its tiles (edge tiles are partial)
+    tiles_x = (fw + TILE - 1) // TILE
+    my_rays = 0
+    for k in range(tiles.tile_count):
+        t = tiles.tile_first + k * tiles.tile_stride
+        x0, y0 = (t % tiles_x) * TILE, (t // tiles_x) * TILE
+        my_rays += min(TILE, fw - x0) * min(TILE, fh - y0)
+
+    # ---- outputs ---------------------------------------------------------------------------------------------
+    n_buf = 2 if world > 1 else 1
+    bufs = [torch.zeros((tiles_per_rank * TILE * TILE if world > 1 else fw * fh, 4), dtype=torch.uint8, device="cuda")
+            for _ in range(n_buf)]
+    gathered = image = None
+    if world > 1 and rank == 0:
+        flat = [torch.empty((world,) + tuple(bufs[0].shape), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
+        gathered = [[flat[b][r] for r in range(world)] for b in range(n_buf)]
+        image = torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda")
+
+    ev_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_stop = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stream = torch.cuda.current_stream()
+
+    def run(n_steps, timed):
+        works = [None] * n_buf
+        for k in range(n_steps):
+            b = k % n_buf
+            if world > 1 and works[b] is not None:
+                works[b].wait()  # buffer b's previous gather must be done before it is overwritten
+                if rank == 0:
+                    ctx.scatter_tiles(flat[b].data_ptr(), image.data_ptr(), (fw, fh), (TILE, TILE), world, tiles_per_rank, 4,
+                                      stream.cuda_stream)
+                works[b] = None
+            p = params[k % N_VIEWS]
+            if timed:
+                ev_start[k].record(stream)
+            sp.draw(p, rgba8=bufs[b])
+            if timed:
+                ev_stop[k].record(stream)
+            if world > 1:
+                works[b] = dist.gather(bufs[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
+        for b in range(n_buf):
+            if world > 1 and works[b] is not None:
+                works[b].wait()
+                if rank == 0:
+                    ctx.scatter_tiles(flat[b].data_ptr(), image.data_ptr(), (fw, fh), (TILE, TILE), world, tiles_per_rank, 4,
+                                      stream.cuda_stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup, False)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = [ev_start[k].elapsed_time(ev_stop[k]) for k in range(args.steps)]
+    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+    # algorithmic bytes of this rank's launches, averaged over the launches actually timed
+    b_out = 4
+    alg_bytes = [n_vs[k % N_VIEWS] * 16 + n_ds[k % N_VIEWS] * 1 + my_rays * b_out for k in range(args.steps)]
+    alg_avg = sum(alg_bytes) / len(alg_bytes)
+    achieved_gbs = alg_avg / (kernel_ms_avg * 1e-3) / 1e9
+
+    # whole-job sample rates need every rank's counters
+    tot = torch.tensor([sum(n_vs[k % N_VIEWS] for k in range(args.steps)), sum(n_ds[k % N_VIEWS] for k in range(args.steps))],
+                       dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tot)
+    vs_total, ds_total = float(tot[0].item()), float(tot[1].item())
+
+    if rank != 0:
+        dist.destroy_process_group()
+        return
+
+    value = rays_per_frame_all * args.steps / elapsed / 1e6
+    out = {
+        "metric": "Mray/s", "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (u8 voxels)", "data": "synthetic",
+        "config": {"workload": "%s: %dx%dx%d uint8 synthetic shells, %dx%d frame, %s ESS + ERT, block 4, TF imin 0.1 imax 1 gmin 0 gmax 0.2, "
+                               "8 orbit views" % (args.workload, *WORKLOADS[args.workload][0], fw, fh,
+                                                  {1: "block", 2: "Chebyshev distance-map", 3: "anisotropic"}[skip]),
+                   "parallelism": "screen tiles 16x16 round-robin over %d GPU(s), RCCL gather to rank 0" % world if world > 1 else "1 GPU",
+                   "output": "RGBA8"},
+        "volume_samples_per_s": round(vs_total / elapsed, 1), "distance_probes_per_s": round(ds_total / elapsed, 1),
+        "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                     "kernel": "k_raymarch", "kernel_ms_avg": round(kernel_ms_avg, 4),
+                     "algorithmic_bytes_per_launch": int(alg_avg),
+                     "note": "algorithmic (requested) bytes: 16 B/volume sample + 1 B/distance probe + 4 B/ray; NOT DRAM traffic"},
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(v, params, (fw, fh), args.cpu_seconds)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(v, params, frame, target_seconds):
+    """Time the CPU oracle (scalar port of the reference shaders, all host cores) on every s-th pixel in x and y of the
+    same 8 frames.  The oracle is only the baseline being timed here; nothing it computes feeds the GPU result."""
+    from oracle import vkv_oracle as O
+    cores = os.cpu_count() or 1
+    vol, grad = v.volume.cpu().numpy(), v.gradient.cpu().numpy()
+    tex = v.transfer_function.cpu().numpy()
+    maps = [m.cpu().numpy() for m in v.distance_maps]
+    # calibrate on a sparse sample of view 0, then pick the stride that fills the time budget over the 8 views
+    t = time.perf_counter()
+    r = O.render(params[0], vol, grad, tex, maps, n_threads=cores, pixel_stride=24)
+    rate = r.rays / max(time.perf_counter() - t, 1e-6)
+    want = rate * target_seconds / N_VIEWS
+    stride = max(1, int(math.ceil(math.sqrt(frame[0] * frame[1] / max(want, 1.0)))))
+    rays = 0
+    t = time.perf_counter()
+    for p in params:
+        rays += O.render(p, vol, grad, tex, maps, n_threads=cores, pixel_stride=stride).rays
+    dt = time.perf_counter() - t
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mray/s", "cores": cores, "kind": "port",
+            "sample": "oracle/vkv_oracle.c (scalar C port of the shaders, pthreads over scanlines), every %d-th pixel in x and y of the "
+                      "same 8 frames: %d rays in %.1f s" % (stride, rays, dt)}
+
+
+if __name__ == "__main__":
+    main()

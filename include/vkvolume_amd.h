@@ -1,0 +1,233 @@
+/*
+ * vkvolume_amd.h — C ABI of the MI355X-native volume ray-caster hot path.
+ *
+ * This is the drop-in boundary: every entry point below replaces one
+ * Vulkan dispatcher of the reference (LDeakin/VkVolume) and is what a maintainer's FFI
+ * would bind.  Plain C types only: device pointers, sizes, POD structs, an opaque
+ * context and a `void *stream` that is a `hipStream_t`.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative VKV_E_* code for argument /
+ *     capability errors, or a positive `hipError_t` value when the HIP runtime failed;
+ *   - device functions ENQUEUE on `stream` and do not synchronise (the reference's
+ *     compute_submit() fence wait, src/volume_render.cpp:301-327, is the caller's job);
+ *   - pointers named `d_*` are device pointers owned by the caller; POD structs are
+ *     passed by const pointer and copied at call time;
+ *   - volumes are dense uint8, x fastest: index = (z*height + y)*width + x
+ *     (raw file order, src/volume_component.cpp:47-52); distance / occupancy maps the same;
+ *   - matrices are column-major float[16] (glm::mat4 byte layout).
+ */
+#ifndef VKVOLUME_AMD_H
+#define VKVOLUME_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VKV_OK 0
+#define VKV_E_INVALID_ARGUMENT (-1) /* null pointer, zero extent, bad enum              */
+#define VKV_E_UNSUPPORTED (-2)      /* e.g. depth_attachment input, map axis > 2048      */
+#define VKV_E_NO_DEVICE (-3)        /* no HIP device / wrong architecture               */
+#define VKV_E_IO (-4)               /* file errors of the loader                        */
+
+/* VkExtent3D stand-in (src/load_volume.h:31, src/volume_component.cpp:91-92). */
+typedef struct VkvExtent3D
+{
+	uint32_t width, height, depth;
+} VkvExtent3D;
+
+/* TransferFunctionUniform, src/transfer_function.h:20-32 (32 bytes; the texture-path shaders read
+ * the first 16, shaders/transfer_function.glsl:18-29). use_gradient is a VkBool32. */
+typedef struct VkvTransferFunctionUniform
+{
+	float    sampling_factor;
+	float    voxel_alpha_factor;
+	float    grad_magnitude_modifier;
+	uint32_t use_gradient;
+	float    intensity_min;
+	float    intensity_range_inv;
+	float    gradient_min;
+	float    gradient_range_inv;
+} VkvTransferFunctionUniform;
+
+/* Volume::Options, src/volume_component.h:45-56. */
+typedef struct VkvVolumeOptions
+{
+	float    sampling_factor;          /* 1.0 */
+	float    voxel_alpha_factor;       /* 1.0 */
+	uint32_t use_precomputed_gradient; /* true */
+	float    intensity_min;            /* 0.0 */
+	float    intensity_max;            /* 1.0 */
+	float    gradient_min;             /* 0.0 */
+	float    gradient_max;             /* 1.0 */
+} VkvVolumeOptions;
+
+/* CameraUniform, src/volume_render_subpass.h:32-39 (320 bytes). */
+typedef struct VkvCameraUniform
+{
+	float camera_view[16];
+	float camera_proj[16];
+	float camera_view_proj_inv[16];
+	float model[16];
+	float model_inv[16];
+} VkvCameraUniform;
+
+/* RayCastUniform, src/volume_render_subpass.h:46-53 (68 bytes). */
+typedef struct VkvRayCastUniform
+{
+	float   plane[4];          /* clipping plane, global coordinates  */
+	float   plane_tex[4];      /* clipping plane, texture coordinates */
+	float   camera_pos_tex[4]; /* camera position, texture coordinates */
+	float   block_size[4];     /* ceil(volume extent / map extent) per axis, as floats */
+	int32_t front_index;
+} VkvRayCastUniform;
+
+/* Analytic pinhole ray generator.  It stands in for the rasteriser + the two vertex shaders
+ * (shaders/volume_render_clipped.vert:50-65, shaders/volume_render_plane_intersection.vert:101-130):
+ * the un-normalised texture-space direction of the ray through pixel (px, py) is
+ *   dir = dir00 + (px + 0.5) * ddx + (py + 0.5) * ddy
+ * which is exact for a pinhole camera.  vkv_build_uniforms() fills it from the matrices. */
+typedef struct VkvRayGen
+{
+	float dir00[4];
+	float ddx[4];
+	float ddy[4];
+} VkvRayGen;
+
+/* VolumeRenderSubpass::SkippingType / Test / Options, src/volume_render_subpass.h:58-81. */
+enum VkvSkippingType
+{
+	VKV_SKIP_NONE                 = 0,
+	VKV_SKIP_BLOCK                = 1,
+	VKV_SKIP_DISTANCE             = 2,
+	VKV_SKIP_ANISOTROPIC_DISTANCE = 3
+};
+
+enum VkvTest
+{
+	VKV_TEST_NONE                = 0,
+	VKV_TEST_RAY_ENTRY           = 1,
+	VKV_TEST_RAY_EXIT            = 2,
+	VKV_TEST_NUM_TEXTURE_SAMPLES = 3
+};
+
+typedef struct VkvRenderOptions
+{
+	int32_t skipping_type;         /* VKV_SKIP_DISTANCE */
+	float   clip_distance;         /* 50.0 */
+	int32_t early_ray_termination; /* true */
+	int32_t depth_attachment;      /* false; true is VKV_E_UNSUPPORTED */
+	int32_t test;                  /* VKV_TEST_NONE */
+} VkvRenderOptions;
+
+/* Screen tiling of one launch (single GPU: all tiles; multi GPU: every tile_stride-th tile).
+ * The W×H image is cut into tiles of tile_width × tile_height pixels, numbered row-major.
+ * The launch renders tiles tile_first + k*tile_stride, k = 0 .. tile_count-1.
+ * compact == 0: outputs are indexed by image pixel  (y*image_width + x);
+ * compact != 0: outputs are indexed by (k*tile_height + ly)*tile_width + lx  (the per-rank
+ *               buffer that is gathered over RCCL and de-interleaved by vkv_scatter_tiles). */
+typedef struct VkvTileSchedule
+{
+	uint32_t tile_width, tile_height; /* multiples of 8 */
+	uint32_t tile_first, tile_stride, tile_count;
+	uint32_t compact;
+} VkvTileSchedule;
+
+/* Everything VolumeRenderSubpass::draw binds for one volume
+ * (src/volume_render_subpass.cpp:219-293) plus the output images. */
+typedef struct VkvRenderParams
+{
+	VkvCameraUniform           camera;
+	VkvRayCastUniform          ray_cast;
+	VkvTransferFunctionUniform transfer_function;
+	VkvRayGen                  ray_gen;
+	VkvRenderOptions           options;
+	uint32_t                   use_precomputed_gradient; /* PRECOMPUTED_GRADIENT variant */
+	uint32_t                   image_width, image_height;
+	VkvTileSchedule            tiles;
+	VkvExtent3D                volume_extent;
+	VkvExtent3D                map_extent;
+	const uint8_t *            d_volume;                   /* R8_UNORM  W*H*D                */
+	const uint8_t *            d_gradient;                 /* R8_UNORM  W*H*D, may be NULL when !use_precomputed_gradient */
+	const uint8_t *            d_transfer_function;        /* RGBA8 256x256, row = gradient  */
+	const uint8_t *            d_distance_maps[8];         /* [0] (or [0..7] anisotropic); unused for VKV_SKIP_NONE */
+	float *                    d_out_color;                /* RGBA32F premultiplied, or NULL */
+	uint8_t *                  d_out_rgba8;                /* RGBA8 round-to-nearest of the above, or NULL */
+	uint32_t *                 d_out_counts;               /* 3 x u32 per pixel: volume samples, distance probes, empty samples; or NULL */
+	float *                    d_out_depth;                /* gl_FragDepth (reverse-Z, 0 = far), or NULL */
+} VkvRenderParams;
+
+typedef struct vkv_ctx vkv_ctx;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int         vkv_create(int device_ordinal, vkv_ctx **out_ctx);
+void        vkv_destroy(vkv_ctx *ctx);
+const char *vkv_last_error(const vkv_ctx *ctx);
+const char *vkv_version(void);
+
+/* ---- host-side helpers (pure CPU, no device access) ------------------------------------------ */
+
+/* Volume::get_transfer_function_uniform, src/volume_component.cpp:226-240. */
+int vkv_transfer_function_uniform(const VkvVolumeOptions *options, VkvTransferFunctionUniform *out);
+
+/* CPU half of Volume::update_transfer_function_texture, src/volume_component.cpp:242-261:
+ * fills 256*256 RGBA8 texels (row = gradient, column = intensity). */
+int vkv_transfer_function_texture(const VkvVolumeOptions *options, uint8_t *out_rgba8_256x256);
+
+/* Uniform maths of VolumeRenderSubpass::draw, src/volume_render_subpass.cpp:221-249, plus the ray
+ * generator.  view / proj (already vulkan-style, y flipped) / node_transform / image_transform are
+ * column-major 4x4. */
+int vkv_build_uniforms(const float *view, const float *proj, const float *node_transform, const float *image_transform,
+                       float clip_distance, uint32_t image_width, uint32_t image_height,
+                       VkvExtent3D volume_extent, VkvExtent3D map_extent,
+                       VkvCameraUniform *out_camera, VkvRayCastUniform *out_ray_cast, VkvRayGen *out_ray_gen);
+
+/* ---- device entry points ------------------------------------------------------------------- */
+
+/* ComputeGradientMap::compute, src/compute_gradient_map.cpp:57-81 (shaders/gradient_map.comp). */
+int vkv_gradient_map(vkv_ctx *ctx, const uint8_t *d_volume, uint8_t *d_gradient, VkvExtent3D extent,
+                     const VkvTransferFunctionUniform *tf, void *stream);
+
+/* ComputeDistanceMap::computeOccupancy, src/compute_distance_map.cpp:103-140
+ * (shaders/occupancy_map.comp).  d_gradient == NULL selects the on-the-fly gradient variant. */
+int vkv_occupancy_map(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_t *d_gradient,
+                      const uint8_t *d_transfer_function, const VkvTransferFunctionUniform *tf,
+                      VkvExtent3D extent, uint8_t *d_map, VkvExtent3D map_extent, void *stream);
+
+/* ComputeDistanceMap::computeDistance, src/compute_distance_map.cpp:142-175
+ * (shaders/distance_map.comp): in-place on d_map (holding the occupancy map), d_swap is scratch. */
+int vkv_distance_map(vkv_ctx *ctx, uint8_t *d_map, uint8_t *d_swap, VkvExtent3D map_extent, void *stream);
+
+/* ComputeDistanceMap::computeDistanceAnisotropic, src/compute_distance_map.cpp:177-290
+ * (shaders/distance_map_anisotropic.comp): occupancy in d_maps[7]; on return d_maps[k] is the map
+ * for ray-direction octant k = (dz<0) + 2(dy<0) + 4(dx<0). */
+int vkv_distance_map_anisotropic(vkv_ctx *ctx, uint8_t *const d_maps[8], uint8_t *d_swap,
+                                 VkvExtent3D map_extent, void *stream);
+
+/* ComputeDistanceMap::compute, src/compute_distance_map.cpp:65-101: occupancy into
+ * d_maps[n-1] (n = 8 for anisotropic, else 1), then the transform selected by skipping_type. */
+int vkv_compute_distance_map(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_t *d_gradient,
+                             const uint8_t *d_transfer_function, const VkvTransferFunctionUniform *tf,
+                             VkvExtent3D extent, uint8_t *const d_maps[8], uint8_t *d_swap,
+                             VkvExtent3D map_extent, int32_t skipping_type, void *stream);
+
+/* VolumeRenderSubpass::draw, src/volume_render_subpass.cpp:159-294 (shaders/volume_render.frag). */
+int vkv_render(vkv_ctx *ctx, const VkvRenderParams *params, void *stream);
+
+/* Root-rank de-interleave of gathered compact tile buffers into the W×H image (multi-GPU):
+ * d_gathered holds n_ranks buffers of tiles_per_rank tiles each, bytes_per_pixel per pixel. */
+int vkv_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, uint32_t image_width,
+                      uint32_t image_height, uint32_t tile_width, uint32_t tile_height,
+                      uint32_t n_ranks, uint32_t tiles_per_rank, uint32_t bytes_per_pixel, void *stream);
+
+/* Deterministic synthetic uint8 volume, generated on the device. kind 0 = soft
+ * sphere (config C1), kind 1 = ellipsoid shells + hash noise (configs C2..C5). */
+int vkv_synth_volume(vkv_ctx *ctx, uint8_t *d_volume, VkvExtent3D extent, uint32_t kind, uint32_t seed, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VKVOLUME_AMD_H */

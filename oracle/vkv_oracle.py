@@ -1,0 +1,216 @@
+"""ctypes/numpy front-end of the CPU oracle (``oracle/vkv_oracle.c``).
+
+TEST INFRASTRUCTURE ONLY: imported by ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` — never by the product package.  PARITY UNPINNED (see ``vkv_oracle.h``).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from vkvolume_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    """Compile the oracle with gcc (Makefile in this directory)."""
+    if force or not os.path.exists(os.path.join(_HERE, "libvkv_oracle.so")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+
+
+def _has_fma():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return " fma " in line + " "
+    except OSError:
+        pass
+    return False
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    build()
+    name = "libvkv_oracle_fma.so" if _has_fma() and os.path.exists(os.path.join(_HERE, "libvkv_oracle_fma.so")) \
+        else "libvkv_oracle.so"
+    L = C.CDLL(os.path.join(_HERE, name))
+    u8p, f32p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.c_void_p
+    L.vkvo_transfer_function_uniform.argtypes = [C.POINTER(abi.VolumeOptions), C.POINTER(abi.TransferFunctionUniform)]
+    L.vkvo_transfer_function_texture.argtypes = [C.POINTER(abi.VolumeOptions), vp]
+    L.vkvo_build_uniforms.argtypes = [vp, vp, vp, vp, C.c_float, C.c_uint32, C.c_uint32, abi.Extent3D, abi.Extent3D,
+                                      C.POINTER(abi.CameraUniform), C.POINTER(abi.RayCastUniform), C.POINTER(abi.RayGen)]
+    L.vkvo_gradient_map.argtypes = [vp, vp, abi.Extent3D, C.POINTER(abi.TransferFunctionUniform)]
+    L.vkvo_occupancy_map.argtypes = [vp, vp, vp, C.POINTER(abi.TransferFunctionUniform), abi.Extent3D, vp, abi.Extent3D]
+    L.vkvo_distance_map.argtypes = [vp, vp, abi.Extent3D]
+    L.vkvo_distance_map_anisotropic.argtypes = [C.POINTER(vp), vp, abi.Extent3D]
+    L.vkvo_compute_distance_map.argtypes = [vp, vp, vp, C.POINTER(abi.TransferFunctionUniform), abi.Extent3D,
+                                            C.POINTER(vp), vp, abi.Extent3D, C.c_int32]
+    L.vkvo_render.argtypes = [C.POINTER(abi.RenderParams), C.c_int, C.c_uint32]
+    L.vkvo_render.restype = C.c_uint64
+    L.vkvo_synth_volume.argtypes = [vp, abi.Extent3D, C.c_uint32, C.c_uint32]
+    L.vkvo_load_header.argtypes = [C.c_char_p, vp]
+    L.vkvo_load_data.argtypes = [C.c_char_p, vp, vp]
+    del u8p, f32p
+    _LIB = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _extent_of(vol):
+    d, h, w = vol.shape
+    return abi.Extent3D(w, h, d)
+
+
+def map_extent(extent, block):
+    """ceil(extent / block), src/volume_component.cpp:91-92"""
+    return abi.Extent3D(*[(v + block - 1) // block for v in extent.as_tuple()])
+
+
+def transfer_function_uniform(options):
+    out = abi.TransferFunctionUniform()
+    lib().vkvo_transfer_function_uniform(C.byref(options), C.byref(out))
+    return out
+
+
+def transfer_function_texture(options):
+    tex = np.zeros((256, 256, 4), np.uint8)
+    lib().vkvo_transfer_function_texture(C.byref(options), _ptr(tex))
+    return tex
+
+
+def build_uniforms(view, proj, node_transform, image_transform, clip_distance, image_size, volume_extent, map_ext):
+    cam, rc, rg = abi.CameraUniform(), abi.RayCastUniform(), abi.RayGen()
+    mats = [np.ascontiguousarray(m, np.float32).reshape(16) for m in (view, proj, node_transform, image_transform)]
+    lib().vkvo_build_uniforms(_ptr(mats[0]), _ptr(mats[1]), _ptr(mats[2]), _ptr(mats[3]), clip_distance,
+                              image_size[0], image_size[1], volume_extent, map_ext, C.byref(cam), C.byref(rc), C.byref(rg))
+    return cam, rc, rg
+
+
+def gradient_map(vol, tf):
+    """vol: uint8 [D,H,W] → gradient uint8 [D,H,W]"""
+    vol = np.ascontiguousarray(vol, np.uint8)
+    grad = np.empty_like(vol)
+    lib().vkvo_gradient_map(_ptr(vol), _ptr(grad), _extent_of(vol), C.byref(tf))
+    return grad
+
+
+def occupancy_map(vol, grad, tf_tex, tf, block):
+    vol = np.ascontiguousarray(vol, np.uint8)
+    me = map_extent(_extent_of(vol), block)
+    out = np.empty((me.depth, me.height, me.width), np.uint8)
+    lib().vkvo_occupancy_map(_ptr(vol), _ptr(grad), _ptr(tf_tex), C.byref(tf), _extent_of(vol), _ptr(out), me)
+    return out
+
+
+def distance_map(occ):
+    m = np.ascontiguousarray(occ, np.uint8).copy()
+    swap = np.zeros_like(m)
+    lib().vkvo_distance_map(_ptr(m), _ptr(swap), _extent_of(m))
+    return m
+
+
+def distance_map_anisotropic(occ):
+    """occ: occupancy [md,mh,mw] → uint8 [8,md,mh,mw], index = (dz<0) + 2(dy<0) + 4(dx<0)"""
+    occ = np.ascontiguousarray(occ, np.uint8)
+    maps = np.zeros((8,) + occ.shape, np.uint8)
+    maps[7] = occ
+    swap = np.zeros_like(occ)
+    ptrs = (C.c_void_p * 8)(*[maps[i].ctypes.data for i in range(8)])
+    lib().vkvo_distance_map_anisotropic(ptrs, _ptr(swap), _extent_of(occ))
+    return maps
+
+
+def compute_distance_map(vol, grad, tf_tex, tf, block, skipping_type):
+    """ComputeDistanceMap::compute → array [n_maps, md, mh, mw] (n_maps = 8 for anisotropic, else 1)."""
+    vol = np.ascontiguousarray(vol, np.uint8)
+    me = map_extent(_extent_of(vol), block)
+    n = 8 if skipping_type == abi.SKIP_ANISOTROPIC_DISTANCE else 1
+    maps = np.zeros((8, me.depth, me.height, me.width), np.uint8)
+    swap = np.zeros((me.depth, me.height, me.width), np.uint8)
+    ptrs = (C.c_void_p * 8)(*[maps[i].ctypes.data for i in range(8)])
+    lib().vkvo_compute_distance_map(_ptr(vol), _ptr(grad), _ptr(tf_tex), C.byref(tf), _extent_of(vol), ptrs, _ptr(swap),
+                                    me, skipping_type)
+    return maps[:n].copy()
+
+
+def synth_volume(shape_whd, kind, seed):
+    w, h, d = shape_whd
+    vol = np.empty((d, h, w), np.uint8)
+    lib().vkvo_synth_volume(_ptr(vol), abi.Extent3D(w, h, d), kind, seed)
+    return vol
+
+
+class RenderResult:
+    def __init__(self, color, counts, depth, rgba8, rays):
+        self.color, self.counts, self.depth, self.rgba8, self.rays = color, counts, depth, rgba8, rays
+
+
+def render(params, vol, grad, tf_tex, maps, n_threads=None, pixel_stride=1, want_rgba8=False):
+    """Run the oracle ray-marcher. ``params`` is an ``abi.RenderParams`` whose pointer fields are overwritten with
+    host arrays; outputs are image-shaped (or compact, following ``params.tiles``)."""
+    p = abi.RenderParams.from_buffer_copy(params)
+    vol = np.ascontiguousarray(vol, np.uint8)
+    tf_tex = np.ascontiguousarray(tf_tex, np.uint8)
+    keep = [vol, tf_tex]
+    p.d_volume = vol.ctypes.data
+    p.d_gradient = None
+    if grad is not None:
+        grad = np.ascontiguousarray(grad, np.uint8)
+        keep.append(grad)
+        p.d_gradient = grad.ctypes.data
+    p.d_transfer_function = tf_tex.ctypes.data
+    for i in range(8):
+        p.d_distance_maps[i] = None
+    if maps is not None:
+        for i in range(len(maps)):
+            m = np.ascontiguousarray(maps[i], np.uint8)
+            keep.append(m)
+            p.d_distance_maps[i] = m.ctypes.data
+    if p.tiles.compact:
+        npix = p.tiles.tile_count * p.tiles.tile_width * p.tiles.tile_height
+        shape = (npix,)
+    else:
+        shape = (p.image_height, p.image_width)
+    color = np.zeros(shape + (4,), np.float32)
+    counts = np.zeros(shape + (3,), np.uint32)
+    depth = np.zeros(shape, np.float32)
+    rgba8 = np.zeros(shape + (4,), np.uint8) if want_rgba8 else None
+    p.d_out_color, p.d_out_counts, p.d_out_depth = color.ctypes.data, counts.ctypes.data, depth.ctypes.data
+    p.d_out_rgba8 = rgba8.ctypes.data if want_rgba8 else None
+    if n_threads is None:
+        n_threads = os.cpu_count() or 1
+    rays = lib().vkvo_render(C.byref(p), n_threads, pixel_stride)
+    del keep
+    return RenderResult(color, counts, depth, rgba8, rays)
+
+
+class Header(C.Structure):
+    """VkvoHeader (LoadVolume::Header, src/load_volume.h:29-39)"""
+    _fields_ = [("extent", abi.Extent3D), ("voxel_size", C.c_float * 3), ("normalisation_range", C.c_float * 2),
+                ("type", C.c_char * 16), ("endianness", C.c_char * 16), ("image_transform", C.c_float * 16)]
+
+
+def load_header(path):
+    h = Header()
+    rc = lib().vkvo_load_header(path.encode(), C.byref(h))
+    if rc != 0:
+        raise RuntimeError("Failed to open header file")
+    return h
+
+
+def load_data(path, header):
+    e = header.extent
+    out = np.empty((e.depth, e.height, e.width), np.uint8)
+    rc = lib().vkvo_load_data(path.encode(), C.byref(header), _ptr(out))
+    if rc != 0:
+        raise RuntimeError("load_data failed (%d)" % rc)
+    return out

@@ -1,0 +1,320 @@
+"""GPU parity: every HIP kernel of the hot path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Bar: bit-exact for all uint8 maps and the uint32 sample counters; the float RGBA /
+depth outputs are compared with the tolerance COLOR_TOL below (the arithmetic is pinned op-for-op, so the
+observed difference is expected to be 0; the tolerance is the contract)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vkv_oracle as O
+from tests import helpers as T
+from vkvolume_amd import abi, lib, volume as V
+
+pytestmark = pytest.mark.gpu
+
+COLOR_TOL = 1e-5  # max abs difference per premultiplied float channel (SURVEY.md §8c suggests 1e-4)
+DEPTH_TOL = 1e-6
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def make_gpu_volume(ctx, scene):
+    """Upload the oracle scene's voxels and run the product's precompute chain in the reference's call order."""
+    v = V.Volume(ctx)
+    v.options = scene.options
+    v.load_from_array(scene.vol, scene.block, scene.image_transform)
+    v.node_transform = scene.node_transform
+    tf = v.get_transfer_function_uniform()
+    if v.options.use_precomputed_gradient:
+        V.ComputeGradientMap(ctx).compute(v, tf)
+    v.update_transfer_function_texture()
+    return v, tf
+
+
+# ------------------------------------------------------------------------------------------------------
+# synthetic generator
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,kind,seed", [((64, 64, 64), 0, 1), ((64, 64, 64), 1, 0xC0FFEE02), ((97, 50, 33), 1, 7),
+                                             ((130, 70, 41), 0, 3)])
+def test_synth_volume_matches_oracle(ctx, shape, kind, seed):
+    w, h, d = shape
+    t = torch.empty((d, h, w), dtype=torch.uint8, device="cuda")
+    ctx.synth_volume(t.data_ptr(), abi.Extent3D(w, h, d), kind, seed, torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(t.cpu().numpy(), O.synth_volume(shape, kind, seed))
+
+
+# ------------------------------------------------------------------------------------------------------
+# gradient map
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(64, 64, 64), (37, 29, 23), (130, 5, 3), (1, 1, 1), (65, 1, 9)])
+@pytest.mark.parametrize("use_gradient", [True, False])
+def test_gradient_map_parity(ctx, shape, use_gradient):
+    vol = T.random_volume(shape, seed=11)
+    opt = abi.VolumeOptions(**T.APP_TF) if use_gradient else abi.VolumeOptions(intensity_min=0.1)
+    tf = lib.transfer_function_uniform(opt)
+    assert bool(tf.use_gradient) == use_gradient
+    d_vol, d_grad = dev(vol), torch.empty(vol.shape, dtype=torch.uint8, device="cuda")
+    ctx.gradient_map(d_vol.data_ptr(), d_grad.data_ptr(), abi.Extent3D(*shape), tf, torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(d_grad.cpu().numpy(), O.gradient_map(vol, tf))
+
+
+def test_gradient_map_smooth_volume(ctx):
+    vol = O.synth_volume((96, 80, 72), 1, 5)
+    tf = lib.transfer_function_uniform(abi.VolumeOptions(**T.APP_TF))
+    d_vol, d_grad = dev(vol), torch.empty(vol.shape, dtype=torch.uint8, device="cuda")
+    ctx.gradient_map(d_vol.data_ptr(), d_grad.data_ptr(), abi.Extent3D(96, 80, 72), tf, 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_grad.cpu().numpy(), O.gradient_map(vol, tf))
+
+
+# ------------------------------------------------------------------------------------------------------
+# occupancy + distance maps
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,block", [((64, 64, 64), 4), ((61, 45, 30), 4), ((50, 33, 21), 3), ((40, 40, 40), 2),
+                                         ((67, 31, 18), 5), ((48, 48, 48), 6), ((20, 9, 7), 1)])
+@pytest.mark.parametrize("variant", ["precomputed", "on_the_fly", "no_gradient"])
+def test_occupancy_map_parity(ctx, shape, block, variant):
+    vol = T.random_volume(shape, seed=5, sparsity=0.97)
+    if variant == "no_gradient":
+        opt = abi.VolumeOptions(intensity_min=0.1)
+    else:
+        opt = abi.VolumeOptions(use_precomputed_gradient=(variant == "precomputed"), **T.APP_TF)
+    scene = T.OracleScene(vol, opt, block)
+    expect = O.occupancy_map(scene.vol, scene.grad, scene.tex, scene.tf, block)
+    assert 0 < (expect == 0).mean() < 1, "test volume must give a mixed occupancy map"
+    v, tf = make_gpu_volume(ctx, scene)
+    d_map = torch.empty(expect.shape, dtype=torch.uint8, device="cuda")
+    grad = v.gradient if opt.use_precomputed_gradient else None
+    ctx.occupancy_map(v.volume.data_ptr(), None if grad is None else grad.data_ptr(), v.transfer_function.data_ptr(), tf,
+                      v.extent, d_map.data_ptr(), v.map_extent, torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(d_map.cpu().numpy(), expect)
+
+
+def sparse_occupancy(shape_dhw, seed, p):
+    rng = np.random.default_rng(seed)
+    return np.where(rng.random(shape_dhw) < p, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("shape_dhw,p", [((16, 16, 16), 0.02), ((9, 10, 13), 0.01), ((5, 70, 3), 0.01), ((40, 33, 130), 0.0005),
+                                         ((1, 1, 1), 1.0), ((7, 7, 7), 0.0), ((3, 300, 2), 0.002)])
+def test_distance_map_parity(ctx, shape_dhw, p):
+    occ = sparse_occupancy(shape_dhw, 3, p)
+    d, h, w = shape_dhw
+    d_map, d_swap = dev(occ), torch.empty(shape_dhw, dtype=torch.uint8, device="cuda")
+    ctx.distance_map(d_map.data_ptr(), d_swap.data_ptr(), abi.Extent3D(w, h, d), torch.cuda.current_stream().cuda_stream)
+    got = d_map.cpu().numpy()
+    assert np.array_equal(got, O.distance_map(occ))
+    if occ.size <= 20000:
+        assert np.array_equal(got, T.brute_force_chebyshev(occ))
+
+
+@pytest.mark.parametrize("shape_dhw,p", [((16, 16, 16), 0.02), ((9, 10, 13), 0.01), ((5, 70, 3), 0.01), ((40, 33, 130), 0.0005),
+                                         ((1, 1, 1), 1.0), ((6, 6, 6), 0.0)])
+def test_distance_map_anisotropic_parity(ctx, shape_dhw, p):
+    occ = sparse_occupancy(shape_dhw, 4, p)
+    d, h, w = shape_dhw
+    maps = [torch.empty(shape_dhw, dtype=torch.uint8, device="cuda") for _ in range(8)]
+    maps[7].copy_(dev(occ))
+    swap = torch.empty(shape_dhw, dtype=torch.uint8, device="cuda")
+    ctx.distance_map_anisotropic([m.data_ptr() for m in maps], swap.data_ptr(), abi.Extent3D(w, h, d),
+                                 torch.cuda.current_stream().cuda_stream)
+    expect = O.distance_map_anisotropic(occ)
+    for k in range(8):
+        got = maps[k].cpu().numpy()
+        assert np.array_equal(got, expect[k]), "octant %d" % k
+        if occ.size <= 3000:
+            assert np.array_equal(got, T.brute_force_chebyshev_octant(occ, k)), "octant %d vs brute force" % k
+
+
+@pytest.mark.parametrize("skipping_type", [abi.SKIP_NONE, abi.SKIP_BLOCK, abi.SKIP_DISTANCE, abi.SKIP_ANISOTROPIC_DISTANCE])
+def test_compute_distance_map_chain(ctx, skipping_type):
+    """ComputeDistanceMap::compute end to end (occupancy -> transform) on a synthetic shell volume."""
+    scene = T.OracleScene(O.synth_volume((72, 64, 56), 1, 9), abi.VolumeOptions(**T.APP_TF), 4)
+    v, tf = make_gpu_volume(ctx, scene)
+    V.ComputeDistanceMap(ctx).compute(v, tf, skipping_type)
+    expect = scene.maps(skipping_type)
+    assert len(v.distance_maps) == expect.shape[0]
+    for k in range(expect.shape[0]):
+        assert np.array_equal(v.distance_maps[k].cpu().numpy(), expect[k]), "map %d" % k
+
+
+# ------------------------------------------------------------------------------------------------------
+# ray-march integrator
+# ------------------------------------------------------------------------------------------------------
+def gpu_render(ctx, v, params, want_rgba8=False):
+    if params.tiles.compact:
+        shape = (params.tiles.tile_count * params.tiles.tile_width * params.tiles.tile_height,)
+    else:
+        shape = (params.image_height, params.image_width)
+    # image-shaped outputs start from sentinels (every pixel must be written); compact buffers have padding
+    # pixels in partial edge tiles that nobody writes, so they start from zero like the oracle's
+    s_col, s_cnt = (0.0, 0) if params.tiles.compact else (-1.0, 0xFFFF)
+    color = torch.full(shape + (4,), s_col, dtype=torch.float32, device="cuda")
+    counts = torch.full(shape + (3,), s_cnt, dtype=torch.int32, device="cuda")
+    depth = torch.full(shape, s_col, dtype=torch.float32, device="cuda")
+    rgba8 = torch.zeros(shape + (4,), dtype=torch.uint8, device="cuda") if want_rgba8 else None
+    sp = V.VolumeRenderSubpass(ctx, v, params.options, (params.image_width, params.image_height))
+    p = sp.bind(params)
+    sp.draw(p, color, rgba8, counts, depth)
+    torch.cuda.synchronize()
+    return (color.cpu().numpy(), counts.cpu().numpy().astype(np.uint32), depth.cpu().numpy(),
+            None if rgba8 is None else rgba8.cpu().numpy())
+
+
+def compare_render(got, ref, label):
+    color, counts, depth, _ = got
+    assert np.array_equal(counts, ref.counts), "%s: sample counters differ in %d pixels" % (
+        label, int((counts != ref.counts).any(-1).sum()))
+    dc = float(np.abs(color - ref.color).max())
+    dd = float(np.abs(depth - ref.depth).max())
+    assert dc <= COLOR_TOL, "%s: colour max abs diff %g" % (label, dc)
+    assert dd <= DEPTH_TOL, "%s: depth max abs diff %g" % (label, dd)
+    return dc, dd
+
+
+@pytest.fixture(scope="module")
+def shell_scene(ctx):
+    scene = T.OracleScene(O.synth_volume((96, 80, 72), 1, 0xC0FFEE02), abi.VolumeOptions(**T.APP_TF), 4)
+    v, tf = make_gpu_volume(ctx, scene)
+    cdm = V.ComputeDistanceMap(ctx)
+    cdm.compute(v, tf, abi.SKIP_ANISOTROPIC_DISTANCE)  # 8 maps; map 0 is overwritten per mode below
+    return scene, v, tf, cdm
+
+
+@pytest.mark.parametrize("skipping_type", [abi.SKIP_NONE, abi.SKIP_BLOCK, abi.SKIP_DISTANCE, abi.SKIP_ANISOTROPIC_DISTANCE])
+@pytest.mark.parametrize("ert", [True, False])
+def test_render_parity_modes(ctx, shell_scene, skipping_type, ert):
+    scene, v, tf, cdm = shell_scene
+    cdm.compute(v, tf, skipping_type)
+    size = (160, 96)
+    worst = 0.0
+    for az in (0.0, 33.0, 90.0, 201.0):
+        view, proj = T.orbit(az, image_size=size)
+        opts = abi.RenderOptions(skipping_type=skipping_type, clip_distance=1.0, early_ray_termination=ert)
+        params = scene.params(view, proj, size, opts)
+        ref = scene.render(params)
+        assert ref.counts[..., 0].sum() > 0
+        dc, _ = compare_render(gpu_render(ctx, v, params), ref, "mode %d ert %d az %g" % (skipping_type, ert, az))
+        worst = max(worst, dc)
+    print("max colour diff", worst)
+
+
+@pytest.mark.parametrize("variant", ["on_the_fly", "no_gradient"])
+@pytest.mark.parametrize("skipping_type", [abi.SKIP_NONE, abi.SKIP_DISTANCE])
+def test_render_parity_gradient_variants(ctx, variant, skipping_type):
+    vol = O.synth_volume((64, 56, 48), 1, 21)
+    opt = abi.VolumeOptions(intensity_min=0.1) if variant == "no_gradient" else abi.VolumeOptions(use_precomputed_gradient=False, **T.APP_TF)
+    scene = T.OracleScene(vol, opt, 4)
+    v, tf = make_gpu_volume(ctx, scene)
+    V.ComputeDistanceMap(ctx).compute(v, tf, skipping_type)
+    size = (96, 64)
+    view, proj = T.orbit(40.0, image_size=size)
+    params = scene.params(view, proj, size, abi.RenderOptions(skipping_type=skipping_type, clip_distance=1.0))
+    compare_render(gpu_render(ctx, v, params), scene.render(params), variant)
+
+
+@pytest.mark.parametrize("sampling_factor,alpha_factor,block", [(0.5, 1.0, 4), (2.0, 0.7, 3), (3.0, 2.0, 5), (1.0, 0.0, 2)])
+def test_render_parity_sampling_and_blocks(ctx, sampling_factor, alpha_factor, block):
+    vol = O.synth_volume((70, 61, 45), 1, 33)
+    opt = abi.VolumeOptions(sampling_factor=sampling_factor, voxel_alpha_factor=alpha_factor, **T.APP_TF)
+    scene = T.OracleScene(vol, opt, block, voxel_size=(0.0003, 0.0003, 0.0007), axis_angle=(1, 0, 0, 90))
+    v, tf = make_gpu_volume(ctx, scene)
+    for st in (abi.SKIP_BLOCK, abi.SKIP_DISTANCE, abi.SKIP_ANISOTROPIC_DISTANCE):
+        V.ComputeDistanceMap(ctx).compute(v, tf, st)
+        size = (112, 80)
+        view, proj = T.orbit(135.0, elevation=-15.0, image_size=size)
+        params = scene.params(view, proj, size, abi.RenderOptions(skipping_type=st, clip_distance=1.0))
+        compare_render(gpu_render(ctx, v, params), scene.render(params), "sf %g block %d mode %d" % (sampling_factor, block, st))
+
+
+def test_render_camera_inside_volume_and_axis_aligned(ctx, shell_scene):
+    """Clip plane cuts the box (the plane-intersection vertex shader's case) and exactly axis-parallel rays
+    (SURVEY.md Appendix B 12)."""
+    scene, v, tf, cdm = shell_scene
+    cdm.compute(v, tf, abi.SKIP_DISTANCE)
+    size = (96, 96)
+    for radius, clip in ((20.0, 5.0), (55.0, 30.0)):
+        view, proj = T.orbit(0.0, elevation=0.0, radius=radius, image_size=size)
+        params = scene.params(view, proj, size, abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=clip))
+        ref = scene.render(params)
+        assert (ref.counts[..., 0] > 0).mean() > 0.5
+        compare_render(gpu_render(ctx, v, params), ref, "inside r=%g" % radius)
+
+
+@pytest.mark.parametrize("test", [abi.TEST_RAY_ENTRY, abi.TEST_RAY_EXIT, abi.TEST_NUM_TEXTURE_SAMPLES])
+def test_render_test_modes(ctx, shell_scene, test):
+    scene, v, tf, cdm = shell_scene
+    cdm.compute(v, tf, abi.SKIP_DISTANCE)
+    size = (96, 64)
+    view, proj = T.orbit(60.0, image_size=size)
+    # the reference's benchmark configuration: ERT off, count output (src/volume_render.cpp:177-183)
+    opts = abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0, early_ray_termination=False, test=test)
+    params = scene.params(view, proj, size, opts)
+    ref = scene.render(params)
+    color, counts, depth, _ = gpu_render(ctx, v, params)
+    assert np.array_equal(color, ref.color)  # entry/exit coordinates and the count grey level: exact
+    assert np.array_equal(counts, ref.counts)
+
+
+def test_render_compact_tiles_and_rgba8(ctx, shell_scene):
+    """Interleaved tile schedule of rank 1 of 3 into a compact buffer + RGBA8 quantisation, then the root-side
+    de-interleave of three ranks' buffers (vkv_scatter_tiles)."""
+    scene, v, tf, cdm = shell_scene
+    cdm.compute(v, tf, abi.SKIP_DISTANCE)
+    size = (150, 70)  # not a multiple of the tile size: edge tiles are partial
+    view, proj = T.orbit(300.0, image_size=size)
+    opts = abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0)
+    full = scene.params(view, proj, size, opts, tiles=abi.full_frame_tiles(size[0], size[1], 32, 16))
+    ref_full = scene.render(full, want_rgba8=True)
+    world = 3
+    per_rank = []
+    tiles_per_rank = 0
+    for rank in range(world):
+        tiles = abi.full_frame_tiles(size[0], size[1], 32, 16, rank, world, compact=True)
+        tiles_per_rank = max(tiles_per_rank, tiles.tile_count)
+        params = scene.params(view, proj, size, opts, tiles=tiles)
+        ref = scene.render(params, want_rgba8=True)
+        color, counts, depth, rgba8 = gpu_render(ctx, v, params, want_rgba8=True)
+        inside = ref.counts[..., 0] + ref.counts[..., 1] > 0
+        assert np.array_equal(counts, ref.counts)
+        assert np.abs(color - ref.color).max() <= COLOR_TOL
+        assert np.array_equal(rgba8[inside], ref.rgba8[inside])
+        per_rank.append(rgba8)
+    gathered = np.zeros((world, tiles_per_rank * 32 * 16, 4), np.uint8)
+    for r, buf in enumerate(per_rank):
+        gathered[r, :buf.shape[0]] = buf
+    d_g, d_img = dev(gathered), torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda")
+    ctx.scatter_tiles(d_g.data_ptr(), d_img.data_ptr(), size, (32, 16), world, tiles_per_rank, 4, torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(d_img.cpu().numpy(), ref_full.rgba8)
+
+
+def test_render_error_paths(ctx, shell_scene):
+    scene, v, tf, cdm = shell_scene
+    size = (64, 64)
+    view, proj = T.orbit(0.0, image_size=size)
+    sp = V.VolumeRenderSubpass(ctx, v, abi.RenderOptions(clip_distance=1.0), size)
+    p = sp.make_params(view, proj)
+    out = torch.zeros((64, 64, 4), dtype=torch.float32, device="cuda")
+    p.d_out_color = out.data_ptr()
+    assert ctx.render_rc(p) == 0
+    bad = abi.RenderParams.from_buffer_copy(p)
+    bad.options.depth_attachment = 1
+    assert ctx.render_rc(bad) == abi.VKV_E_UNSUPPORTED and "depth_attachment" in ctx.last_error()
+    bad = abi.RenderParams.from_buffer_copy(p)
+    bad.d_volume = None
+    assert ctx.render_rc(bad) == abi.VKV_E_INVALID_ARGUMENT
+    bad = abi.RenderParams.from_buffer_copy(p)
+    bad.tiles.tile_width = 12
+    assert ctx.render_rc(bad) == abi.VKV_E_INVALID_ARGUMENT
+    bad = abi.RenderParams.from_buffer_copy(p)
+    bad.options.skipping_type = 9
+    assert ctx.render_rc(bad) == abi.VKV_E_INVALID_ARGUMENT
+    bad = abi.RenderParams.from_buffer_copy(p)
+    bad.d_out_color = None
+    assert ctx.render_rc(bad) == abi.VKV_E_INVALID_ARGUMENT
+    with pytest.raises(lib.VkvError):
+        ctx.distance_map(out.data_ptr(), out.data_ptr(), abi.Extent3D(4, 4, 4))  # aliased buffers
+    with pytest.raises(lib.VkvError):
+        ctx.distance_map(out.data_ptr(), out.data_ptr() + 64, abi.Extent3D(4096, 4, 4))  # axis > 2048

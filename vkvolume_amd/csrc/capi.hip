@@ -1,0 +1,359 @@
+// capi.hip — the extern "C" boundary of include/vkvolume_amd.h: context, argument checking, host-side
+// uniform / transfer-function helpers, and dispatch to the kernel launchers.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../host/vkv_math.hpp"
+#include "vkv_device.hpp"
+
+namespace vkv
+{
+int launch_gradient_map(vkv_ctx *, const uint8_t *, uint8_t *, VkvExtent3D, const VkvTransferFunctionUniform *, hipStream_t);
+int launch_occupancy_map(vkv_ctx *, const uint8_t *, const uint8_t *, const uint8_t *, const VkvTransferFunctionUniform *, VkvExtent3D, uint8_t *,
+                         VkvExtent3D, hipStream_t);
+int launch_distance_map(vkv_ctx *, uint8_t *, uint8_t *, VkvExtent3D, hipStream_t);
+int launch_distance_map_anisotropic(vkv_ctx *, uint8_t *const[8], uint8_t *, VkvExtent3D, hipStream_t);
+int launch_synth_volume(vkv_ctx *, uint8_t *, VkvExtent3D, uint32_t, uint32_t, hipStream_t);
+int launch_scatter_tiles(vkv_ctx *, const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
+int launch_render(vkv_ctx *, const VkvRenderParams *, const float *, hipStream_t);
+
+int set_error(vkv_ctx *ctx, int code, const char *fmt, ...)
+{
+	if (ctx)
+	{
+		va_list ap;
+		va_start(ap, fmt);
+		vsnprintf(ctx->error, sizeof(ctx->error), fmt, ap);
+		va_end(ap);
+	}
+	return code;
+}
+
+int check_launch(vkv_ctx *ctx, const char *what)
+{
+	const hipError_t e = hipGetLastError();
+	if (e != hipSuccess)
+		return set_error(ctx, (int) e, "%s: %s", what, hipGetErrorString(e));
+	return VKV_OK;
+}
+
+static bool extent_ok(VkvExtent3D e) { return e.width > 0 && e.height > 0 && e.depth > 0; }
+
+// ceil(volume / map) must reproduce a valid block size (src/compute_distance_map.cpp:110-113)
+static bool map_extent_ok(VkvExtent3D e, VkvExtent3D me) { return extent_ok(me) && me.width <= e.width && me.height <= e.height && me.depth <= e.depth; }
+
+}        // namespace vkv
+
+using namespace vkv;
+
+extern "C" {
+
+const char *vkv_version(void) { return "vkvolume_amd 0.1.0 (gfx950)"; }
+
+int vkv_create(int device_ordinal, vkv_ctx **out_ctx)
+{
+	if (!out_ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	*out_ctx  = nullptr;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_ordinal < 0 || device_ordinal >= count)
+		return VKV_E_NO_DEVICE;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess)
+		return VKV_E_NO_DEVICE;
+	if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("VKV_ALLOW_ANY_ARCH"))
+		return VKV_E_NO_DEVICE;        // the code object is built for gfx950 only
+	hipError_t e = hipSetDevice(device_ordinal);
+	if (e != hipSuccess)
+		return (int) e;
+	vkv_ctx *ctx = new (std::nothrow) vkv_ctx();
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	ctx->device          = device_ordinal;
+	ctx->error[0]        = 0;
+	ctx->workspace_bytes = kWorkspaceBytes;
+	e                    = hipMalloc((void **) &ctx->d_workspace, ctx->workspace_bytes);
+	if (e != hipSuccess)
+	{
+		delete ctx;
+		return (int) e;
+	}
+	*out_ctx = ctx;
+	return VKV_OK;
+}
+
+void vkv_destroy(vkv_ctx *ctx)
+{
+	if (!ctx)
+		return;
+	if (ctx->d_workspace)
+		(void) hipFree(ctx->d_workspace);
+	delete ctx;
+}
+
+const char *vkv_last_error(const vkv_ctx *ctx) { return ctx ? ctx->error : "null context"; }
+
+// ---- host helpers ------------------------------------------------------------------------------
+
+// src/volume_component.cpp:226-240
+int vkv_transfer_function_uniform(const VkvVolumeOptions *o, VkvTransferFunctionUniform *u)
+{
+	if (!o || !u)
+		return VKV_E_INVALID_ARGUMENT;
+	u->sampling_factor         = o->sampling_factor;
+	u->voxel_alpha_factor      = o->voxel_alpha_factor;
+	u->grad_magnitude_modifier = 1.0f;
+	u->use_gradient            = o->gradient_max != o->gradient_min;
+	u->intensity_min           = o->intensity_min;
+	u->intensity_range_inv     = 1.0f / (o->intensity_max - o->intensity_min);
+	u->gradient_min            = o->gradient_min;
+	u->gradient_range_inv      = 1.0f / (o->gradient_max - o->gradient_min);
+	return VKV_OK;
+}
+
+// src/volume_component.cpp:242-261
+int vkv_transfer_function_texture(const VkvVolumeOptions *o, uint8_t *tex)
+{
+	if (!o || !tex)
+		return VKV_E_INVALID_ARGUMENT;
+	auto        clampf       = [](float x, float lo, float hi) { return std::min(std::max(x, lo), hi); };
+	const float i_inv        = 1.0f / (o->intensity_max - o->intensity_min);
+	const float g_inv        = 1.0f / (o->gradient_max - o->gradient_min);
+	const bool  use_gradient = o->gradient_max != o->gradient_min;
+	size_t      idx          = 0;
+	for (int gi = 0; gi < 256; ++gi)
+		for (int ii = 0; ii < 256; ++ii, ++idx)
+		{
+			const float   g = (float) gi, i = (float) ii;
+			const float   alpha_i = clampf(((i / 255.0f) - o->intensity_min) * i_inv, 0.0f, 1.0f);
+			const float   alpha_g = use_gradient ? clampf(((g / 255.0f) - o->gradient_min) * g_inv, 0.0f, 1.0f) : 1.0f;
+			const uint8_t alpha   = static_cast<uint8_t>(clampf(alpha_i * alpha_g * 255, 0, 255));
+			tex[idx * 4 + 0] = tex[idx * 4 + 1] = tex[idx * 4 + 2] = tex[idx * 4 + 3] = alpha;
+		}
+	return VKV_OK;
+}
+
+// src/volume_render_subpass.cpp:221-249
+int vkv_build_uniforms(const float *view, const float *proj, const float *node_transform, const float *image_transform, float clip_distance,
+                       uint32_t image_width, uint32_t image_height, VkvExtent3D ve, VkvExtent3D me, VkvCameraUniform *cam, VkvRayCastUniform *rc,
+                       VkvRayGen *rg)
+{
+	if (!view || !proj || !node_transform || !image_transform || !cam || !rc || !rg || !extent_ok(ve) || !extent_ok(me) || image_width == 0 ||
+	    image_height == 0)
+		return VKV_E_INVALID_ARGUMENT;
+	const mat4 V(view), P(proj), N(node_transform), I(image_transform);
+	const mat4 model         = N * I;
+	const mat4 model_inv     = inverse(model);
+	const mat4 view_proj_inv = inverse(P * V);
+	std::memcpy(cam->camera_view, V.m, 64);
+	std::memcpy(cam->camera_proj, P.m, 64);
+	std::memcpy(cam->camera_view_proj_inv, view_proj_inv.m, 64);
+	std::memcpy(cam->model, model.m, 64);
+	std::memcpy(cam->model_inv, model_inv.m, 64);
+
+	const mat4 model_to_tex  = translate(vec3{0.5f, 0.5f, 0.5f});
+	const mat4 global_to_tex = model_to_tex * model_inv;
+	const mat4 view_inv      = inverse(V);
+	const vec3 cam_pos_global{view_inv.at(0, 3), view_inv.at(1, 3), view_inv.at(2, 3)};
+	const vec4 cam_pos_model = model_inv * vec4{cam_pos_global.x, cam_pos_global.y, cam_pos_global.z, 1.0f};
+	const vec4 cam_pos_tex   = model_to_tex * vec4{cam_pos_model.x, cam_pos_model.y, cam_pos_model.z, 1.0f};
+	const vec4 cam_dir4      = view_inv * vec4{0, 0, -1, 0};
+	const vec3 cam_dir{cam_dir4.x, cam_dir4.y, cam_dir4.z};
+	const vec4 plane{cam_dir.x, cam_dir.y, cam_dir.z,
+	                 -clip_distance - (cam_pos_global.x * cam_dir.x + cam_pos_global.y * cam_dir.y + cam_pos_global.z * cam_dir.z)};
+	const vec4 plane_tex = inverse_transpose(global_to_tex) * plane;
+	rc->plane[0] = plane.x, rc->plane[1] = plane.y, rc->plane[2] = plane.z, rc->plane[3] = plane.w;
+	rc->plane_tex[0] = plane_tex.x, rc->plane_tex[1] = plane_tex.y, rc->plane_tex[2] = plane_tex.z, rc->plane_tex[3] = plane_tex.w;
+	rc->camera_pos_tex[0] = cam_pos_tex.x, rc->camera_pos_tex[1] = cam_pos_tex.y, rc->camera_pos_tex[2] = cam_pos_tex.z, rc->camera_pos_tex[3] = cam_pos_tex.w;
+	rc->front_index   = (plane_tex.x < 0 ? 1 : 0) + (plane_tex.y < 0 ? 2 : 0) + (plane_tex.z < 0 ? 4 : 0);
+	rc->block_size[0] = (float) ((ve.width + me.width - 1) / me.width);
+	rc->block_size[1] = (float) ((ve.height + me.height - 1) / me.height);
+	rc->block_size[2] = (float) ((ve.depth + me.depth - 1) / me.depth);
+	rc->block_size[3] = 0.0f;
+
+	// Ray generator (replaces the rasteriser): in double precision from the same float matrices.  Unproject pixel-space
+	// points (0,0), (1,0), (0,1) at two depths, express the direction in texture space and scale it to unit distance along
+	// the view direction (plane_tex.xyz is that covector), which makes the direction affine in pixel coordinates.
+	double PV[16], PVinv[16], Md[16], Minv[16];
+	{
+		const mat4 pv = P * V;        // product in float like the uniform above, inverted in double
+		for (int i = 0; i < 16; ++i)
+			PV[i] = pv.m[i], Md[i] = model.m[i];
+		if (!invert4x4<double>(PV, PVinv) || !invert4x4<double>(Md, Minv))
+			return VKV_E_INVALID_ARGUMENT;
+	}
+	auto mulv = [](const double *m, const double *v, double *r) {
+		for (int i = 0; i < 4; ++i)
+			r[i] = m[i] * v[0] + m[4 + i] * v[1] + m[8 + i] * v[2] + m[12 + i] * v[3];
+	};
+	double       dirs[3][3];
+	const double pts[3][2] = {{0, 0}, {1, 0}, {0, 1}};
+	for (int p = 0; p < 3; ++p)
+	{
+		const double nx = 2.0 * pts[p][0] / (double) image_width - 1.0, ny = 2.0 * pts[p][1] / (double) image_height - 1.0;
+		const double c1[4] = {nx, ny, 1.0, 1.0}, c2[4] = {nx, ny, 0.25, 1.0};
+		double       w1[4], w2[4], t1[4], t2[4];
+		mulv(PVinv, c1, w1);
+		mulv(PVinv, c2, w2);
+		for (int i = 0; i < 3; ++i)
+			w1[i] /= w1[3], w2[i] /= w2[3];
+		w1[3] = w2[3] = 1.0;
+		mulv(Minv, w1, t1);        // model space; the +0.5 translation cancels in the difference
+		mulv(Minv, w2, t2);
+		const double dx = t2[0] - t1[0], dy = t2[1] - t1[1], dz = t2[2] - t1[2];
+		const double along = (double) plane_tex.x * dx + (double) plane_tex.y * dy + (double) plane_tex.z * dz;
+		dirs[p][0] = dx / along, dirs[p][1] = dy / along, dirs[p][2] = dz / along;
+	}
+	for (int i = 0; i < 3; ++i)
+	{
+		rg->dir00[i] = (float) dirs[0][i];
+		rg->ddx[i]   = (float) (dirs[1][i] - dirs[0][i]);
+		rg->ddy[i]   = (float) (dirs[2][i] - dirs[0][i]);
+	}
+	rg->dir00[3] = rg->ddx[3] = rg->ddy[3] = 0.0f;
+	return VKV_OK;
+}
+
+// ---- device entry points -----------------------------------------------------------------------
+
+int vkv_gradient_map(vkv_ctx *ctx, const uint8_t *d_volume, uint8_t *d_gradient, VkvExtent3D extent, const VkvTransferFunctionUniform *tf, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (!d_volume || !d_gradient || !tf || !extent_ok(extent))
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "gradient_map: null pointer or zero extent");
+	return launch_gradient_map(ctx, d_volume, d_gradient, extent, tf, (hipStream_t) stream);
+}
+
+int vkv_occupancy_map(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_t *d_gradient, const uint8_t *d_tf, const VkvTransferFunctionUniform *tf,
+                      VkvExtent3D extent, uint8_t *d_map, VkvExtent3D map_extent, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (!d_volume || !d_tf || !tf || !d_map || !extent_ok(extent) || !map_extent_ok(extent, map_extent))
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "occupancy_map: null pointer or bad extent");
+	return launch_occupancy_map(ctx, d_volume, d_gradient, d_tf, tf, extent, d_map, map_extent, (hipStream_t) stream);
+}
+
+int vkv_distance_map(vkv_ctx *ctx, uint8_t *d_map, uint8_t *d_swap, VkvExtent3D map_extent, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (!d_map || !d_swap || d_map == d_swap)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "distance_map: null or aliased buffers");
+	return launch_distance_map(ctx, d_map, d_swap, map_extent, (hipStream_t) stream);
+}
+
+int vkv_distance_map_anisotropic(vkv_ctx *ctx, uint8_t *const d_maps[8], uint8_t *d_swap, VkvExtent3D map_extent, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (!d_maps || !d_swap)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "distance_map_anisotropic: null pointer");
+	for (int i = 0; i < 8; ++i)
+		if (!d_maps[i] || d_maps[i] == d_swap)
+			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "distance_map_anisotropic: map %d null or aliasing swap", i);
+	return launch_distance_map_anisotropic(ctx, d_maps, d_swap, map_extent, (hipStream_t) stream);
+}
+
+// src/compute_distance_map.cpp:65-101
+int vkv_compute_distance_map(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_t *d_gradient, const uint8_t *d_tf, const VkvTransferFunctionUniform *tf,
+                             VkvExtent3D extent, uint8_t *const d_maps[8], uint8_t *d_swap, VkvExtent3D map_extent, int32_t skipping_type, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (skipping_type < VKV_SKIP_NONE || skipping_type > VKV_SKIP_ANISOTROPIC_DISTANCE || !d_maps)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "compute_distance_map: bad skipping_type or null maps");
+	const bool aniso = skipping_type == VKV_SKIP_ANISOTROPIC_DISTANCE;
+	const int  n     = aniso ? 8 : 1;
+	int        rc    = vkv_occupancy_map(ctx, d_volume, d_gradient, d_tf, tf, extent, d_maps[n - 1], map_extent, stream);
+	if (rc)
+		return rc;
+	if (aniso)
+		return vkv_distance_map_anisotropic(ctx, d_maps, d_swap, map_extent, stream);
+	if (skipping_type == VKV_SKIP_DISTANCE)
+		return vkv_distance_map(ctx, d_maps[0], d_swap, map_extent, stream);
+	return VKV_OK;        // None / Block use the raw 0/255 occupancy map (:96-99)
+}
+
+int vkv_render(vkv_ctx *ctx, const VkvRenderParams *P, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (!P)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: null params");
+	const VkvRenderOptions &o = P->options;
+	if (o.depth_attachment)
+		return set_error(ctx, VKV_E_UNSUPPORTED, "render: depth_attachment input is not implemented (SURVEY.md 8f row 4)");
+	if (o.test < VKV_TEST_NONE || o.test > VKV_TEST_NUM_TEXTURE_SAMPLES)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: bad test mode %d", o.test);
+	if (o.skipping_type < VKV_SKIP_NONE || o.skipping_type > VKV_SKIP_ANISOTROPIC_DISTANCE)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: bad skipping_type %d", o.skipping_type);
+	if (!extent_ok(P->volume_extent) || P->image_width == 0 || P->image_height == 0)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: zero extent");
+	if (!P->d_volume || !P->d_transfer_function)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: null volume or transfer function");
+	if (P->transfer_function.use_gradient && P->use_precomputed_gradient && !P->d_gradient)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: precomputed gradient requested but d_gradient is null");
+	if (!(P->transfer_function.sampling_factor > 0.0f))
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: sampling_factor must be positive");
+	if (o.skipping_type != VKV_SKIP_NONE)
+	{
+		if (!map_extent_ok(P->volume_extent, P->map_extent))
+			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: bad map extent");
+		const int n = o.skipping_type == VKV_SKIP_ANISOTROPIC_DISTANCE ? 8 : 1;
+		for (int i = 0; i < n; ++i)
+			if (!P->d_distance_maps[i])
+				return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: distance map %d is null", i);
+	}
+	const VkvTileSchedule &t = P->tiles;
+	if (t.tile_width == 0 || t.tile_height == 0 || (t.tile_width % 16) || (t.tile_height % 16) || t.tile_stride == 0)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: tile size must be a positive multiple of 16 and tile_stride > 0");
+	{
+		const uint64_t tiles_x = (P->image_width + t.tile_width - 1) / t.tile_width, tiles_y = (P->image_height + t.tile_height - 1) / t.tile_height;
+		if (t.tile_count && (uint64_t) t.tile_first + (uint64_t) (t.tile_count - 1) * t.tile_stride >= tiles_x * tiles_y)
+			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: tile schedule runs past the image");
+	}
+	if (!P->d_out_color && !P->d_out_rgba8 && !P->d_out_counts && !P->d_out_depth)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: no output buffer");
+
+	// opacity-correction table keyed by the TF alpha byte (frag:283):
+	// lut[a] = clamp(voxel_alpha_factor * (1 - pow(1 - a/255, 1/sampling_factor)), 0, 1)
+	float       lut[256];
+	const float sf_inv = 1.0f / P->transfer_function.sampling_factor;
+	for (int a = 0; a < 256; ++a)
+	{
+		const float v = P->transfer_function.voxel_alpha_factor * (1.0f - std::pow(1.0f - (float) a / 255.0f, sf_inv));
+		lut[a]        = std::min(std::max(v, 0.0f), 1.0f);
+	}
+	return launch_render(ctx, P, lut, (hipStream_t) stream);
+}
+
+int vkv_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, uint32_t image_width, uint32_t image_height, uint32_t tile_width,
+                      uint32_t tile_height, uint32_t n_ranks, uint32_t tiles_per_rank, uint32_t bytes_per_pixel, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (!d_gathered || !d_image || !image_width || !image_height || !tile_width || !tile_height || !n_ranks)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "scatter_tiles: null pointer or zero size");
+	const uint64_t tiles = (uint64_t) ((image_width + tile_width - 1) / tile_width) * ((image_height + tile_height - 1) / tile_height);
+	if ((uint64_t) tiles_per_rank * n_ranks < tiles)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "scatter_tiles: gathered buffer holds fewer tiles than the image");
+	return launch_scatter_tiles(ctx, d_gathered, d_image, image_width, image_height, tile_width, tile_height, n_ranks, tiles_per_rank, bytes_per_pixel,
+	                            (hipStream_t) stream);
+}
+
+int vkv_synth_volume(vkv_ctx *ctx, uint8_t *d_volume, VkvExtent3D extent, uint32_t kind, uint32_t seed, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (!d_volume || !extent_ok(extent))
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "synth_volume: null pointer or zero extent");
+	return launch_synth_volume(ctx, d_volume, extent, kind, seed, (hipStream_t) stream);
+}
+
+}        // extern "C"

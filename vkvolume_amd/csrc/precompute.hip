@@ -1,0 +1,492 @@
+// precompute.hip — gradient map, occupancy map and Chebyshev distance transforms for gfx950.
+//
+// Replaces ComputeGradientMap / ComputeDistanceMap (src/compute_gradient_map.cpp, src/compute_distance_map.cpp)
+// and their shaders (gradient_map.comp, occupancy_map.comp, distance_map.comp, distance_map_anisotropic.comp).
+// All kernels are integer/byte streaming work bound by HBM / LDS bandwidth; no MFMA.
+#include "vkv_device.hpp"
+
+using namespace vkv;
+
+// ---------------------------------------------------------------------------------------------
+// Gradient map (shaders/gradient_map.comp:35-41)
+// ---------------------------------------------------------------------------------------------
+// One thread per voxel, x fastest so every load/store of a wave is one contiguous 64-byte row segment.
+// The four taps sit on the (±1,±1,±1) tetrahedron, i.e. in four different (y,z) rows; L1/L2 absorb the
+// 4x re-read (each byte is requested by the 4 voxels diagonal to it).
+__global__ void __launch_bounds__(256) k_gradient_map(const uint8_t *__restrict__ vol, uint8_t *__restrict__ grad, int W, int H, int D,
+                                                      int use_gradient, float modifier, uint32_t blocks_x, uint32_t nblocks)
+{
+	const uint32_t b  = xcd_remap(blockIdx.x, nblocks);
+	const uint32_t bx = b % blocks_x;
+	const uint32_t r  = b / blocks_x;        // (y, z) row group: 4 rows per block
+	const int      x  = (int) (bx * 64 + (threadIdx.x & 63));
+	const uint32_t row = r * 4 + (threadIdx.x >> 6);
+	if (x >= W || row >= (uint32_t) H * (uint32_t) D)
+		return;
+	const int y = (int) (row % (uint32_t) H), z = (int) (row / (uint32_t) H);
+	float     g = 1.0f;        // get_gradient_compute.glsl:6-7
+	if (use_gradient)
+		g = gradient_on_the_fly(vol, W, H, D, x, y, z, modifier);
+	grad[vidx(x, y, z, W, H)] = store_unorm8(g);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Occupancy map (shaders/occupancy_map.comp:45-73)
+// ---------------------------------------------------------------------------------------------
+// alpha > 0 is a pure function of (gradient texel, intensity texel) of the NEAREST-sampled TF texture, so the
+// 256x256 alpha channel is first reduced to a 1-bit table (8 KiB) that every block stages in LDS.
+__global__ void __launch_bounds__(256) k_tf_bits(const uint8_t *__restrict__ tf_rgba8, uint32_t *__restrict__ bits)
+{
+	const uint32_t w = blockIdx.x * 256 + threadIdx.x;        // 2048 words
+	if (w >= 2048)
+		return;
+	uint32_t v = 0;
+	for (int i = 0; i < 32; ++i)
+		v |= (tf_rgba8[((size_t) w * 32 + i) * 4 + 3] > 0 ? 1u : 0u) << i;
+	bits[w] = v;
+}
+
+// Block = 256 threads = 256 consecutive voxels in x of one cell row (cy, cz); it walks the by*bz voxel rows of
+// that cell row, every load being a coalesced 64-byte segment per wave, ORs "occupied" into one LDS flag per cell.
+// GRAD: 0 = use_gradient false (gradient = 1.0), 1 = precomputed map, 2 = on-the-fly tetrahedron.
+template <int GRAD>
+__global__ void __launch_bounds__(256) k_occupancy_map(const uint8_t *__restrict__ vol, const uint8_t *__restrict__ grad,
+                                                       const uint32_t *__restrict__ tf_bits, uint8_t *__restrict__ map, int W, int H, int D,
+                                                       int mw, int mh, int md, int bx, int by, int bz, float modifier, uint32_t blocks_x)
+{
+	__shared__ uint32_t s_bits[2048];
+	__shared__ uint32_t s_cell[256];
+	for (int i = threadIdx.x; i < 2048; i += 256)
+		s_bits[i] = tf_bits[i];
+	s_cell[threadIdx.x] = 0;
+	__syncthreads();
+
+	const uint32_t b   = blockIdx.x;
+	const uint32_t bxi = b % blocks_x;
+	const uint32_t r   = b / blocks_x;
+	const int      cy = (int) (r % (uint32_t) mh), cz = (int) (r / (uint32_t) mh);
+	// the block covers cells [c0, c0 + cells_per_block) of this cell row
+	const int cells_per_block = 256 / bx > 0 ? 256 / bx : 1;
+	const int c0              = (int) bxi * cells_per_block;
+	const int x0              = c0 * bx;
+	const int span            = cells_per_block * bx;        // voxels handled per pass (<= 256 unless bx > 256)
+	const int y_end = min((cy + 1) * by, H), z_end = min((cz + 1) * bz, D);
+
+	uint32_t occ = 0;
+	for (int lx = threadIdx.x; lx < span; lx += 256)
+	{
+		const int x = x0 + lx;
+		if (x >= W)
+			break;
+		occ = 0;
+		for (int z = cz * bz; z < z_end; ++z)
+			for (int y = cy * by; y < y_end; ++y)
+			{
+				const size_t   o = vidx(x, y, z, W, H);
+				const uint32_t v = vol[o];
+				uint32_t       g;
+				if (GRAD == 1)
+					g = grad[o];        // unorm8 byte: NEAREST lookup of b/255 lands on texel b
+				else if (GRAD == 2)
+					g = (uint32_t) tf_texel(gradient_on_the_fly(vol, W, H, D, x, y, z, modifier));
+				else
+					g = 255;        // gradient = 1.0 -> texel 255
+				const uint32_t bit = g * 256 + v;
+				occ |= (s_bits[bit >> 5] >> (bit & 31)) & 1u;
+			}
+		if (occ)
+			s_cell[lx / bx] = 1;        // benign race: every writer stores 1
+	}
+	__syncthreads();
+	const int c = c0 + (int) threadIdx.x;
+	if ((int) threadIdx.x < cells_per_block && c < mw)
+		map[vidx(c, cy, cz, mw, mh)] = s_cell[threadIdx.x] ? 0 : 255;        // OCCUPIED = 0, EMPTY = 255
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chebyshev distance transform (shaders/distance_map.comp, distance_map_anisotropic.comp)
+// ---------------------------------------------------------------------------------------------
+// x pass.  One wave stages 64 rows in LDS (coalesced), each lane scans one row serially out of LDS (row stride
+// chosen so the 64 lanes hit distinct banks), then the rows are written back coalesced.
+// MODE 0: isotropic two-sided in-place scan (distance_map.comp:57-71);
+// MODE +1 / -1: one-sided scan of the anisotropic shader (distance_map_anisotropic.comp:44-53).
+template <int MODE>
+__global__ void __launch_bounds__(64) k_dm_x(const uint8_t *src, uint8_t *dst, int mw, uint32_t n_rows, int stride)        // src may alias dst (in-place)
+{
+	extern __shared__ __align__(16) uint8_t s_rows[];
+	const uint32_t row0 = blockIdx.x * 64;
+	const int      lane = threadIdx.x;
+	const uint32_t rows = min(64u, n_rows - row0);
+	for (uint32_t r = 0; r < rows; ++r)
+	{
+		const uint8_t *g = src + (size_t) (row0 + r) * (size_t) mw;
+		for (int x = lane; x < mw; x += 64)
+			s_rows[r * stride + x] = g[x];
+	}
+	__syncthreads();
+	if ((uint32_t) lane < rows)
+	{
+		uint8_t *row = s_rows + lane * stride;
+		if (MODE == 0)
+		{
+			uint32_t g1 = row[0];
+			for (int x = 1; x < mw; ++x)
+			{
+				const uint32_t g = min(g1 + 1, (uint32_t) row[x]);
+				row[x]           = (uint8_t) g;
+				g1               = g;
+			}
+			for (int x = mw - 2; x >= 0; --x)
+			{
+				const uint32_t g = min(g1 + 1, (uint32_t) row[x]);
+				row[x]           = (uint8_t) g;
+				g1               = g;
+			}
+		}
+		else
+		{
+			const int start = MODE > 0 ? mw - 1 : 0, end = MODE > 0 ? -1 : mw;
+			uint32_t  g1    = row[start];
+			for (int x = start; x != end; x -= MODE)
+			{
+				const uint32_t g = min(g1 + 1, (uint32_t) row[x]);
+				row[x]           = (uint8_t) g;
+				g1               = g;
+			}
+		}
+	}
+	__syncthreads();
+	for (uint32_t r = 0; r < rows; ++r)
+	{
+		uint8_t *g = dst + (size_t) (row0 + r) * (size_t) mw;
+		for (int x = lane; x < mw; x += 64)
+			g[x] = s_rows[r * stride + x];
+	}
+}
+
+// y / z pass: D(p) = min_n max(|n|, g(p + n)) along one axis (two-sided, MODE 0: distance_map.comp:72-107) or over
+// n >= 0 in direction MODE = ±1 (distance_map_anisotropic.comp:55-91).  A block stages a strip of 64 x-columns by
+// the whole axis in LDS (64-byte rows: every global access is coalesced, LDS reads of a wave hit 16 consecutive
+// banks with 4-lane broadcast) and 256 threads split the axis in four.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_dm_axis(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int mw, int len, size_t axis_stride,
+                                                 size_t other_stride, uint32_t chunks_x)
+{
+	extern __shared__ __align__(16) uint8_t s_strip[];        // [len][64]
+	const uint32_t cx    = blockIdx.x % chunks_x;
+	const uint32_t other = blockIdx.x / chunks_x;
+	const int      lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+	const int      x    = (int) cx * 64 + lane;
+	const bool     live = x < mw;
+	const size_t   base = (size_t) other * other_stride + (size_t) x;
+	for (int p = part; p < len; p += 4)
+		s_strip[p * 64 + lane] = live ? src[base + (size_t) p * axis_stride] : 255;
+	__syncthreads();
+	if (!live)
+		return;
+	for (int p = part; p < len; p += 4)
+	{
+		uint32_t m = s_strip[p * 64 + lane];
+		if (MODE == 0)
+		{
+			for (int n = 1; (uint32_t) n < m; ++n)
+			{
+				if (p >= n)
+					m = min(m, max((uint32_t) n, (uint32_t) s_strip[(p - n) * 64 + lane]));
+				if (p + n < len && (uint32_t) n < m)
+					m = min(m, max((uint32_t) n, (uint32_t) s_strip[(p + n) * 64 + lane]));
+			}
+		}
+		else
+		{
+			for (int n = 1; (uint32_t) n < m && n < 255; ++n)
+			{
+				const int q = p + MODE * n;
+				if (q < 0 || q >= len)
+					break;
+				m = min(m, max((uint32_t) n, (uint32_t) s_strip[q * 64 + lane]));
+			}
+		}
+		dst[base + (size_t) p * axis_stride] = (uint8_t) m;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic volumes (DESIGN.md "Synthetic inputs")
+// ---------------------------------------------------------------------------------------------
+struct SynthShell
+{
+	float cx, cy, cz, irx, iry, irz, slope, amp, lo2, hi2;
+};
+constexpr int kSynthShells = 40;
+struct SynthArgs
+{
+	SynthShell sh[kSynthShells];
+};
+
+__device__ __forceinline__ uint32_t synth_hash(uint32_t seed, uint32_t x, uint32_t y, uint32_t z)
+{
+	uint32_t h = seed ^ (x * 0x8da6b343u) ^ (y * 0xd8163841u) ^ (z * 0xcb1ab31fu);
+	h ^= h >> 16;
+	h *= 0x7feb352du;
+	h ^= h >> 15;
+	h *= 0x846ca68bu;
+	h ^= h >> 16;
+	return h;
+}
+
+__global__ void __launch_bounds__(256) k_synth_sphere(uint8_t *__restrict__ vol, int W, int H, int D, uint32_t blocks_x)
+{
+	const uint32_t bx  = blockIdx.x % blocks_x;
+	const uint32_t row = (blockIdx.x / blocks_x) * 4 + (threadIdx.x >> 6);
+	const int      x   = (int) (bx * 64 + (threadIdx.x & 63));
+	if (x >= W || row >= (uint32_t) H * (uint32_t) D)
+		return;
+	const int   y = (int) (row % (uint32_t) H), z = (int) (row / (uint32_t) H);
+	const float dm = (float) max(max(W, H), D);
+	const float R0 = 0.375f * dm, R1 = 0.25f * dm;
+	const float cx = ((float) W - 1.0f) * 0.5f, cy = ((float) H - 1.0f) * 0.5f, cz = ((float) D - 1.0f) * 0.5f;
+	const float dx = (float) x - cx, dy = (float) y - cy, dz = (float) z - cz;
+	const float r  = __builtin_sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+	const float t  = g_clamp((R0 - r) / (R0 - R1), 0.0f, 1.0f);
+	vol[vidx(x, y, z, W, H)] = (uint8_t) __builtin_rintf(255.0f * t);
+}
+
+__global__ void __launch_bounds__(256) k_synth_shells(uint8_t *__restrict__ vol, int W, int H, int D, uint32_t seed, uint32_t blocks_x, SynthArgs args)
+{
+	__shared__ SynthShell s_sh[kSynthShells];
+	for (int i = threadIdx.x; i < kSynthShells * 10; i += 256)
+		reinterpret_cast<float *>(s_sh)[i] = reinterpret_cast<const float *>(args.sh)[i];
+	__syncthreads();
+	const uint32_t bx  = blockIdx.x % blocks_x;
+	const uint32_t row = (blockIdx.x / blocks_x) * 4 + (threadIdx.x >> 6);
+	const int      x   = (int) (bx * 64 + (threadIdx.x & 63));
+	if (x >= W || row >= (uint32_t) H * (uint32_t) D)
+		return;
+	const int y = (int) (row % (uint32_t) H), z = (int) (row / (uint32_t) H);
+	float     best = 0.0f;
+	for (int k = 0; k < kSynthShells; ++k)
+	{
+		const float dx = ((float) x - s_sh[k].cx) * s_sh[k].irx;
+		const float dy = ((float) y - s_sh[k].cy) * s_sh[k].iry;
+		const float dz = ((float) z - s_sh[k].cz) * s_sh[k].irz;
+		const float q2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+		if (q2 > s_sh[k].lo2 && q2 < s_sh[k].hi2)
+		{
+			const float q   = __builtin_sqrtf(q2);
+			const float val = s_sh[k].amp * (1.0f - __builtin_fabsf(q - 1.0f) * s_sh[k].slope);
+			if (val > best)
+				best = val;
+		}
+	}
+	const uint32_t noise = synth_hash(seed, (uint32_t) x, (uint32_t) y, (uint32_t) z) % 21u;
+	const uint32_t v     = (uint32_t) best + noise;
+	vol[vidx(x, y, z, W, H)] = (uint8_t) min(v, 255u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU: de-interleave gathered compact tile buffers into the final image (one thread per pixel)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_scatter_tiles(const T *__restrict__ gathered, T *__restrict__ image, uint32_t iw, uint32_t ih,
+                                                       uint32_t tw, uint32_t th, uint32_t n_ranks, uint32_t tiles_per_rank)
+{
+	const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+	const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+	if (x >= iw || y >= ih)
+		return;
+	const uint32_t tiles_x = (iw + tw - 1) / tw;
+	const uint32_t t       = (y / th) * tiles_x + (x / tw);
+	const uint32_t rank = t % n_ranks, k = t / n_ranks;
+	const size_t   src = (((size_t) rank * tiles_per_rank + k) * th + (y % th)) * tw + (x % tw);
+	image[(size_t) y * iw + x] = gathered[src];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------------------------
+namespace vkv
+{
+
+int launch_gradient_map(vkv_ctx *ctx, const uint8_t *d_vol, uint8_t *d_grad, VkvExtent3D e, const VkvTransferFunctionUniform *tf, hipStream_t s)
+{
+	const uint32_t blocks_x = (e.width + 63) / 64;
+	const uint64_t rows     = (uint64_t) e.height * e.depth;
+	const uint64_t nblocks  = blocks_x * ((rows + 3) / 4);
+	if (nblocks > 0x7fffffffull)
+		return set_error(ctx, VKV_E_UNSUPPORTED, "gradient_map: volume too large for one launch");
+	hipLaunchKernelGGL(k_gradient_map, dim3((uint32_t) nblocks), dim3(256), 0, s, d_vol, d_grad, (int) e.width, (int) e.height, (int) e.depth,
+	                   (int) (tf->use_gradient != 0), tf->grad_magnitude_modifier, blocks_x, (uint32_t) nblocks);
+	return check_launch(ctx, "gradient_map");
+}
+
+int launch_occupancy_map(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_grad, const uint8_t *d_tf, const VkvTransferFunctionUniform *tf,
+                         VkvExtent3D e, uint8_t *d_map, VkvExtent3D me, hipStream_t s)
+{
+	uint32_t *d_bits = reinterpret_cast<uint32_t *>(ctx->d_workspace + kTfBitsOffset);
+	hipLaunchKernelGGL(k_tf_bits, dim3(8), dim3(256), 0, s, d_tf, d_bits);
+	// src/compute_distance_map.cpp:110-113
+	const int bx = (int) ((e.width + me.width - 1) / me.width), by = (int) ((e.height + me.height - 1) / me.height),
+	          bz = (int) ((e.depth + me.depth - 1) / me.depth);
+	const int      cells_per_block = 256 / bx > 0 ? 256 / bx : 1;
+	const uint32_t blocks_x        = (me.width + cells_per_block - 1) / cells_per_block;
+	const uint64_t nblocks         = (uint64_t) blocks_x * me.height * me.depth;
+	if (nblocks > 0x7fffffffull)
+		return set_error(ctx, VKV_E_UNSUPPORTED, "occupancy_map: map too large for one launch");
+	const int W = (int) e.width, H = (int) e.height, D = (int) e.depth, mw = (int) me.width, mh = (int) me.height, md = (int) me.depth;
+	if (!tf->use_gradient)
+		hipLaunchKernelGGL(k_occupancy_map<0>, dim3((uint32_t) nblocks), dim3(256), 0, s, d_vol, d_grad, d_bits, d_map, W, H, D, mw, mh, md, bx, by,
+		                   bz, tf->grad_magnitude_modifier, blocks_x);
+	else if (d_grad)
+		hipLaunchKernelGGL(k_occupancy_map<1>, dim3((uint32_t) nblocks), dim3(256), 0, s, d_vol, d_grad, d_bits, d_map, W, H, D, mw, mh, md, bx, by,
+		                   bz, tf->grad_magnitude_modifier, blocks_x);
+	else
+		hipLaunchKernelGGL(k_occupancy_map<2>, dim3((uint32_t) nblocks), dim3(256), 0, s, d_vol, d_grad, d_bits, d_map, W, H, D, mw, mh, md, bx, by,
+		                   bz, tf->grad_magnitude_modifier, blocks_x);
+	return check_launch(ctx, "occupancy_map");
+}
+
+static int row_stride_for(int mw)
+{
+	int s4 = (mw + 3) / 4 + 1;
+	if ((s4 & 1) == 0)
+		++s4;        // odd dword stride: the 64 lanes of a scan hit distinct banks
+	return s4 * 4;
+}
+
+template <int MODE>
+static int launch_dm_x(vkv_ctx *ctx, const uint8_t *src, uint8_t *dst, VkvExtent3D me, hipStream_t s)
+{
+	const uint32_t n_rows = me.height * me.depth;
+	const int      stride = row_stride_for((int) me.width);
+	const size_t   lds    = (size_t) stride * 64;
+	if (lds > 64 * 1024)
+		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dm_x<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+	hipLaunchKernelGGL(k_dm_x<MODE>, dim3((n_rows + 63) / 64), dim3(64), lds, s, src, dst, (int) me.width, n_rows, stride);
+	return check_launch(ctx, "distance_map x pass");
+}
+
+// axis: 1 = y, 2 = z
+template <int MODE>
+static int launch_dm_axis(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *dst, VkvExtent3D me, hipStream_t s)
+{
+	const uint32_t chunks_x = (me.width + 63) / 64;
+	const size_t   sy = me.width, sz = (size_t) me.width * me.height;
+	const int      len   = axis == 1 ? (int) me.height : (int) me.depth;
+	const uint32_t other = axis == 1 ? me.depth : me.height;
+	if ((size_t) len * 64 > 64 * 1024)
+		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dm_axis<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, len * 64);
+	hipLaunchKernelGGL(k_dm_axis<MODE>, dim3(chunks_x * other), dim3(256), (size_t) len * 64, s, src, dst, (int) me.width, len, axis == 1 ? sy : sz,
+	                   axis == 1 ? sz : sy, chunks_x);
+	return check_launch(ctx, "distance_map axis pass");
+}
+
+static int dm_check_extent(vkv_ctx *ctx, VkvExtent3D me)
+{
+	if (me.width == 0 || me.height == 0 || me.depth == 0)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "distance_map: zero map extent");
+	if (me.width > 2048 || me.height > 2048 || me.depth > 2048)
+		return set_error(ctx, VKV_E_UNSUPPORTED, "distance_map: map axis longer than 2048 cells (LDS strip limit)");
+	return VKV_OK;
+}
+
+// src/compute_distance_map.cpp:142-175
+int launch_distance_map(vkv_ctx *ctx, uint8_t *d_map, uint8_t *d_swap, VkvExtent3D me, hipStream_t s)
+{
+	int rc = dm_check_extent(ctx, me);
+	if (rc) return rc;
+	if ((rc = launch_dm_x<0>(ctx, d_map, d_map, me, s))) return rc;
+	if ((rc = launch_dm_axis<0>(ctx, 1, d_map, d_swap, me, s))) return rc;
+	return launch_dm_axis<0>(ctx, 2, d_swap, d_map, me, s);
+}
+
+// src/compute_distance_map.cpp:201-252 — same buffers, same order (stream order replaces the image barriers)
+int launch_distance_map_anisotropic(vkv_ctx *ctx, uint8_t *const m[8], uint8_t *swap, VkvExtent3D me, hipStream_t s)
+{
+	int rc = dm_check_extent(ctx, me);
+	if (rc) return rc;
+	const uint8_t *occ = m[7];
+	if ((rc = launch_dm_x<1>(ctx, occ, m[3], me, s))) return rc;                  // stage1(3, +1)
+	if ((rc = launch_dm_axis<1>(ctx, 1, m[3], swap, me, s))) return rc;           // stage2(3, +1)
+	if ((rc = launch_dm_axis<1>(ctx, 2, swap, m[0], me, s))) return rc;           // stage3(0, +1)
+	if ((rc = launch_dm_axis<-1>(ctx, 2, swap, m[1], me, s))) return rc;          // stage3(1, -1)
+	if ((rc = launch_dm_axis<-1>(ctx, 1, m[3], swap, me, s))) return rc;          // stage2(3, -1)
+	if ((rc = launch_dm_axis<1>(ctx, 2, swap, m[2], me, s))) return rc;           // stage3(2, +1)
+	if ((rc = launch_dm_axis<-1>(ctx, 2, swap, m[3], me, s))) return rc;          // stage3(3, -1)
+	if ((rc = launch_dm_x<-1>(ctx, occ, m[7], me, s))) return rc;                 // stage1(7, -1) in place
+	if ((rc = launch_dm_axis<1>(ctx, 1, m[7], swap, me, s))) return rc;           // stage2(7, +1)
+	if ((rc = launch_dm_axis<1>(ctx, 2, swap, m[4], me, s))) return rc;           // stage3(4, +1)
+	if ((rc = launch_dm_axis<-1>(ctx, 2, swap, m[5], me, s))) return rc;          // stage3(5, -1)
+	if ((rc = launch_dm_axis<-1>(ctx, 1, m[7], swap, me, s))) return rc;          // stage2(7, -1)
+	if ((rc = launch_dm_axis<1>(ctx, 2, swap, m[6], me, s))) return rc;           // stage3(6, +1)
+	return launch_dm_axis<-1>(ctx, 2, swap, m[7], me, s);                         // stage3(7, -1)
+}
+
+// --- synthetic volume: host builds the shell table (same definition as DESIGN.md "Synthetic inputs") ---
+static uint64_t splitmix64(uint64_t *s)
+{
+	uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+	z          = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z          = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+static float u01(uint64_t *s) { return (float) (splitmix64(s) >> 40) * (1.0f / 16777216.0f); }
+
+int launch_synth_volume(vkv_ctx *ctx, uint8_t *d_vol, VkvExtent3D e, uint32_t kind, uint32_t seed, hipStream_t s)
+{
+	const uint32_t blocks_x = (e.width + 63) / 64;
+	const uint64_t rows     = (uint64_t) e.height * e.depth;
+	const uint64_t nblocks  = blocks_x * ((rows + 3) / 4);
+	if (nblocks > 0x7fffffffull)
+		return set_error(ctx, VKV_E_UNSUPPORTED, "synth_volume: volume too large for one launch");
+	const int W = (int) e.width, H = (int) e.height, D = (int) e.depth;
+	if (kind == 0)
+	{
+		hipLaunchKernelGGL(k_synth_sphere, dim3((uint32_t) nblocks), dim3(256), 0, s, d_vol, W, H, D, blocks_x);
+		return check_launch(ctx, "synth_volume");
+	}
+	if (kind != 1)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "synth_volume: unknown kind %u", kind);
+	SynthArgs   args;
+	uint64_t    st = (0x5EEDull << 32) | (uint64_t) seed;
+	const float Wf = (float) e.width, Hf = (float) e.height, Df = (float) e.depth;
+	const float dm = fmaxf(fmaxf(Wf, Hf), Df);
+	const float th = 0.001f * dm + 1.0f;
+	for (int k = 0; k < kSynthShells; ++k)
+	{
+		SynthShell &sh = args.sh[k];
+		sh.cx          = (0.15f + 0.70f * u01(&st)) * Wf;
+		sh.cy          = (0.15f + 0.70f * u01(&st)) * Hf;
+		sh.cz          = (0.15f + 0.70f * u01(&st)) * Df;
+		const float r  = (0.05f + 0.13f * u01(&st)) * dm;
+		const float rx = r * (0.7f + 0.6f * u01(&st));
+		const float ry = r * (0.7f + 0.6f * u01(&st));
+		const float rz = r * (0.7f + 0.6f * u01(&st));
+		sh.irx = 1.0f / rx, sh.iry = 1.0f / ry, sh.irz = 1.0f / rz;
+		sh.slope       = fminf(fminf(rx, ry), rz) / th;
+		sh.amp         = 110.0f + 145.0f * u01(&st);
+		const float w  = 1.0f / sh.slope + 0.001f;
+		const float lo = 1.0f - w, hi = 1.0f + w;
+		sh.lo2 = lo > 0.0f ? lo * lo : 0.0f;
+		sh.hi2 = hi * hi;
+	}
+	hipLaunchKernelGGL(k_synth_shells, dim3((uint32_t) nblocks), dim3(256), 0, s, d_vol, W, H, D, seed, blocks_x, args);
+	return check_launch(ctx, "synth_volume");
+}
+
+int launch_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, uint32_t iw, uint32_t ih, uint32_t tw, uint32_t th, uint32_t n_ranks,
+                         uint32_t tiles_per_rank, uint32_t bpp, hipStream_t s)
+{
+	const dim3 grid((iw + 63) / 64, (ih + 3) / 4);
+	if (bpp == 4)
+		hipLaunchKernelGGL(k_scatter_tiles<uint32_t>, grid, dim3(256), 0, s, (const uint32_t *) d_gathered, (uint32_t *) d_image, iw, ih, tw, th, n_ranks,
+		                   tiles_per_rank);
+	else if (bpp == 16)
+		hipLaunchKernelGGL(k_scatter_tiles<uint4>, grid, dim3(256), 0, s, (const uint4 *) d_gathered, (uint4 *) d_image, iw, ih, tw, th, n_ranks,
+		                   tiles_per_rank);
+	else
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "scatter_tiles: bytes_per_pixel must be 4 or 16");
+	return check_launch(ctx, "scatter_tiles");
+}
+
+}        // namespace vkv

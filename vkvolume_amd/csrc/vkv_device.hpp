@@ -1,0 +1,89 @@
+// vkv_device.hpp — shared device-side definitions for the gfx950 kernels.
+//
+// The arithmetic below is the product's definition of the numerics the reference leaves to the Vulkan
+// implementation (DESIGN.md "Pinned numerics"): fp32 only, no implicit contraction (the library is
+// built with -ffp-contract=off), fused multiply-adds only where __builtin_fmaf is written out,
+// IEEE-correct division and square root (-fhip-fp32-correctly-rounded-divide-sqrt).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vkvolume_amd.h"
+
+namespace vkv
+{
+
+// GLSL built-ins with specification semantics (min(x,y) = y<x ? y : x, ...).
+__device__ __forceinline__ float g_min(float x, float y) { return (y < x) ? y : x; }
+__device__ __forceinline__ float g_max(float x, float y) { return (x < y) ? y : x; }
+__device__ __forceinline__ float g_clamp(float x, float lo, float hi) { return g_min(g_max(x, lo), hi); }
+__device__ __forceinline__ float g_step(float edge, float x) { return (x < edge) ? 0.0f : 1.0f; }
+__device__ __forceinline__ float g_sign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+__device__ __forceinline__ int   i_clamp(int x, int lo, int hi) { return min(max(x, lo), hi); }
+
+constexpr float kInv255 = 1.0f / 255.0f;
+
+__device__ __forceinline__ size_t vidx(int x, int y, int z, int W, int H)
+{
+	return ((size_t) z * (size_t) H + (size_t) y) * (size_t) W + (size_t) x;
+}
+
+// R8_UNORM texel -> float: exactly byte / 255 (IEEE division).
+__device__ __forceinline__ float unorm8(uint32_t b) { return (float) b / 255.0f; }
+
+// NEAREST lookup coordinate of the 256-wide TF texture (sampler: src/volume_component.cpp:149-151).
+__device__ __forceinline__ int tf_texel(float u) { return i_clamp((int) __builtin_floorf(u * 256.0f), 0, 255); }
+
+// Tetrahedron gradient on integer texels, shaders/get_gradient_compute.glsl:12-20; returns the float in [0,1]
+// before the UNORM store.  Term order k.xyy, k.yyx, k.yxy, k.xxx, sums left to right.
+__device__ __forceinline__ float gradient_from_taps(float v1, float v2, float v3, float v4, float modifier)
+{
+	const float gx  = 0.25f * (((v1 - v2) - v3) + v4);
+	const float gy  = 0.25f * (((-v1 - v2) + v3) + v4);
+	const float gz  = 0.25f * (((-v1 + v2) - v3) + v4);
+	const float len = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
+	return g_clamp(len * modifier, 0.0f, 1.0f);
+}
+
+__device__ __forceinline__ float gradient_on_the_fly(const uint8_t *__restrict__ vol, int W, int H, int D, int x, int y, int z, float modifier)
+{
+	const int   xm = max(x - 1, 0), xp = min(x + 1, W - 1);
+	const int   ym = max(y - 1, 0), yp = min(y + 1, H - 1);
+	const int   zm = max(z - 1, 0), zp = min(z + 1, D - 1);
+	const float v1 = unorm8(vol[vidx(xp, ym, zm, W, H)]);
+	const float v2 = unorm8(vol[vidx(xm, ym, zp, W, H)]);
+	const float v3 = unorm8(vol[vidx(xm, yp, zm, W, H)]);
+	const float v4 = unorm8(vol[vidx(xp, yp, zp, W, H)]);
+	return gradient_from_taps(v1, v2, v3, v4, modifier);
+}
+
+// R8_UNORM store: round to nearest even.
+__device__ __forceinline__ uint8_t store_unorm8(float g) { return (uint8_t) __builtin_rintf(g * 255.0f); }
+
+// XCD-aware block remap: hardware deals consecutive block ids round-robin over the 8 XCDs, so give each XCD a
+// contiguous range of logical ids (neighbouring screen tiles / slabs then share one L2).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb)
+{
+	const uint32_t q = nb >> 3, r = nb & 7u, xcd = b & 7u, idx = b >> 3;
+	return xcd * q + min(xcd, r) + idx;
+}
+
+}        // namespace vkv
+
+// Host-side context (capi.cpp owns it).
+struct vkv_ctx
+{
+	int      device;
+	char     error[512];
+	uint8_t *d_workspace;        // small device scratch: TF bit table (8 KiB)
+	size_t   workspace_bytes;
+};
+
+namespace vkv
+{
+int  set_error(vkv_ctx *ctx, int code, const char *fmt, ...);
+int  check_launch(vkv_ctx *ctx, const char *what);
+constexpr size_t kWorkspaceBytes = 64 * 1024;
+constexpr size_t kTfBitsOffset   = 0;        // 256*256 bits = 8 KiB
+}        // namespace vkv

@@ -1,0 +1,159 @@
+"""ctypes binding of ``csrc/libvkvolume_amd.so`` (the C ABI of ``include/vkvolume_amd.h``).
+
+There is no fallback: if the shared library is missing or a call fails, a ``VkvError`` is raised.
+"""
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvkvolume_amd.so")
+
+# every symbol include/vkvolume_amd.h declares
+EXPORTS = [
+    "vkv_create", "vkv_destroy", "vkv_last_error", "vkv_version",
+    "vkv_transfer_function_uniform", "vkv_transfer_function_texture", "vkv_build_uniforms",
+    "vkv_gradient_map", "vkv_occupancy_map", "vkv_distance_map", "vkv_distance_map_anisotropic",
+    "vkv_compute_distance_map", "vkv_render", "vkv_scatter_tiles", "vkv_synth_volume",
+]
+
+
+class VkvError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("vkvolume_amd error %d: %s" % (code, message))
+        self.code = code
+
+
+_LIB = None
+
+
+def load():
+    """Load the HIP library (once).  Raises VkvError if it has not been built — there is no CPU path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise VkvError(abi.VKV_E_NO_DEVICE, "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
+    P = C.POINTER
+    L.vkv_create.argtypes = [C.c_int, P(vp)]
+    L.vkv_destroy.argtypes = [vp]
+    L.vkv_destroy.restype = None
+    L.vkv_last_error.argtypes = [vp]
+    L.vkv_last_error.restype = C.c_char_p
+    L.vkv_version.restype = C.c_char_p
+    L.vkv_transfer_function_uniform.argtypes = [P(abi.VolumeOptions), P(abi.TransferFunctionUniform)]
+    L.vkv_transfer_function_texture.argtypes = [P(abi.VolumeOptions), vp]
+    L.vkv_build_uniforms.argtypes = [vp, vp, vp, vp, C.c_float, u32, u32, abi.Extent3D, abi.Extent3D,
+                                     P(abi.CameraUniform), P(abi.RayCastUniform), P(abi.RayGen)]
+    L.vkv_gradient_map.argtypes = [vp, vp, vp, abi.Extent3D, P(abi.TransferFunctionUniform), vp]
+    L.vkv_occupancy_map.argtypes = [vp, vp, vp, vp, P(abi.TransferFunctionUniform), abi.Extent3D, vp, abi.Extent3D, vp]
+    L.vkv_distance_map.argtypes = [vp, vp, vp, abi.Extent3D, vp]
+    L.vkv_distance_map_anisotropic.argtypes = [vp, P(vp), vp, abi.Extent3D, vp]
+    L.vkv_compute_distance_map.argtypes = [vp, vp, vp, vp, P(abi.TransferFunctionUniform), abi.Extent3D, P(vp), vp,
+                                           abi.Extent3D, i32, vp]
+    L.vkv_render.argtypes = [vp, P(abi.RenderParams), vp]
+    L.vkv_scatter_tiles.argtypes = [vp, vp, vp, u32, u32, u32, u32, u32, u32, u32, vp]
+    L.vkv_synth_volume.argtypes = [vp, vp, abi.Extent3D, u32, u32, vp]
+    for name in EXPORTS:
+        getattr(L, name)  # AttributeError here means the library does not export what the header declares
+    _LIB = L
+    return L
+
+
+class Context:
+    """RAII wrapper of ``vkv_ctx`` for one device."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.vkv_create(int(device), C.byref(h))
+        if rc != 0:
+            raise VkvError(rc, "vkv_create(device=%d) failed (no gfx950 device?)" % device)
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.vkv_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise VkvError(rc, self._lib.vkv_last_error(self.handle).decode(errors="replace"))
+
+    # ---- device entry points (pointers are ints / None; stream is a hipStream_t handle as int) ----
+    def gradient_map(self, d_volume, d_gradient, extent, tf, stream=0):
+        self.check(self._lib.vkv_gradient_map(self.handle, d_volume, d_gradient, extent, C.byref(tf), stream))
+
+    def occupancy_map(self, d_volume, d_gradient, d_tf, tf, extent, d_map, map_extent, stream=0):
+        self.check(self._lib.vkv_occupancy_map(self.handle, d_volume, d_gradient, d_tf, C.byref(tf), extent, d_map,
+                                               map_extent, stream))
+
+    def distance_map(self, d_map, d_swap, map_extent, stream=0):
+        self.check(self._lib.vkv_distance_map(self.handle, d_map, d_swap, map_extent, stream))
+
+    def distance_map_anisotropic(self, d_maps, d_swap, map_extent, stream=0):
+        arr = (C.c_void_p * 8)(*d_maps)
+        self.check(self._lib.vkv_distance_map_anisotropic(self.handle, arr, d_swap, map_extent, stream))
+
+    def compute_distance_map(self, d_volume, d_gradient, d_tf, tf, extent, d_maps, d_swap, map_extent, skipping_type, stream=0):
+        arr = (C.c_void_p * 8)(*(list(d_maps) + [None] * (8 - len(d_maps))))
+        self.check(self._lib.vkv_compute_distance_map(self.handle, d_volume, d_gradient, d_tf, C.byref(tf), extent, arr,
+                                                      d_swap, map_extent, skipping_type, stream))
+
+    def render(self, params, stream=0):
+        self.check(self._lib.vkv_render(self.handle, C.byref(params), stream))
+
+    def render_rc(self, params, stream=0):
+        """Like render() but returns the status code instead of raising (error-path tests)."""
+        return self._lib.vkv_render(self.handle, C.byref(params), stream)
+
+    def scatter_tiles(self, d_gathered, d_image, image_size, tile_size, n_ranks, tiles_per_rank, bytes_per_pixel, stream=0):
+        self.check(self._lib.vkv_scatter_tiles(self.handle, d_gathered, d_image, image_size[0], image_size[1], tile_size[0],
+                                               tile_size[1], n_ranks, tiles_per_rank, bytes_per_pixel, stream))
+
+    def synth_volume(self, d_volume, extent, kind, seed, stream=0):
+        self.check(self._lib.vkv_synth_volume(self.handle, d_volume, extent, kind, seed, stream))
+
+    def last_error(self):
+        return self._lib.vkv_last_error(self.handle).decode(errors="replace")
+
+
+# ---- host helpers (no device needed) --------------------------------------------------------------
+
+def transfer_function_uniform(options):
+    out = abi.TransferFunctionUniform()
+    rc = load().vkv_transfer_function_uniform(C.byref(options), C.byref(out))
+    if rc != 0:
+        raise VkvError(rc, "vkv_transfer_function_uniform")
+    return out
+
+
+def transfer_function_texture(options):
+    import numpy as np
+    tex = np.zeros((256, 256, 4), np.uint8)
+    rc = load().vkv_transfer_function_texture(C.byref(options), tex.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise VkvError(rc, "vkv_transfer_function_texture")
+    return tex
+
+
+def build_uniforms(view, proj, node_transform, image_transform, clip_distance, image_size, volume_extent, map_extent):
+    import numpy as np
+    cam, rc_, rg = abi.CameraUniform(), abi.RayCastUniform(), abi.RayGen()
+    mats = [np.ascontiguousarray(m, np.float32).reshape(16) for m in (view, proj, node_transform, image_transform)]
+    rc = load().vkv_build_uniforms(*[m.ctypes.data_as(C.c_void_p) for m in mats], clip_distance, image_size[0], image_size[1],
+                                   volume_extent, map_extent, C.byref(cam), C.byref(rc_), C.byref(rg))
+    if rc != 0:
+        raise VkvError(rc, "vkv_build_uniforms")
+    return cam, rc_, rg
