@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from vkvolume_amd import abi, camera, lib, volume as V  # noqa: E402
+from vkvolume_amd import abi, camera, lib, multigpu, volume as V  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
@@ -105,15 +105,13 @@ def main():
     opts = abi.RenderOptions(skipping_type=skip, clip_distance=1.0, early_ray_termination=True)
     sp = V.VolumeRenderSubpass(ctx, v, opts, (fw, fh))
     tiles = abi.full_frame_tiles(fw, fh, TILE, TILE, rank, world, compact=(world > 1))
-    total_tiles = ((fw + TILE - 1) // TILE) * ((fh + TILE - 1) // TILE)
-    tiles_per_rank = (total_tiles + world - 1) // world
     params = [sp.make_params(view, proj, tiles) for view, proj in views]
     my_pixels = tiles.tile_count * TILE * TILE if world > 1 else fw * fh
     rays_per_frame_all = fw * fh  # every pixel of the frame is a ray (covered or not), summed over ranks
 
     # ---- pre-pass (untimed): frag counters per view -> algorithmic bytes per launch ------------------------------
     counts = torch.zeros((my_pixels, 3), dtype=torch.int32, device="cuda")
-    n_vs, n_ds = [], []
+    n_vs, n_ds, n_cov = [], [], []
     for p in params:
         counts.zero_()
         sp.draw(p, counts=counts)
@@ -121,53 +119,45 @@ def main():
         s = counts.to(torch.int64).sum(0).cpu().numpy()
         n_vs.append(int(s[0]))
         n_ds.append(int(s[1]))
+        n_cov.append(int(((counts[:, 0] + counts[:, 1]) > 0).sum().item()))
     del counts
-    # rays this rank marches per frame = in-image pixels of its tiles (edge tiles are partial)
-    tiles_x = (fw + TILE - 1) // TILE
-    my_rays = 0
-    for k in range(tiles.tile_count):
-        t = tiles.tile_first + k * tiles.tile_stride
-        x0, y0 = (t % tiles_x) * TILE, (t // tiles_x) * TILE
-        my_rays += min(TILE, fw - x0) * min(TILE, fh - y0)
-
-    # ---- outputs ---------------------------------------------------------------------------------------------
-    n_buf = 2 if world > 1 else 1
-    bufs = [torch.zeros((tiles_per_rank * TILE * TILE if world > 1 else fw * fh, 4), dtype=torch.uint8, device="cuda")
-            for _ in range(n_buf)]
-    gathered = image = None
-    if world > 1 and rank == 0:
-        flat = [torch.empty((world,) + tuple(bufs[0].shape), dtype=torch.uint8, device="cuda") for _ in range(n_buf)]
-        gathered = [[flat[b][r] for r in range(world)] for b in range(n_buf)]
-        image = torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda")
+    # ---- outputs: N = 1 renders straight into the frame; N > 1 into double-buffered compact tile buffers -----------
+    gather = image = None
+    if world > 1:
+        gather = multigpu.TileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda")
+        bufs, my_rays = gather.buffers, gather.my_ray_count()
+        if rank == 0:
+            image = torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda")
+    else:
+        bufs, my_rays = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda")], fw * fh
+    n_buf = len(bufs)
 
     ev_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_stop = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     stream = torch.cuda.current_stream()
 
+    def collect(b):
+        """finish buffer b's gather (if any) and de-interleave it into the frame on rank 0"""
+        flat = gather.finish(b)
+        if flat is not None:
+            ctx.scatter_tiles(flat.data_ptr(), image.data_ptr(), (fw, fh), (TILE, TILE), world, gather.tiles_per_rank, 4, stream.cuda_stream)
+
     def run(n_steps, timed):
-        works = [None] * n_buf
         for k in range(n_steps):
             b = k % n_buf
-            if world > 1 and works[b] is not None:
-                works[b].wait()  # buffer b's previous gather must be done before it is overwritten
-                if rank == 0:
-                    ctx.scatter_tiles(flat[b].data_ptr(), image.data_ptr(), (fw, fh), (TILE, TILE), world, tiles_per_rank, 4,
-                                      stream.cuda_stream)
-                works[b] = None
+            if gather:
+                collect(b)  # buffer b's previous gather must be done before it is overwritten
             p = params[k % N_VIEWS]
             if timed:
                 ev_start[k].record(stream)
             sp.draw(p, rgba8=bufs[b])
             if timed:
                 ev_stop[k].record(stream)
-            if world > 1:
-                works[b] = dist.gather(bufs[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
-        for b in range(n_buf):
-            if world > 1 and works[b] is not None:
-                works[b].wait()
-                if rank == 0:
-                    ctx.scatter_tiles(flat[b].data_ptr(), image.data_ptr(), (fw, fh), (TILE, TILE), world, tiles_per_rank, 4,
-                                      stream.cuda_stream)
+            if gather:
+                gather.start(b)  # overlaps the next frame's render
+        if gather:
+            for b in range(n_buf):
+                collect(b)
 
     def fence():
         if world > 1:
@@ -194,11 +184,11 @@ def main():
     achieved_gbs = alg_avg / (kernel_ms_avg * 1e-3) / 1e9
 
     # whole-job sample rates need every rank's counters
-    tot = torch.tensor([sum(n_vs[k % N_VIEWS] for k in range(args.steps)), sum(n_ds[k % N_VIEWS] for k in range(args.steps))],
-                       dtype=torch.float64, device="cuda")
+    tot = torch.tensor([sum(n_vs[k % N_VIEWS] for k in range(args.steps)), sum(n_ds[k % N_VIEWS] for k in range(args.steps)),
+                        sum(n_cov[k % N_VIEWS] for k in range(args.steps))], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tot)
-    vs_total, ds_total = float(tot[0].item()), float(tot[1].item())
+    vs_total, ds_total, cov_total = float(tot[0].item()), float(tot[1].item()), float(tot[2].item())
 
     if rank != 0:
         dist.destroy_process_group()
@@ -214,6 +204,7 @@ def main():
                                                   {1: "block", 2: "Chebyshev distance-map", 3: "anisotropic"}[skip]),
                    "parallelism": "screen tiles 16x16 round-robin over %d GPU(s), RCCL gather to rank 0" % world if world > 1 else "1 GPU",
                    "output": "RGBA8"},
+        "covered_Mray_per_s": round(cov_total / elapsed / 1e6, 3), "covered_fraction": round(cov_total / (rays_per_frame_all * args.steps), 4),
         "volume_samples_per_s": round(vs_total / elapsed, 1), "distance_probes_per_s": round(ds_total / elapsed, 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,

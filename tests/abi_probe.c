@@ -1,0 +1,17 @@
+/* prints sizeof / offsetof of the public structs so the ctypes mirror (vkvolume_amd/abi.py) can be checked against the C header */
+#include <stddef.h>
+#include <stdio.h>
+#include "../include/vkvolume_amd.h"
+#define S(T) printf("sizeof %s %zu\n", #T, sizeof(T))
+#define O(T, f) printf("offsetof %s.%s %zu\n", #T, #f, offsetof(T, f))
+int main(void)
+{
+	S(VkvExtent3D); S(VkvTransferFunctionUniform); S(VkvVolumeOptions); S(VkvCameraUniform); S(VkvRayCastUniform); S(VkvRayGen);
+	S(VkvRenderOptions); S(VkvTileSchedule); S(VkvRenderParams);
+	O(VkvRenderParams, ray_cast); O(VkvRenderParams, transfer_function); O(VkvRenderParams, ray_gen); O(VkvRenderParams, options);
+	O(VkvRenderParams, use_precomputed_gradient); O(VkvRenderParams, image_width); O(VkvRenderParams, tiles);
+	O(VkvRenderParams, volume_extent); O(VkvRenderParams, map_extent); O(VkvRenderParams, d_volume); O(VkvRenderParams, d_gradient);
+	O(VkvRenderParams, d_transfer_function); O(VkvRenderParams, d_distance_maps); O(VkvRenderParams, d_out_color);
+	O(VkvRenderParams, d_out_rgba8); O(VkvRenderParams, d_out_counts); O(VkvRenderParams, d_out_depth);
+	return 0;
+}

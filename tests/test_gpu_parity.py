@@ -52,7 +52,7 @@ def test_synth_volume_matches_oracle(ctx, shape, kind, seed):
 @pytest.mark.parametrize("use_gradient", [True, False])
 def test_gradient_map_parity(ctx, shape, use_gradient):
     vol = T.random_volume(shape, seed=11)
-    opt = abi.VolumeOptions(**T.APP_TF) if use_gradient else abi.VolumeOptions(intensity_min=0.1)
+    opt = abi.VolumeOptions(**T.APP_TF) if use_gradient else abi.VolumeOptions(intensity_min=0.1, gradient_min=0.0, gradient_max=0.0)
     tf = lib.transfer_function_uniform(opt)
     assert bool(tf.use_gradient) == use_gradient
     d_vol, d_grad = dev(vol), torch.empty(vol.shape, dtype=torch.uint8, device="cuda")
@@ -78,7 +78,7 @@ def test_gradient_map_smooth_volume(ctx):
 def test_occupancy_map_parity(ctx, shape, block, variant):
     vol = T.random_volume(shape, seed=5, sparsity=0.97)
     if variant == "no_gradient":
-        opt = abi.VolumeOptions(intensity_min=0.1)
+        opt = abi.VolumeOptions(intensity_min=0.1, gradient_min=0.0, gradient_max=0.0)
     else:
         opt = abi.VolumeOptions(use_precomputed_gradient=(variant == "precomputed"), **T.APP_TF)
     scene = T.OracleScene(vol, opt, block)
@@ -205,7 +205,7 @@ def test_render_parity_modes(ctx, shell_scene, skipping_type, ert):
 @pytest.mark.parametrize("skipping_type", [abi.SKIP_NONE, abi.SKIP_DISTANCE])
 def test_render_parity_gradient_variants(ctx, variant, skipping_type):
     vol = O.synth_volume((64, 56, 48), 1, 21)
-    opt = abi.VolumeOptions(intensity_min=0.1) if variant == "no_gradient" else abi.VolumeOptions(use_precomputed_gradient=False, **T.APP_TF)
+    opt = abi.VolumeOptions(intensity_min=0.1, gradient_min=0.0, gradient_max=0.0) if variant == "no_gradient" else abi.VolumeOptions(use_precomputed_gradient=False, **T.APP_TF)
     scene = T.OracleScene(vol, opt, 4)
     v, tf = make_gpu_volume(ctx, scene)
     V.ComputeDistanceMap(ctx).compute(v, tf, skipping_type)

@@ -1,0 +1,133 @@
+"""CPU: the C-ABI library loads and exports every symbol the header declares, the ctypes mirror matches the C layout,
+the host-side helpers agree with the oracle, and the product fails loudly (no fallback) without its library / a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vkv_oracle as O
+from tests import helpers as T
+from vkvolume_amd import abi, camera, lib, multigpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "vkvolume_amd.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vkv_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = lib.load()
+    names = declared_functions()
+    assert len(names) >= 15
+    assert sorted(names) == sorted(lib.EXPORTS)
+    for n in names:
+        assert hasattr(L, n), n
+    assert b"gfx950" in L.vkv_version()
+
+
+def test_ctypes_mirror_matches_c_layout(tmp_path):
+    exe = tmp_path / "abi_probe"
+    subprocess.check_call(["gcc", "-std=c99", "-o", str(exe), os.path.join(ROOT, "tests", "abi_probe.c")])
+    out = subprocess.check_output([str(exe)]).decode().split("\n")
+    mirror = {"VkvExtent3D": abi.Extent3D, "VkvTransferFunctionUniform": abi.TransferFunctionUniform, "VkvVolumeOptions": abi.VolumeOptions,
+              "VkvCameraUniform": abi.CameraUniform, "VkvRayCastUniform": abi.RayCastUniform, "VkvRayGen": abi.RayGen,
+              "VkvRenderOptions": abi.RenderOptions, "VkvTileSchedule": abi.TileSchedule, "VkvRenderParams": abi.RenderParams}
+    n = 0
+    for line in out:
+        f = line.split()
+        if not f:
+            continue
+        if f[0] == "sizeof":
+            assert C.sizeof(mirror[f[1]]) == int(f[2]), line
+        else:
+            t, field = f[1].split(".")
+            assert getattr(mirror[t], field).offset == int(f[2]), line
+        n += 1
+    assert n >= 25
+    # the reference's uniform block sizes
+    assert C.sizeof(abi.CameraUniform) == 320 and C.sizeof(abi.RayCastUniform) == 68 and C.sizeof(abi.TransferFunctionUniform) == 32
+
+
+@pytest.mark.parametrize("opts", [dict(), T.APP_TF, dict(intensity_min=0.4, intensity_max=0.8, gradient_min=0.0, gradient_max=0.0),
+                                  dict(intensity_min=0.2, intensity_max=0.8, gradient_min=0.06, gradient_max=0.12),
+                                  dict(sampling_factor=2.5, voxel_alpha_factor=0.3, intensity_min=0.5, intensity_max=0.5)])
+def test_transfer_function_helpers_match_oracle(opts):
+    o = abi.VolumeOptions(**opts)
+    assert bytes(lib.transfer_function_uniform(o)) == bytes(O.transfer_function_uniform(o))
+    assert np.array_equal(lib.transfer_function_texture(o), O.transfer_function_texture(o))
+
+
+@pytest.mark.parametrize("az,el,radius,clip", [(0.0, 0.0, 150.0, 1.0), (33.0, 20.0, 95.0, 1.0), (200.0, -40.0, 30.0, 12.0), (90.0, 89.0, 60.0, 50.0)])
+def test_build_uniforms_matches_double_precision_oracle(az, el, radius, clip):
+    ext = abi.Extent3D(1024, 1024, 795)
+    me = O.map_extent(ext, 4)
+    ixf = camera.image_transform((0.0003, 0.0003, 0.0007), ext.as_tuple(), (1, 0, 0, 90))
+    node = camera.benchmark_node_transform(ixf)
+    view, proj = camera.orbit_camera(az, el, radius), camera.perspective_vulkan(60.0, 16 / 9)
+    a = lib.build_uniforms(view, proj, node, ixf, clip, (1920, 1080), ext, me)
+    b = O.build_uniforms(view, proj, node, ixf, clip, (1920, 1080), ext, me)
+    assert a[1].front_index == b[1].front_index
+    assert list(a[1].block_size) == [4.0, 4.0, 4.0, 0.0]
+    for x, y in zip(a, b):
+        n = C.sizeof(x) // 4 * 4
+        fa, fb = np.frombuffer(bytes(x)[:n], np.float32)[:16 * 5], np.frombuffer(bytes(y)[:n], np.float32)[:16 * 5]
+        if isinstance(x, abi.RayCastUniform):
+            fa, fb = fa[:16], fb[:16]
+        assert np.abs(fa - fb).max() <= 2e-6 * max(1.0, np.abs(fb).max())
+    # the clip plane sits clip_distance in front of the camera: plane . (cam_pos, 1) == -clip  (volume_render_subpass.cpp:238)
+    cam_pos = np.linalg.inv(view.astype(np.float64).T)[:3, 3]
+    assert abs(np.dot(list(a[1].plane)[:3], cam_pos) + a[1].plane[3] + clip) < 1e-3
+
+
+def test_map_extent_is_ceil_div():
+    assert O.map_extent(abi.Extent3D(1024, 1024, 795), 4).as_tuple() == (256, 256, 199)
+    assert O.map_extent(abi.Extent3D(64, 64, 64), 4).as_tuple() == (16, 16, 16)
+    assert O.map_extent(abi.Extent3D(9, 8, 7), 4).as_tuple() == (3, 2, 2)
+
+
+@pytest.mark.parametrize("frame,tile,world", [((1920, 1080), 16, 1), ((3840, 1080), 16, 2), ((150, 70), 16, 3), ((7680, 2160), 16, 8), ((33, 17), 16, 8)])
+def test_tile_schedules_partition_the_frame(frame, tile, world):
+    tiles_x, tiles_y = -(-frame[0] // tile), -(-frame[1] // tile)
+    seen = np.zeros(tiles_x * tiles_y, int)
+    rays = 0
+    for r in range(world):
+        s = abi.full_frame_tiles(frame[0], frame[1], tile, tile, r, world, compact=True)
+        for k in range(s.tile_count):
+            seen[s.tile_first + k * s.tile_stride] += 1
+        g = multigpu.TileGather(None, r, world, frame, tile, 4, device="cpu")
+        assert g.schedule.tile_count == s.tile_count and s.tile_count <= g.tiles_per_rank
+        rays += g.my_ray_count()
+    assert (seen == 1).all() and rays == frame[0] * frame[1]
+
+
+def test_product_fails_loudly_without_library(monkeypatch):
+    monkeypatch.setattr(lib, "_LIB", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libvkvolume_amd.so")
+    with pytest.raises(lib.VkvError, match="no CPU fallback"):
+        lib.Context(0)
+    with pytest.raises(lib.VkvError):
+        lib.transfer_function_texture(abi.VolumeOptions())
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful on a box without a GPU")
+def test_context_creation_fails_without_gpu():
+    with pytest.raises(lib.VkvError) as e:
+        lib.Context(0)
+    assert e.value.code == abi.VKV_E_NO_DEVICE
+
+
+def test_null_arguments_are_rejected_on_the_host_side():
+    L = lib.load()
+    assert L.vkv_transfer_function_uniform(None, None) == abi.VKV_E_INVALID_ARGUMENT
+    assert L.vkv_transfer_function_texture(None, None) == abi.VKV_E_INVALID_ARGUMENT
+    assert L.vkv_render(None, None, None) == abi.VKV_E_INVALID_ARGUMENT
+    assert L.vkv_gradient_map(None, None, None, abi.Extent3D(1, 1, 1), None, None) == abi.VKV_E_INVALID_ARGUMENT
+    L.vkv_destroy(None)  # no-op

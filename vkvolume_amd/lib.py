@@ -36,6 +36,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise VkvError(abi.VKV_E_NO_DEVICE, "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    # torch bundles its own HIP runtime (same soname as /opt/rocm's).  It must be the one already mapped when this
+    # library is dlopen()ed, so that streams and device pointers handed over from torch belong to the same runtime.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
     P = C.POINTER

@@ -1,0 +1,68 @@
+"""Screen-tile sharding of one frame over the ranks of a node.
+
+Rays are independent, so the path shards by screen tiles with the volume replicated per GPU and exactly one exchange
+step: every rank's compact tile buffer is gathered to rank 0 (RCCL gather over xGMI = 7 concurrent point-to-point
+transfers, one per link into the root), where ``vkv_scatter_tiles`` de-interleaves them into the frame.
+
+Tiles are dealt round-robin (tile t -> rank t mod world) because empty-space skipping makes per-pixel cost vary by
+more than 10x; contiguous strips would not balance.
+"""
+import numpy as np
+
+from . import abi
+
+
+class TileGather:
+    """Double-buffered gather of per-rank compact tile buffers to rank 0, overlapping the collective of frame k with the
+    render of frame k+1.  Works with any torch.distributed backend (nccl == RCCL on ROCm; gloo in the CPU tests)."""
+
+    def __init__(self, dist, rank, world, frame_size, tile=16, bytes_per_pixel=4, device="cuda", n_buffers=2):
+        import torch
+        self.dist, self.rank, self.world = dist, rank, world
+        self.frame_size, self.tile, self.bpp = frame_size, tile, bytes_per_pixel
+        fw, fh = frame_size
+        self.tiles_x, self.tiles_y = (fw + tile - 1) // tile, (fh + tile - 1) // tile
+        self.total_tiles = self.tiles_x * self.tiles_y
+        self.tiles_per_rank = (self.total_tiles + world - 1) // world
+        self.schedule = abi.full_frame_tiles(fw, fh, tile, tile, rank, world, compact=True)
+        n = self.tiles_per_rank * tile * tile
+        self.buffers = [torch.zeros((n, bytes_per_pixel), dtype=torch.uint8, device=device) for _ in range(n_buffers)]
+        self.flat = None
+        if rank == 0:
+            self.flat = [torch.zeros((world, n, bytes_per_pixel), dtype=torch.uint8, device=device) for _ in range(n_buffers)]
+        self.works = [None] * n_buffers
+
+    def my_ray_count(self):
+        """in-image pixels of this rank's tiles (edge tiles are partial)"""
+        fw, fh = self.frame_size
+        n = 0
+        for k in range(self.schedule.tile_count):
+            t = self.schedule.tile_first + k * self.schedule.tile_stride
+            x0, y0 = (t % self.tiles_x) * self.tile, (t // self.tiles_x) * self.tile
+            n += min(self.tile, fw - x0) * min(self.tile, fh - y0)
+        return n
+
+    def start(self, b):
+        """launch the gather of buffer b (asynchronous)"""
+        gl = [self.flat[b][r] for r in range(self.world)] if self.rank == 0 else None
+        self.works[b] = self.dist.gather(self.buffers[b], gl, dst=0, async_op=True)
+
+    def finish(self, b):
+        """wait for buffer b's gather; returns rank 0's [world, n, bpp] tensor (None elsewhere / if nothing pending)"""
+        if self.works[b] is None:
+            return None
+        self.works[b].wait()
+        self.works[b] = None
+        return self.flat[b] if self.rank == 0 else None
+
+
+def deinterleave_reference(flat, frame_size, tile, world):
+    """numpy statement of vkv_scatter_tiles (tests only): flat[rank, k*tile*tile + ly*tile + lx, c] -> image[y, x, c]."""
+    fw, fh = frame_size
+    tiles_x = (fw + tile - 1) // tile
+    flat = np.asarray(flat)
+    img = np.zeros((fh, fw, flat.shape[-1]), flat.dtype)
+    y, x = np.mgrid[0:fh, 0:fw]
+    t = (y // tile) * tiles_x + (x // tile)
+    img[y, x] = flat[t % world, ((t // world) * tile + (y % tile)) * tile + (x % tile)]
+    return img
