@@ -131,7 +131,7 @@ typedef struct VkvRenderOptions
  *               buffer that is gathered over RCCL and de-interleaved by vkv_scatter_tiles). */
 typedef struct VkvTileSchedule
 {
-	uint32_t tile_width, tile_height; /* multiples of 8 */
+	uint32_t tile_width, tile_height; /* multiples of 16 (one 256-thread workgroup marches 16x16 pixels) */
 	uint32_t tile_first, tile_stride, tile_count;
 	uint32_t compact;
 } VkvTileSchedule;
@@ -154,6 +154,8 @@ typedef struct VkvRenderParams
 	const uint8_t *            d_gradient;                 /* R8_UNORM  W*H*D, may be NULL when !use_precomputed_gradient */
 	const uint8_t *            d_transfer_function;        /* RGBA8 256x256, row = gradient  */
 	const uint8_t *            d_distance_maps[8];         /* [0] (or [0..7] anisotropic); unused for VKV_SKIP_NONE */
+	const void *               d_packed_volume;            /* optional: vkv_pack_volume() image of d_volume (+ d_gradient); NULL = sample the linear buffers */
+	const uint32_t *           d_transfer_function_bits;   /* optional: vkv_transfer_function_bits() of d_transfer_function; NULL = fetch the texel */
 	float *                    d_out_color;                /* RGBA32F premultiplied, or NULL */
 	uint8_t *                  d_out_rgba8;                /* RGBA8 round-to-nearest of the above, or NULL */
 	uint32_t *                 d_out_counts;               /* 3 x u32 per pixel: volume samples, distance probes, empty samples; or NULL */
@@ -213,6 +215,18 @@ int vkv_compute_distance_map(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_
                              const uint8_t *d_transfer_function, const VkvTransferFunctionUniform *tf,
                              VkvExtent3D extent, uint8_t *const d_maps[8], uint8_t *d_swap,
                              VkvExtent3D map_extent, int32_t skipping_type, void *stream);
+
+/* Device-internal sampling layout of the volume (the counterpart of uploading into a VK_IMAGE_TILING_OPTIMAL image,
+ * src/volume_component.cpp:68-83): 4x4x4-voxel bricks with a one-voxel apron, volume and gradient bytes interleaved,
+ * clamp-to-edge baked in, bricks grouped 8x8x8.  Every trilinear footprint of both textures then lies inside one
+ * 256-byte brick.  vkv_packed_volume_bytes() sizes the buffer; d_gradient may be NULL (gradient channel = 0).
+ * Results of vkv_render are bit-identical with and without it. */
+size_t vkv_packed_volume_bytes(VkvExtent3D extent);
+int    vkv_pack_volume(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_t *d_gradient, VkvExtent3D extent, void *d_packed, void *stream);
+
+/* 1 bit per texel of the 256x256 TF texture: alpha > 0 (8 KiB, row = gradient).  Lets the integrator decide
+ * "voxel_occupied" (frag:276) from LDS and fetch the RGBA texel only for occupied samples. */
+int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_transfer_function, uint32_t *d_bits_2048, void *stream);
 
 /* VolumeRenderSubpass::draw, src/volume_render_subpass.cpp:159-294 (shaders/volume_render.frag). */
 int vkv_render(vkv_ctx *ctx, const VkvRenderParams *params, void *stream);

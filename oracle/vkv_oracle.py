@@ -17,8 +17,11 @@ _LIB = None
 
 def build(force=False):
     """Compile the oracle with gcc (Makefile in this directory)."""
-    if force or not os.path.exists(os.path.join(_HERE, "libvkv_oracle.so")):
+    try:  # make is a no-op when the library is newer than its sources and the ABI header
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    except (OSError, subprocess.CalledProcessError):
+        if not os.path.exists(os.path.join(_HERE, "libvkv_oracle.so")):
+            raise
 
 
 def _has_fma():

@@ -156,11 +156,20 @@ def gpu_render(ctx, v, params, want_rgba8=False):
     depth = torch.full(shape, s_col, dtype=torch.float32, device="cuda")
     rgba8 = torch.zeros(shape + (4,), dtype=torch.uint8, device="cuda") if want_rgba8 else None
     sp = V.VolumeRenderSubpass(ctx, v, params.options, (params.image_width, params.image_height))
-    p = sp.bind(params)
-    sp.draw(p, color, rgba8, counts, depth)
-    torch.cuda.synchronize()
-    return (color.cpu().numpy(), counts.cpu().numpy().astype(np.uint32), depth.cpu().numpy(),
-            None if rgba8 is None else rgba8.cpu().numpy())
+    outs = []
+    for packed in (True, False):  # bricked image + TF bit table, then the plain linear buffers + texel fetch
+        v.use_packed = packed
+        p = sp.bind(params)
+        assert bool(p.d_packed_volume) == packed and bool(p.d_transfer_function_bits) == packed
+        c, n, d = color.clone(), counts.clone(), depth.clone()
+        q = None if rgba8 is None else rgba8.clone()
+        sp.draw(p, c, q, n, d)
+        torch.cuda.synchronize()
+        outs.append((c.cpu().numpy(), n.cpu().numpy().astype(np.uint32), d.cpu().numpy(), None if q is None else q.cpu().numpy()))
+    v.use_packed = True
+    for a, b in zip(outs[0], outs[1]):
+        assert (a is None and b is None) or np.array_equal(a, b), "packed and linear sampling paths disagree"
+    return outs[0]
 
 
 def compare_render(got, ref, label):

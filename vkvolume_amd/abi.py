@@ -92,7 +92,8 @@ class RenderParams(C.Structure):
                 ("use_precomputed_gradient", C.c_uint32), ("image_width", C.c_uint32), ("image_height", C.c_uint32),
                 ("tiles", TileSchedule), ("volume_extent", Extent3D), ("map_extent", Extent3D),
                 ("d_volume", C.c_void_p), ("d_gradient", C.c_void_p), ("d_transfer_function", C.c_void_p),
-                ("d_distance_maps", C.c_void_p * 8), ("d_out_color", C.c_void_p), ("d_out_rgba8", C.c_void_p),
+                ("d_distance_maps", C.c_void_p * 8), ("d_packed_volume", C.c_void_p),
+                ("d_transfer_function_bits", C.c_void_p), ("d_out_color", C.c_void_p), ("d_out_rgba8", C.c_void_p),
                 ("d_out_counts", C.c_void_p), ("d_out_depth", C.c_void_p)]
 
 

@@ -20,6 +20,8 @@ int launch_distance_map_anisotropic(vkv_ctx *, uint8_t *const[8], uint8_t *, Vkv
 int launch_synth_volume(vkv_ctx *, uint8_t *, VkvExtent3D, uint32_t, uint32_t, hipStream_t);
 int launch_scatter_tiles(vkv_ctx *, const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 int launch_render(vkv_ctx *, const VkvRenderParams *, const float *, hipStream_t);
+int launch_pack_volume(vkv_ctx *, const uint8_t *, const uint8_t *, VkvExtent3D, void *, hipStream_t);
+int launch_tf_bits(vkv_ctx *, const uint8_t *, uint32_t *, hipStream_t);
 
 int set_error(vkv_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -280,6 +282,33 @@ int vkv_compute_distance_map(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_
 	return VKV_OK;        // None / Block use the raw 0/255 occupancy map (:96-99)
 }
 
+size_t vkv_packed_volume_bytes(VkvExtent3D e)
+{
+	if (!extent_ok(e))
+		return 0;
+	return packed_bytes(packed_dims((int) e.width, (int) e.height, (int) e.depth));
+}
+
+int vkv_pack_volume(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_t *d_gradient, VkvExtent3D extent, void *d_packed, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (!d_volume || !d_packed || !extent_ok(extent))
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "pack_volume: null pointer or zero extent");
+	if (((uintptr_t) d_packed & 255u) != 0)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "pack_volume: d_packed must be 256-byte aligned");
+	return launch_pack_volume(ctx, d_volume, d_gradient, extent, d_packed, (hipStream_t) stream);
+}
+
+int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_tf, uint32_t *d_bits, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (!d_tf || !d_bits)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "transfer_function_bits: null pointer");
+	return launch_tf_bits(ctx, d_tf, d_bits, (hipStream_t) stream);
+}
+
 int vkv_render(vkv_ctx *ctx, const VkvRenderParams *P, void *stream)
 {
 	if (!ctx)
@@ -318,6 +347,8 @@ int vkv_render(vkv_ctx *ctx, const VkvRenderParams *P, void *stream)
 		if (t.tile_count && (uint64_t) t.tile_first + (uint64_t) (t.tile_count - 1) * t.tile_stride >= tiles_x * tiles_y)
 			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: tile schedule runs past the image");
 	}
+	if (P->d_packed_volume && ((uintptr_t) P->d_packed_volume & 255u) != 0)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: d_packed_volume must be 256-byte aligned");
 	if (!P->d_out_color && !P->d_out_rgba8 && !P->d_out_counts && !P->d_out_depth)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: no output buffer");
 

@@ -212,6 +212,30 @@ __global__ void __launch_bounds__(256) k_dm_axis(const uint8_t *__restrict__ src
 }
 
 // ---------------------------------------------------------------------------------------------
+// Packed sampling layout (see vkv_device.hpp): one 128-thread half-block per brick, thread = one of the 5^3 texels
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pack_volume(const uint8_t *__restrict__ vol, const uint8_t *__restrict__ grad, uint8_t *__restrict__ packed,
+                                                     int W, int H, int D, PackedDims pd, uint32_t n_bricks)
+{
+	const uint32_t brick = blockIdx.x * 2 + (threadIdx.x >> 7);        // linear over (bz, by, bx)
+	const int      t     = threadIdx.x & 127;
+	if (brick >= n_bricks)
+		return;
+	const int bx = (int) (brick % (uint32_t) pd.bx), by = (int) ((brick / (uint32_t) pd.bx) % (uint32_t) pd.by), bz = (int) (brick / ((uint32_t) pd.bx * (uint32_t) pd.by));
+	uint16_t *dst = reinterpret_cast<uint16_t *>(packed + packed_brick_offset(bx, by, bz, pd.mx, pd.my));
+	if (t >= 125)
+	{
+		dst[t] = 0;        // the 6 padding bytes
+		return;
+	}
+	const int lx = t % 5, ly = (t / 5) % 5, lz = t / 25;
+	const int x = min(max(bx * 4 + lx - 1, 0), W - 1), y = min(max(by * 4 + ly - 1, 0), H - 1), z = min(max(bz * 4 + lz - 1, 0), D - 1);
+	const size_t   o = vidx(x, y, z, W, H);
+	const uint32_t v = vol[o], g = grad ? grad[o] : 0u;
+	dst[t] = (uint16_t) (v | (g << 8));
+}
+
+// ---------------------------------------------------------------------------------------------
 // Synthetic volumes (DESIGN.md "Synthetic inputs")
 // ---------------------------------------------------------------------------------------------
 struct SynthShell
@@ -420,6 +444,24 @@ int launch_distance_map_anisotropic(vkv_ctx *ctx, uint8_t *const m[8], uint8_t *
 	if ((rc = launch_dm_axis<-1>(ctx, 1, m[7], swap, me, s))) return rc;          // stage2(7, -1)
 	if ((rc = launch_dm_axis<1>(ctx, 2, swap, m[6], me, s))) return rc;           // stage3(6, +1)
 	return launch_dm_axis<-1>(ctx, 2, swap, m[7], me, s);                         // stage3(7, -1)
+}
+
+int launch_pack_volume(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_grad, VkvExtent3D e, void *d_packed, hipStream_t s)
+{
+	const PackedDims pd = packed_dims((int) e.width, (int) e.height, (int) e.depth);
+	const uint64_t   nb = (uint64_t) pd.bx * pd.by * pd.bz;
+	if (nb > 0xfffffffeull)
+		return set_error(ctx, VKV_E_UNSUPPORTED, "pack_volume: volume too large");
+	// macro-brick padding (bricks that exist only because of the 8x8x8 grouping) is never addressed by the sampler
+	hipLaunchKernelGGL(k_pack_volume, dim3((uint32_t) ((nb + 1) / 2)), dim3(256), 0, s, d_vol, d_grad, (uint8_t *) d_packed, (int) e.width, (int) e.height,
+	                   (int) e.depth, pd, (uint32_t) nb);
+	return check_launch(ctx, "pack_volume");
+}
+
+int launch_tf_bits(vkv_ctx *ctx, const uint8_t *d_tf, uint32_t *d_bits, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_tf_bits, dim3(8), dim3(256), 0, s, d_tf, d_bits);
+	return check_launch(ctx, "transfer_function_bits");
 }
 
 // --- synthetic volume: host builds the shell table (same definition as DESIGN.md "Synthetic inputs") ---

@@ -27,6 +27,9 @@ struct RayMarchArgs
 	// extents
 	int W, H, D, mw, mh, md;
 	const uint8_t *vol, *grad, *tf;
+	const uint8_t *packed;        // vkv_pack_volume image (PACKED variants) or null
+	int            pmx, pmy;      // macro-bricks per axis of the packed image
+	const uint32_t *tf_bits;      // 2048-word alpha>0 bit table or null
 	const uint8_t *maps[8];
 	float *        out_color;
 	uint8_t *      out_rgba8;
@@ -60,6 +63,46 @@ __device__ __forceinline__ float sample_linear(const uint8_t *__restrict__ tex, 
 	return __builtin_fmaf(wz, c1 - c0, c0) * kInv255;
 }
 
+// Same filter on the packed image: the whole 2x2x2 footprint of BOTH textures sits in one 256-byte brick, the x pair of
+// a row is one (2-byte aligned) dword = (v0, g0, v1, g1).  Arithmetic identical to sample_linear, so results are too.
+typedef uint32_t u32_align2 __attribute__((aligned(2)));
+
+template <bool WANT_G>
+__device__ __forceinline__ void sample_packed(const uint8_t *__restrict__ P, int W, int H, int D, int pmx, int pmy, float px, float py, float pz,
+                                              float &out_v, float &out_g)
+{
+	const float cx = __builtin_fmaf(px, (float) W, -0.5f), cy = __builtin_fmaf(py, (float) H, -0.5f), cz = __builtin_fmaf(pz, (float) D, -0.5f);
+	const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy), fz = __builtin_floorf(cz);
+	const float wx = cx - fx, wy = cy - fy, wz = cz - fz;
+	const int   bx = i_clamp((int) fx, -1, W) + 1, by = i_clamp((int) fy, -1, H) + 1, bz = i_clamp((int) fz, -1, D) + 1;
+	const uint8_t *b = P + packed_brick_offset(bx >> 2, by >> 2, bz >> 2, pmx, pmy) + (uint32_t) ((((bz & 3) * 5 + (by & 3)) * 5 + (bx & 3)) * 2);
+	const uint32_t q00 = *reinterpret_cast<const u32_align2 *>(b);
+	const uint32_t q10 = *reinterpret_cast<const u32_align2 *>(b + 10);
+	const uint32_t q01 = *reinterpret_cast<const u32_align2 *>(b + 50);
+	const uint32_t q11 = *reinterpret_cast<const u32_align2 *>(b + 60);
+	{
+		const float b000 = (float) (q00 & 255u), b100 = (float) ((q00 >> 16) & 255u);
+		const float b010 = (float) (q10 & 255u), b110 = (float) ((q10 >> 16) & 255u);
+		const float b001 = (float) (q01 & 255u), b101 = (float) ((q01 >> 16) & 255u);
+		const float b011 = (float) (q11 & 255u), b111 = (float) ((q11 >> 16) & 255u);
+		const float c00 = __builtin_fmaf(wx, b100 - b000, b000), c10 = __builtin_fmaf(wx, b110 - b010, b010);
+		const float c01 = __builtin_fmaf(wx, b101 - b001, b001), c11 = __builtin_fmaf(wx, b111 - b011, b011);
+		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
+		out_v = __builtin_fmaf(wz, c1 - c0, c0) * kInv255;
+	}
+	if (WANT_G)
+	{
+		const float b000 = (float) ((q00 >> 8) & 255u), b100 = (float) (q00 >> 24);
+		const float b010 = (float) ((q10 >> 8) & 255u), b110 = (float) (q10 >> 24);
+		const float b001 = (float) ((q01 >> 8) & 255u), b101 = (float) (q01 >> 24);
+		const float b011 = (float) ((q11 >> 8) & 255u), b111 = (float) (q11 >> 24);
+		const float c00 = __builtin_fmaf(wx, b100 - b000, b000), c10 = __builtin_fmaf(wx, b110 - b010, b010);
+		const float c01 = __builtin_fmaf(wx, b101 - b001, b001), c11 = __builtin_fmaf(wx, b111 - b011, b011);
+		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
+		out_g = __builtin_fmaf(wz, c1 - c0, c0) * kInv255;
+	}
+}
+
 __device__ __forceinline__ void mat4_mul_vec4(const float *m, const float *v, float *r)
 {
 #pragma unroll
@@ -70,11 +113,17 @@ __device__ __forceinline__ void mat4_mul_vec4(const float *m, const float *v, fl
 __device__ __forceinline__ uint8_t quantise_rgba8(float c) { return (uint8_t) __builtin_rintf(g_clamp(c, 0.0f, 1.0f) * 255.0f); }
 
 // SKIP: VkvSkippingType; ERT: early ray termination; GRAD: 0 = use_gradient false, 1 = precomputed map, 2 = on the fly.
-template <int SKIP, bool ERT, int GRAD>
+// PACKED: sample the vkv_pack_volume image instead of the linear buffers.
+template <int SKIP, bool ERT, int GRAD, bool PACKED>
 __global__ void __launch_bounds__(256) k_raymarch(const RayMarchArgs A)
 {
-	__shared__ float s_alpha[256];
+	__shared__ float    s_alpha[256];
+	__shared__ uint32_t s_bits[2048];
 	s_alpha[threadIdx.x] = A.alpha_lut[threadIdx.x];
+	const bool tf_bits = A.tf_bits != nullptr;        // wave-uniform
+	if (tf_bits)
+		for (int i = threadIdx.x; i < 2048; i += 256)
+			s_bits[i] = A.tf_bits[i];
 	__syncthreads();
 
 	// ---- workgroup -> 16x16 pixel block of one scheduled tile -------------------------------------------------
@@ -257,25 +306,57 @@ __global__ void __launch_bounds__(256) k_raymarch(const RayMarchArgs A)
 			else
 			{
 				++n_vol;
-				const float intensity = sample_linear(A.vol, W, H, D, posx, posy, posz);
-				float       gradient  = 1.0f;
-				if (GRAD == 1)
-					gradient = sample_linear(A.grad, W, H, D, posx, posy, posz);
-				else if (GRAD == 2)
+				float intensity, gradient = 1.0f;
+				if (PACKED)
 				{
-					const float t1 = sample_linear(A.vol, W, H, D, posx + dix, posy - diy, posz - diz);
-					const float t2 = sample_linear(A.vol, W, H, D, posx - dix, posy - diy, posz + diz);
-					const float t3 = sample_linear(A.vol, W, H, D, posx - dix, posy + diy, posz - diz);
-					const float t4 = sample_linear(A.vol, W, H, D, posx + dix, posy + diy, posz + diz);
+					float unused;
+					if (GRAD == 1)
+						sample_packed<true>(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, intensity, gradient);
+					else
+						sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, intensity, unused);
+				}
+				else
+				{
+					intensity = sample_linear(A.vol, W, H, D, posx, posy, posz);
+					if (GRAD == 1)
+						gradient = sample_linear(A.grad, W, H, D, posx, posy, posz);
+				}
+				if (GRAD == 2)
+				{
+					float t1, t2, t3, t4, unused;
+					if (PACKED)
+					{
+						sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx + dix, posy - diy, posz - diz, t1, unused);
+						sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx - dix, posy - diy, posz + diz, t2, unused);
+						sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx - dix, posy + diy, posz - diz, t3, unused);
+						sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx + dix, posy + diy, posz + diz, t4, unused);
+					}
+					else
+					{
+						t1 = sample_linear(A.vol, W, H, D, posx + dix, posy - diy, posz - diz);
+						t2 = sample_linear(A.vol, W, H, D, posx - dix, posy - diy, posz + diz);
+						t3 = sample_linear(A.vol, W, H, D, posx - dix, posy + diy, posz - diz);
+						t4 = sample_linear(A.vol, W, H, D, posx + dix, posy + diy, posz + diz);
+					}
 					const float gx = (((t1 - t2) - t3) + t4) * 0.25f;
 					const float gy = (((-t1 - t2) + t3) + t4) * 0.25f;
 					const float gz = (((-t1 + t2) - t3) + t4) * 0.25f;
 					const float len = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
 					gradient = g_clamp(len * A.grad_modifier, 0.0f, 1.0f);
 				}
-				const uint32_t texel = *reinterpret_cast<const uint32_t *>(A.tf + ((size_t) tf_texel(gradient) * 256 + (size_t) tf_texel(intensity)) * 4);
-				const uint32_t ab    = texel >> 24;
-				occupied             = ab > 0;
+				// get_color (transfer_function.glsl:35-38): NEAREST texel.  With the bit table the occupied test (frag:276)
+				// comes from LDS and only occupied samples pay the dependent RGBA fetch.
+				const uint32_t tidx  = (uint32_t) tf_texel(gradient) * 256u + (uint32_t) tf_texel(intensity);
+				uint32_t       texel = 0;
+				if (tf_bits)
+				{
+					if ((s_bits[tidx >> 5] >> (tidx & 31u)) & 1u)
+						texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
+				}
+				else
+					texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
+				const uint32_t ab = texel >> 24;
+				occupied          = ab > 0;
 				if (occupied)
 				{
 					if (SKIP != VKV_SKIP_NONE)
@@ -338,25 +419,35 @@ __global__ void __launch_bounds__(256) k_raymarch(const RayMarchArgs A)
 namespace vkv
 {
 
-template <int SKIP, bool ERT>
+template <int SKIP, bool ERT, bool PACKED>
 static void launch_grad(int grad, const RayMarchArgs &a, hipStream_t s)
 {
 	const dim3 grid(a.nblocks), block(256);
 	if (grad == 0)
-		hipLaunchKernelGGL((k_raymarch<SKIP, ERT, 0>), grid, block, 0, s, a);
+		hipLaunchKernelGGL((k_raymarch<SKIP, ERT, 0, PACKED>), grid, block, 0, s, a);
 	else if (grad == 1)
-		hipLaunchKernelGGL((k_raymarch<SKIP, ERT, 1>), grid, block, 0, s, a);
+		hipLaunchKernelGGL((k_raymarch<SKIP, ERT, 1, PACKED>), grid, block, 0, s, a);
 	else
-		hipLaunchKernelGGL((k_raymarch<SKIP, ERT, 2>), grid, block, 0, s, a);
+		hipLaunchKernelGGL((k_raymarch<SKIP, ERT, 2, PACKED>), grid, block, 0, s, a);
 }
 
 template <int SKIP>
 static void launch_ert(bool ert, int grad, const RayMarchArgs &a, hipStream_t s)
 {
-	if (ert)
-		launch_grad<SKIP, true>(grad, a, s);
+	if (a.packed)
+	{
+		if (ert)
+			launch_grad<SKIP, true, true>(grad, a, s);
+		else
+			launch_grad<SKIP, false, true>(grad, a, s);
+	}
 	else
-		launch_grad<SKIP, false>(grad, a, s);
+	{
+		if (ert)
+			launch_grad<SKIP, true, false>(grad, a, s);
+		else
+			launch_grad<SKIP, false, false>(grad, a, s);
+	}
 }
 
 int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, hipStream_t s)
@@ -377,6 +468,12 @@ int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut
 	a.W = (int) P->volume_extent.width, a.H = (int) P->volume_extent.height, a.D = (int) P->volume_extent.depth;
 	a.mw = (int) P->map_extent.width, a.mh = (int) P->map_extent.height, a.md = (int) P->map_extent.depth;
 	a.vol = P->d_volume, a.grad = P->d_gradient, a.tf = P->d_transfer_function;
+	a.packed  = static_cast<const uint8_t *>(P->d_packed_volume);
+	a.tf_bits = P->d_transfer_function_bits;
+	{
+		const PackedDims pd = packed_dims(a.W, a.H, a.D);
+		a.pmx = pd.mx, a.pmy = pd.my;
+	}
 	for (int i = 0; i < 8; ++i)
 		a.maps[i] = P->d_distance_maps[i];
 	a.out_color = P->d_out_color, a.out_rgba8 = P->d_out_rgba8, a.out_counts = P->d_out_counts, a.out_depth = P->d_out_depth;

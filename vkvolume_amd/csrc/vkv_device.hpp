@@ -69,6 +69,34 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb)
 	return xcd * q + min(xcd, r) + idx;
 }
 
+// ---- packed sampling layout (vkv_pack_volume) -------------------------------------------------------------------
+// Padded index j in [0, W+2] holds voxel clamp(j-1, 0, W-1), so the clamp-to-edge footprint of texel index ix is always
+// the pair (b, b+1) with b = clamp(ix, -1, W) + 1.  Brick (bx,by,bz) stores padded voxels [4b, 4b+4] per axis (5^3 with
+// the apron) as interleaved (volume, gradient) byte pairs, x fastest: 250 bytes padded to 256.  Bricks are grouped
+// 8x8x8 (one 128 KiB macro-brick = 32^3 voxels) so a ray's working set stays within a few pages.
+struct PackedDims
+{
+	int bx, by, bz;        // bricks per axis
+	int mx, my, mz;        // macro-bricks per axis
+};
+
+__host__ __device__ __forceinline__ PackedDims packed_dims(int W, int H, int D)
+{
+	PackedDims p;
+	p.bx = ((W + 1) >> 2) + 1, p.by = ((H + 1) >> 2) + 1, p.bz = ((D + 1) >> 2) + 1;
+	p.mx = (p.bx + 7) >> 3, p.my = (p.by + 7) >> 3, p.mz = (p.bz + 7) >> 3;
+	return p;
+}
+
+__host__ __device__ __forceinline__ size_t packed_bytes(const PackedDims &p) { return (size_t) p.mx * p.my * p.mz * 512 * 256; }
+
+__host__ __device__ __forceinline__ size_t packed_brick_offset(int bx, int by, int bz, int mx, int my)
+{
+	const size_t macro = ((size_t) (bz >> 3) * my + (size_t) (by >> 3)) * mx + (size_t) (bx >> 3);
+	const size_t sub   = (size_t) (((bz & 7) << 6) | ((by & 7) << 3) | (bx & 7));
+	return (macro * 512 + sub) * 256;
+}
+
 }        // namespace vkv
 
 // Host-side context (capi.cpp owns it).

@@ -16,6 +16,7 @@ EXPORTS = [
     "vkv_transfer_function_uniform", "vkv_transfer_function_texture", "vkv_build_uniforms",
     "vkv_gradient_map", "vkv_occupancy_map", "vkv_distance_map", "vkv_distance_map_anisotropic",
     "vkv_compute_distance_map", "vkv_render", "vkv_scatter_tiles", "vkv_synth_volume",
+    "vkv_packed_volume_bytes", "vkv_pack_volume", "vkv_transfer_function_bits",
 ]
 
 
@@ -61,6 +62,10 @@ def load():
     L.vkv_render.argtypes = [vp, P(abi.RenderParams), vp]
     L.vkv_scatter_tiles.argtypes = [vp, vp, vp, u32, u32, u32, u32, u32, u32, u32, vp]
     L.vkv_synth_volume.argtypes = [vp, vp, abi.Extent3D, u32, u32, vp]
+    L.vkv_packed_volume_bytes.argtypes = [abi.Extent3D]
+    L.vkv_packed_volume_bytes.restype = C.c_size_t
+    L.vkv_pack_volume.argtypes = [vp, vp, vp, abi.Extent3D, vp, vp]
+    L.vkv_transfer_function_bits.argtypes = [vp, vp, vp, vp]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here means the library does not export what the header declares
     _LIB = L
@@ -127,6 +132,15 @@ class Context:
 
     def synth_volume(self, d_volume, extent, kind, seed, stream=0):
         self.check(self._lib.vkv_synth_volume(self.handle, d_volume, extent, kind, seed, stream))
+
+    def packed_volume_bytes(self, extent):
+        return int(self._lib.vkv_packed_volume_bytes(extent))
+
+    def pack_volume(self, d_volume, d_gradient, extent, d_packed, stream=0):
+        self.check(self._lib.vkv_pack_volume(self.handle, d_volume, d_gradient, extent, d_packed, stream))
+
+    def transfer_function_bits(self, d_tf, d_bits, stream=0):
+        self.check(self._lib.vkv_transfer_function_bits(self.handle, d_tf, d_bits, stream))
 
     def last_error(self):
         return self._lib.vkv_last_error(self.handle).decode(errors="replace")

@@ -37,6 +37,8 @@ class Volume:
         self.image_transform = np.eye(4, dtype=np.float32)
         self.node_transform = np.eye(4, dtype=np.float32)
         self.volume = self.gradient = self.transfer_function = None
+        self.packed = self.transfer_function_bits = None  # device-internal accelerators (vkv_pack_volume, vkv_transfer_function_bits)
+        self.use_packed = True
         self.distance_maps = []
         self.distance_map_swap = None
         self.extent = self.map_extent = None
@@ -61,6 +63,8 @@ class Volume:
         if self.options.use_precomputed_gradient:
             self.gradient = torch.empty_like(self.volume)
         self.transfer_function = torch.zeros((256, 256, 4), dtype=torch.uint8, device=self.device)
+        self.transfer_function_bits = torch.zeros(2048, dtype=torch.int32, device=self.device)
+        self.packed = None
         self.distance_map_swap = torch.empty((self.map_extent.depth, self.map_extent.height, self.map_extent.width),
                                              dtype=torch.uint8, device=self.device)
         self.distance_maps = []
@@ -83,6 +87,16 @@ class Volume:
     def update_transfer_function_texture(self):
         tex = lib.transfer_function_texture(self.options)  # CPU builds the LUT (volume_component.cpp:242-261)
         self.transfer_function.copy_(torch.from_numpy(tex), non_blocking=False)
+        self.ctx.transfer_function_bits(_ptr(self.transfer_function), _ptr(self.transfer_function_bits), _stream())
+
+    def pack(self):
+        """(Re)build the bricked sampling image from the linear volume (+ gradient map).  Call after the gradient map
+        is computed — the counterpart of the driver's swizzle into an optimally tiled VkImage."""
+        n = self.ctx.packed_volume_bytes(self.extent)
+        if self.packed is None or self.packed.numel() != n:
+            self.packed = torch.empty(n, dtype=torch.uint8, device=self.device)
+        grad = self.gradient if self.options.use_precomputed_gradient else None
+        self.ctx.pack_volume(_ptr(self.volume), _ptr(grad), self.extent, _ptr(self.packed), _stream())
 
 
 class ComputeGradientMap:
@@ -91,6 +105,8 @@ class ComputeGradientMap:
 
     def compute(self, volume, transfer_function_uniform):
         self.ctx.gradient_map(_ptr(volume.volume), _ptr(volume.gradient), volume.extent, transfer_function_uniform, _stream())
+        if volume.use_packed:
+            volume.pack()
 
 
 class ComputeDistanceMap:
@@ -141,6 +157,10 @@ class VolumeRenderSubpass:
         p.d_transfer_function = _ptr(v.transfer_function)
         for i in range(8):
             p.d_distance_maps[i] = _ptr(v.distance_maps[i]) if i < len(v.distance_maps) else None
+        if v.use_packed and v.packed is None:
+            v.pack()  # no gradient pass ran (on-the-fly / no-gradient variants): pack the volume channel alone
+        p.d_packed_volume = _ptr(v.packed) if v.use_packed else None
+        p.d_transfer_function_bits = _ptr(v.transfer_function_bits) if v.use_packed else None
         return p
 
     def draw(self, params, color=None, rgba8=None, counts=None, depth=None):
