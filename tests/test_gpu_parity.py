@@ -2,6 +2,8 @@
 seeded inputs.  Bar: bit-exact for all uint8 maps and the uint32 sample counters; the float RGBA /
 depth outputs are compared with the tolerance COLOR_TOL below (the arithmetic is pinned op-for-op, so the
 observed difference is expected to be 0; the tolerance is the contract)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -157,8 +159,11 @@ def gpu_render(ctx, v, params, want_rgba8=False):
     rgba8 = torch.zeros(shape + (4,), dtype=torch.uint8, device="cuda") if want_rgba8 else None
     sp = V.VolumeRenderSubpass(ctx, v, params.options, (params.image_width, params.image_height))
     outs = []
-    for packed in (True, False):  # bricked image + TF bit table, then the plain linear buffers + texel fetch
+    # every combination of {bricked image + TF bit table, plain linear buffers + texel fetch} x {persistent-wave scheduler,
+    # static tile scheduler} must give the same bits
+    for packed, sched in ((True, "persistent"), (False, "persistent"), (True, "tiles"), (False, "tiles")):
         v.use_packed = packed
+        os.environ["VKV_RAYMARCH_SCHEDULER"] = sched
         p = sp.bind(params)
         assert bool(p.d_packed_volume) == packed and bool(p.d_transfer_function_bits) == packed
         c, n, d = color.clone(), counts.clone(), depth.clone()
@@ -167,8 +172,10 @@ def gpu_render(ctx, v, params, want_rgba8=False):
         torch.cuda.synchronize()
         outs.append((c.cpu().numpy(), n.cpu().numpy().astype(np.uint32), d.cpu().numpy(), None if q is None else q.cpu().numpy()))
     v.use_packed = True
-    for a, b in zip(outs[0], outs[1]):
-        assert (a is None and b is None) or np.array_equal(a, b), "packed and linear sampling paths disagree"
+    os.environ.pop("VKV_RAYMARCH_SCHEDULER", None)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert (a is None and b is None) or np.array_equal(a, b), "sampling-layout / scheduler variants disagree"
     return outs[0]
 
 

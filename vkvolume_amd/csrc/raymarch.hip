@@ -5,10 +5,14 @@
 // shaders/volume_render.frag (integrator), shaders/transfer_function.glsl (get_color) and the two vertex
 // shaders (ray entry; here an analytic per-pixel box / clip-plane intersection, there is no rasteriser on CDNA).
 //
-// Mapping: one lane per ray, one wave per 8x8 pixel tile (rays of a wave stay spatially coherent so the byte
-// gathers of a wave fall into a few cache lines), one 256-thread workgroup per 16x16 pixels, workgroups remapped
-// so each XCD (own L2) owns a contiguous run of screen tiles.  The frag's compile-time variants
-// (volume_render_subpass.cpp:57-92) are template parameters here.
+// One lane marches one ray.  The frag's compile-time variants (volume_render_subpass.cpp:57-92) are template
+// parameters.  Two schedulers share the same per-ray code (ray_setup / ray_event / ray_finish):
+//   k_raymarch_tiles       one wave per 8x8 pixel tile, static (simple; kept for A/B and tiny frames)
+//   k_raymarch_persistent  resident waves pull 8x8 tiles from per-XCD queues and re-fill lanes whose rays have
+//                          ended (ballot + mbcnt compaction), so a wave is not held hostage by its longest ray —
+//                          with ESS + ERT the per-ray event count varies by >100x inside one tile.
+#include <cstdlib>
+
 #include "vkv_device.hpp"
 
 using namespace vkv;
@@ -26,19 +30,37 @@ struct RayMarchArgs
 	float sampling_factor, grad_modifier;
 	// extents
 	int W, H, D, mw, mh, md;
-	const uint8_t *vol, *grad, *tf;
-	const uint8_t *packed;        // vkv_pack_volume image (PACKED variants) or null
-	int            pmx, pmy;      // macro-bricks per axis of the packed image
-	const uint32_t *tf_bits;      // 2048-word alpha>0 bit table or null
-	const uint8_t *maps[8];
-	float *        out_color;
-	uint8_t *      out_rgba8;
-	uint32_t *     out_counts;
-	float *        out_depth;
-	uint32_t       img_w, img_h, tile_w, tile_h, tiles_x, tile_first, tile_stride, tile_count, compact;
-	uint32_t       blocks_per_tile_x, blocks_per_tile, nblocks;
-	int            test;
-	float          alpha_lut[256];        // opacity correction keyed by the TF alpha byte (frag:283)
+	const uint8_t * vol, *grad, *tf;
+	const uint8_t * packed;         // vkv_pack_volume image (PACKED variants) or null
+	int             pmx, pmy;       // macro-bricks per axis of the packed image
+	const uint32_t *tf_bits;        // 2048-word alpha>0 bit table or null
+	const uint8_t * maps[8];
+	float *         out_color;
+	uint8_t *       out_rgba8;
+	uint32_t *      out_counts;
+	float *         out_depth;
+	uint32_t        img_w, img_h, tile_w, tile_h, tiles_x, tile_first, tile_stride, tile_count, compact;
+	uint32_t        blocks_per_tile_x, blocks_per_tile, nblocks;
+	int             test;
+	uint32_t *      queue_heads;        // persistent scheduler: 8 tile-queue heads (one per XCD label), zeroed per launch
+	float           alpha_lut[256];     // opacity correction keyed by the TF alpha byte (frag:283)
+};
+
+// Per-lane ray state (everything main() of the frag keeps across loop iterations).
+struct Ray
+{
+	float          ex, ey, ez;         // ray_entry
+	float          sx, sy, sz;         // step_volume
+	float          six, siy, siz;      // step_dist_texel_inv (frag:195)
+	const uint8_t *dmap;               // distance map of this ray (anisotropic: chosen by direction octant, frag:209)
+	int            n_steps, i, i_min;
+	int            ulx, uly, ulz;      // u_last_alpha
+	int            first_hit;
+	bool           occupied;
+	float          r, g, b, a;         // out_color
+	float          depth;
+	uint32_t       n_vol, n_dist, n_empty;
+	uint32_t       o;                  // output index of the pixel
 };
 
 // Linear filter, clamp-to-edge (sampler: src/volume_component.cpp:139-148); see DESIGN.md "Pinned numerics".
@@ -75,7 +97,11 @@ __device__ __forceinline__ void sample_packed(const uint8_t *__restrict__ P, int
 	const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy), fz = __builtin_floorf(cz);
 	const float wx = cx - fx, wy = cy - fy, wz = cz - fz;
 	const int   bx = i_clamp((int) fx, -1, W) + 1, by = i_clamp((int) fy, -1, H) + 1, bz = i_clamp((int) fz, -1, D) + 1;
-	const uint8_t *b = P + packed_brick_offset(bx >> 2, by >> 2, bz >> 2, pmx, pmy) + (uint32_t) ((((bz & 3) * 5 + (by & 3)) * 5 + (bx & 3)) * 2);
+	// 32-bit brick index (macro-brick * 512 + brick-in-macro), one 64-bit shift for the byte offset
+	const uint32_t macro = ((uint32_t) (bz >> 5) * (uint32_t) pmy + (uint32_t) (by >> 5)) * (uint32_t) pmx + (uint32_t) (bx >> 5);
+	const uint32_t sub   = (uint32_t) ((((bz >> 2) & 7) << 6) | (((by >> 2) & 7) << 3) | ((bx >> 2) & 7));
+	const uint32_t in    = (uint32_t) ((((bz & 3) * 5 + (by & 3)) * 5 + (bx & 3)) * 2);
+	const uint8_t *b     = P + (((uint64_t) (macro * 512u + sub)) << 8) + in;
 	const uint32_t q00 = *reinterpret_cast<const u32_align2 *>(b);
 	const uint32_t q10 = *reinterpret_cast<const u32_align2 *>(b + 10);
 	const uint32_t q01 = *reinterpret_cast<const u32_align2 *>(b + 50);
@@ -112,342 +138,507 @@ __device__ __forceinline__ void mat4_mul_vec4(const float *m, const float *v, fl
 
 __device__ __forceinline__ uint8_t quantise_rgba8(float c) { return (uint8_t) __builtin_rintf(g_clamp(c, 0.0f, 1.0f) * 255.0f); }
 
-// SKIP: VkvSkippingType; ERT: early ray termination; GRAD: 0 = use_gradient false, 1 = precomputed map, 2 = on the fly.
-// PACKED: sample the vkv_pack_volume image instead of the linear buffers.
-template <int SKIP, bool ERT, int GRAD, bool PACKED>
-__global__ void __launch_bounds__(256) k_raymarch(const RayMarchArgs A)
+// ---------------------------------------------------------------------------------------------------------------
+// Ray generation + frag:147-210.  Returns true when the ray has to be marched; false when the pixel is finished
+// already (not covered, grazing-ray early-out, or a RayEntry / RayExit test output) with its result in R.
+// ---------------------------------------------------------------------------------------------------------------
+template <int SKIP>
+__device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, uint32_t py, Ray &R)
 {
-	__shared__ float    s_alpha[256];
-	__shared__ uint32_t s_bits[2048];
-	s_alpha[threadIdx.x] = A.alpha_lut[threadIdx.x];
-	const bool tf_bits = A.tf_bits != nullptr;        // wave-uniform
-	if (tf_bits)
-		for (int i = threadIdx.x; i < 2048; i += 256)
-			s_bits[i] = A.tf_bits[i];
-	__syncthreads();
-
-	// ---- workgroup -> 16x16 pixel block of one scheduled tile -------------------------------------------------
-	const uint32_t b  = xcd_remap(blockIdx.x, A.nblocks);
-	const uint32_t k  = b / A.blocks_per_tile;        // index into this launch's tile list
-	const uint32_t sb = b % A.blocks_per_tile;
-	const uint32_t t  = A.tile_first + k * A.tile_stride;
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const uint32_t lx = (sb % A.blocks_per_tile_x) * 16 + (wave & 1) * 8 + (lane & 7);        // pixel inside the tile
-	const uint32_t ly = (sb / A.blocks_per_tile_x) * 16 + (wave >> 1) * 8 + (lane >> 3);
-	const uint32_t px = (t % A.tiles_x) * A.tile_w + lx, py = (t / A.tiles_x) * A.tile_h + ly;
-	if (px >= A.img_w || py >= A.img_h)
-		return;
-	const size_t o = A.compact ? ((size_t) k * A.tile_h + ly) * A.tile_w + lx : (size_t) py * A.img_w + px;
-
-	float    out_r = 0.0f, out_g = 0.0f, out_b = 0.0f, out_a = 0.0f, out_depth = 0.0f;        // frag:120, :140
-	uint32_t n_vol = 0, n_dist = 0, n_empty = 0;
-
+	R.r = R.g = R.b = R.a = 0.0f;        // out_color = vec4(0) (frag:120)
+	R.depth = 0.0f;                      // gl_FragDepth = 0 (frag:140)
+	R.n_vol = R.n_dist = R.n_empty = 0;
+	R.n_steps = 0, R.i = 0, R.i_min = 0, R.first_hit = 0;
 	const int W = A.W, H = A.H, D = A.D;
-	// `do { ... } while (0)` so every early-out of the shader funnels into the single store block below
-	do
+
+	// ---- ray generation (replaces volume_render_clipped.vert + volume_render_plane_intersection.vert) ----------
+	const float fx = (float) px + 0.5f, fy = (float) py + 0.5f;
+	float       dx = __builtin_fmaf(fy, A.ddy[0], __builtin_fmaf(fx, A.ddx[0], A.dir00[0]));
+	float       dy = __builtin_fmaf(fy, A.ddy[1], __builtin_fmaf(fx, A.ddx[1], A.dir00[1]));
+	float       dz = __builtin_fmaf(fy, A.ddy[2], __builtin_fmaf(fx, A.ddx[2], A.dir00[2]));
 	{
-		// ---- ray generation (replaces volume_render_clipped.vert + volume_render_plane_intersection.vert) ------
-		const float fx = (float) px + 0.5f, fy = (float) py + 0.5f;
-		float       dx = __builtin_fmaf(fy, A.ddy[0], __builtin_fmaf(fx, A.ddx[0], A.dir00[0]));
-		float       dy = __builtin_fmaf(fy, A.ddy[1], __builtin_fmaf(fx, A.ddx[1], A.dir00[1]));
-		float       dz = __builtin_fmaf(fy, A.ddy[2], __builtin_fmaf(fx, A.ddx[2], A.dir00[2]));
-		{
-			const float len = __builtin_sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
-			dx /= len, dy /= len, dz /= len;
-		}
-		const float ox = A.cam[0], oy = A.cam[1], oz = A.cam[2];
-		float       t_near = -INFINITY, t_far = INFINITY;
-		bool        miss   = false;
-		{
-			const float dv[3] = {dx, dy, dz}, ov[3] = {ox, oy, oz};
+		const float len = __builtin_sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+		dx /= len, dy /= len, dz /= len;
+	}
+	const float ox = A.cam[0], oy = A.cam[1], oz = A.cam[2];
+	float       t_near = -INFINITY, t_far = INFINITY;
+	bool        miss   = false;
+	{
+		const float dv[3] = {dx, dy, dz}, ov[3] = {ox, oy, oz};
 #pragma unroll
-			for (int a = 0; a < 3; ++a)
+		for (int a = 0; a < 3; ++a)
+		{
+			if (dv[a] == 0.0f)
 			{
-				if (dv[a] == 0.0f)
-				{
-					if (ov[a] < 0.0f || ov[a] > 1.0f)
-						miss = true;
-				}
-				else
-				{
-					const float inv = 1.0f / dv[a];
-					const float ta = (0.0f - ov[a]) * inv, tb = (1.0f - ov[a]) * inv;
-					t_near = g_max(t_near, g_min(ta, tb));
-					t_far  = g_min(t_far, g_max(ta, tb));
-				}
-			}
-		}
-		if (miss)
-			break;
-		const float Ap = __builtin_fmaf(A.plane_tex[2], oz, __builtin_fmaf(A.plane_tex[1], oy, A.plane_tex[0] * ox)) + A.plane_tex[3];
-		const float Bp = __builtin_fmaf(A.plane_tex[2], dz, __builtin_fmaf(A.plane_tex[1], dy, A.plane_tex[0] * dx));
-		if (!(Bp > 0.0f))
-			break;
-		const float t_plane = (0.0f - Ap) / Bp;
-		const float t0      = g_max(t_near, t_plane);
-		if (!(t0 < t_far))
-			break;
-		const float ex = __builtin_fmaf(t0, dx, ox), ey = __builtin_fmaf(t0, dy, oy), ez = __builtin_fmaf(t0, dz, oz);        // ray_entry
-
-		// ---- frag:147-149 ------------------------------------------------------------------------------------
-		float rdx, rdy, rdz;
-		{
-			const float vx = ex - ox, vy = ey - oy, vz = ez - oz;
-			const float len = __builtin_sqrtf(__builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx)));
-			rdx = vx / len, rdy = vy / len, rdz = vz / len;
-		}
-		float xx, xy, xz, ray_distance;        // ray_exit
-		{
-			const float ix = 1.0f / rdx, iy = 1.0f / rdy, iz = 1.0f / rdz;
-			const float tminx = -ex * ix, tminy = -ey * iy, tminz = -ez * iz;
-			const float tmaxx = (1.0f - ex) * ix, tmaxy = (1.0f - ey) * iy, tmaxz = (1.0f - ez) * iz;
-			const float t2x = g_max(tminx, tmaxx), t2y = g_max(tminy, tmaxy), t2z = g_max(tminz, tmaxz);
-			const float tFar = g_min(g_min(t2x, t2y), t2z);
-			xx = __builtin_fmaf(tFar, rdx, ex), xy = __builtin_fmaf(tFar, rdy, ey), xz = __builtin_fmaf(tFar, rdz, ez);
-			const float vx = ex - xx, vy = ey - xy, vz = ez - xz;
-			ray_distance = __builtin_sqrtf(__builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx)));
-		}
-		if (A.test == VKV_TEST_RAY_ENTRY)
-		{
-			out_r = ex, out_g = ey, out_b = ez, out_a = 1.0f;
-			break;
-		}
-		if (A.test == VKV_TEST_RAY_EXIT)
-		{
-			out_r = xx, out_g = xy, out_b = xz, out_a = 1.0f;
-			break;
-		}
-
-		// ---- frag:176-187 ------------------------------------------------------------------------------------
-		const int   dim_max = max(max(W, H), D);
-		const float sf      = A.sampling_factor;
-		const float nf      = __builtin_ceilf((float) dim_max * ray_distance * sf);
-		if (!(nf >= 2.0f && nf <= 16777216.0f))
-			break;
-		const int   n_steps = (int) nf;
-		const float sx = (rdx * ray_distance) / (nf - 1.0f), sy = (rdy * ray_distance) / (nf - 1.0f), sz = (rdz * ray_distance) / (nf - 1.0f);
-		{
-			const float qx = ex + sx, qy = ey + sy, qz = ez + sz;
-			if (qx <= 0.0f || qy <= 0.0f || qz <= 0.0f || qx >= 1.0f || qy >= 1.0f || qz >= 1.0f)
-				break;
-		}
-
-		// ---- frag:191-210 ------------------------------------------------------------------------------------
-		float kx = 0, ky = 0, kz = 0, six = 0, siy = 0, siz = 0;
-		if (SKIP != VKV_SKIP_NONE)
-		{
-			kx = (float) W / A.block_size[0], ky = (float) H / A.block_size[1], kz = (float) D / A.block_size[2];
-			six = 1.0f / ((sx * (float) W) / A.block_size[0]);
-			siy = 1.0f / ((sy * (float) H) / A.block_size[1]);
-			siz = 1.0f / ((sz * (float) D) / A.block_size[2]);
-		}
-		const int      mw = A.mw, mh = A.mh, md = A.md;
-		const uint8_t *dmap = nullptr;
-		if (SKIP == VKV_SKIP_ANISOTROPIC_DISTANCE)
-			dmap = A.maps[(rdz < 0 ? 1 : 0) + (rdy < 0 ? 2 : 0) + (rdx < 0 ? 4 : 0)];
-		else if (SKIP != VKV_SKIP_NONE)
-			dmap = A.maps[0];
-		const float dix = 1.0f / (float) W, diy = 1.0f / (float) H, diz = 1.0f / (float) D;
-		const int   back = (int) __builtin_ceilf(sf);
-
-		int  i_min_ = 0, ulx = 0, uly = 0, ulz = 0;
-		bool occupied = true;
-		int  i_first_hit = n_steps;
-
-		// ---- frag:215-312 ------------------------------------------------------------------------------------
-		for (int i = 0; i < n_steps;)
-		{
-			const float fi = (float) i;
-			const float posx = __builtin_fmaf(fi, sx, ex), posy = __builtin_fmaf(fi, sy, ey), posz = __builtin_fmaf(fi, sz, ez);
-			int   uix = 0, uiy = 0, uiz = 0;
-			float ux = 0, uy = 0, uz = 0;
-			if (SKIP != VKV_SKIP_NONE)
-			{
-				ux = kx * posx, uy = ky * posy, uz = kz * posz;
-				uix = i_clamp((int) ux, 0, mw - 1), uiy = i_clamp((int) uy, 0, mh - 1), uiz = i_clamp((int) uz, 0, md - 1);
-			}
-			if (SKIP != VKV_SKIP_NONE && !occupied && (uix != ulx || uiy != uly || uiz != ulz))
-			{
-				++n_dist;
-				const uint32_t dist = dmap[vidx(uix, uiy, uiz, mw, mh)];
-				if (dist > 0u)
-				{
-					const float rx = g_clamp((float) uix - ux, -1.0f, 0.0f);
-					const float ry = g_clamp((float) uiy - uy, -1.0f, 0.0f);
-					const float rz = g_clamp((float) uiz - uz, -1.0f, 0.0f);
-					float       ax, ay, az;
-					if (SKIP == VKV_SKIP_BLOCK)
-					{
-						ax = (g_step(0.0f, six) + rx) * six;
-						ay = (g_step(0.0f, siy) + ry) * siy;
-						az = (g_step(0.0f, siz) + rz) * siz;
-					}
-					else
-					{
-						const float fd = (float) dist;
-						ax = ((g_step(0.0f, -six) + g_sign(six) * fd) + rx) * six;
-						ay = ((g_step(0.0f, -siy) + g_sign(siy) * fd) + ry) * siy;
-						az = ((g_step(0.0f, -siz) + g_sign(siz) * fd) + rz) * siz;
-					}
-					if (ax != ax) ax = INFINITY;
-					if (ay != ay) ay = INFINITY;
-					if (az != az) az = INFINITY;
-					float m = g_min(g_min(ax, ay), az);
-					m       = (m < 1073741824.0f) ? m : 1073741824.0f;
-					i += max(1, (int) __builtin_ceilf(m));
-				}
-				else
-				{
-					occupied = true;
-					ulx = uix, uly = uiy, ulz = uiz;
-					i = max(i - back, i_min_);
-				}
+				if (ov[a] < 0.0f || ov[a] > 1.0f)
+					miss = true;
 			}
 			else
 			{
-				++n_vol;
-				float intensity, gradient = 1.0f;
-				if (PACKED)
-				{
-					float unused;
-					if (GRAD == 1)
-						sample_packed<true>(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, intensity, gradient);
-					else
-						sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, intensity, unused);
-				}
-				else
-				{
-					intensity = sample_linear(A.vol, W, H, D, posx, posy, posz);
-					if (GRAD == 1)
-						gradient = sample_linear(A.grad, W, H, D, posx, posy, posz);
-				}
-				if (GRAD == 2)
-				{
-					float t1, t2, t3, t4, unused;
-					if (PACKED)
-					{
-						sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx + dix, posy - diy, posz - diz, t1, unused);
-						sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx - dix, posy - diy, posz + diz, t2, unused);
-						sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx - dix, posy + diy, posz - diz, t3, unused);
-						sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx + dix, posy + diy, posz + diz, t4, unused);
-					}
-					else
-					{
-						t1 = sample_linear(A.vol, W, H, D, posx + dix, posy - diy, posz - diz);
-						t2 = sample_linear(A.vol, W, H, D, posx - dix, posy - diy, posz + diz);
-						t3 = sample_linear(A.vol, W, H, D, posx - dix, posy + diy, posz - diz);
-						t4 = sample_linear(A.vol, W, H, D, posx + dix, posy + diy, posz + diz);
-					}
-					const float gx = (((t1 - t2) - t3) + t4) * 0.25f;
-					const float gy = (((-t1 - t2) + t3) + t4) * 0.25f;
-					const float gz = (((-t1 + t2) - t3) + t4) * 0.25f;
-					const float len = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
-					gradient = g_clamp(len * A.grad_modifier, 0.0f, 1.0f);
-				}
-				// get_color (transfer_function.glsl:35-38): NEAREST texel.  With the bit table the occupied test (frag:276)
-				// comes from LDS and only occupied samples pay the dependent RGBA fetch.
-				const uint32_t tidx  = (uint32_t) tf_texel(gradient) * 256u + (uint32_t) tf_texel(intensity);
-				uint32_t       texel = 0;
-				if (tf_bits)
-				{
-					if ((s_bits[tidx >> 5] >> (tidx & 31u)) & 1u)
-						texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
-				}
-				else
-					texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
-				const uint32_t ab = texel >> 24;
-				occupied          = ab > 0;
-				if (occupied)
-				{
-					if (SKIP != VKV_SKIP_NONE)
-						ulx = uix, uly = uiy, ulz = uiz;
-					const float a  = s_alpha[ab];
-					const float r_ = unorm8(texel & 255u) * a, g_ = unorm8((texel >> 8) & 255u) * a, b_ = unorm8((texel >> 16) & 255u) * a;
-					const float om = 1.0f - out_a;
-					out_r = __builtin_fmaf(om, r_, out_r), out_g = __builtin_fmaf(om, g_, out_g), out_b = __builtin_fmaf(om, b_, out_b);
-					out_a = __builtin_fmaf(om, a, out_a);
-					if (a > 0.0f)
-						i_first_hit = i;
-					if (ERT && out_a > 0.99f)
-					{
-						out_a = 1.0f;
-						break;
-					}
-				}
-				else
-					++n_empty;
-				++i;
-				i_min_ = i;
+				const float inv = 1.0f / dv[a];
+				const float ta = (0.0f - ov[a]) * inv, tb = (1.0f - ov[a]) * inv;
+				t_near = g_max(t_near, g_min(ta, tb));
+				t_far  = g_min(t_far, g_max(ta, tb));
 			}
 		}
+	}
+	if (miss)
+		return false;
+	const float Ap = __builtin_fmaf(A.plane_tex[2], oz, __builtin_fmaf(A.plane_tex[1], oy, A.plane_tex[0] * ox)) + A.plane_tex[3];
+	const float Bp = __builtin_fmaf(A.plane_tex[2], dz, __builtin_fmaf(A.plane_tex[1], dy, A.plane_tex[0] * dx));
+	if (!(Bp > 0.0f))
+		return false;
+	const float t_plane = (0.0f - Ap) / Bp;
+	const float t0      = g_max(t_near, t_plane);
+	if (!(t0 < t_far))
+		return false;
+	const float ex = __builtin_fmaf(t0, dx, ox), ey = __builtin_fmaf(t0, dy, oy), ez = __builtin_fmaf(t0, dz, oz);        // ray_entry
 
-		// ---- frag:315-321 ------------------------------------------------------------------------------------
-		if (out_a > 0.0f && i_first_hit < n_steps)
+	// ---- frag:147-149 --------------------------------------------------------------------------------------
+	float rdx, rdy, rdz;
+	{
+		const float vx = ex - ox, vy = ey - oy, vz = ez - oz;
+		const float len = __builtin_sqrtf(__builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx)));
+		rdx = vx / len, rdy = vy / len, rdz = vz / len;
+	}
+	float xx, xy, xz, ray_distance;        // ray_exit
+	{
+		const float ix = 1.0f / rdx, iy = 1.0f / rdy, iz = 1.0f / rdz;
+		const float tminx = -ex * ix, tminy = -ey * iy, tminz = -ez * iz;
+		const float tmaxx = (1.0f - ex) * ix, tmaxy = (1.0f - ey) * iy, tmaxz = (1.0f - ez) * iz;
+		const float t2x = g_max(tminx, tmaxx), t2y = g_max(tminy, tmaxy), t2z = g_max(tminz, tmaxz);
+		const float tFar = g_min(g_min(t2x, t2y), t2z);
+		xx = __builtin_fmaf(tFar, rdx, ex), xy = __builtin_fmaf(tFar, rdy, ey), xz = __builtin_fmaf(tFar, rdz, ez);
+		const float vx = ex - xx, vy = ey - xy, vz = ez - xz;
+		ray_distance = __builtin_sqrtf(__builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx)));
+	}
+	if (A.test == VKV_TEST_RAY_ENTRY)
+	{
+		R.r = ex, R.g = ey, R.b = ez, R.a = 1.0f;
+		return false;
+	}
+	if (A.test == VKV_TEST_RAY_EXIT)
+	{
+		R.r = xx, R.g = xy, R.b = xz, R.a = 1.0f;
+		return false;
+	}
+
+	// ---- frag:176-187 --------------------------------------------------------------------------------------
+	const int   dim_max = max(max(W, H), D);
+	const float nf      = __builtin_ceilf((float) dim_max * ray_distance * A.sampling_factor);
+	if (!(nf >= 2.0f && nf <= 16777216.0f))
+		return false;
+	const float sx = (rdx * ray_distance) / (nf - 1.0f), sy = (rdy * ray_distance) / (nf - 1.0f), sz = (rdz * ray_distance) / (nf - 1.0f);
+	{
+		const float qx = ex + sx, qy = ey + sy, qz = ez + sz;
+		if (qx <= 0.0f || qy <= 0.0f || qz <= 0.0f || qx >= 1.0f || qy >= 1.0f || qz >= 1.0f)
+			return false;
+	}
+	R.ex = ex, R.ey = ey, R.ez = ez, R.sx = sx, R.sy = sy, R.sz = sz;
+	R.n_steps = (int) nf;
+
+	// ---- frag:191-214 --------------------------------------------------------------------------------------
+	R.six = R.siy = R.siz = 0.0f;
+	R.dmap                = nullptr;
+	if (SKIP != VKV_SKIP_NONE)
+	{
+		R.six = 1.0f / ((sx * (float) W) / A.block_size[0]);
+		R.siy = 1.0f / ((sy * (float) H) / A.block_size[1]);
+		R.siz = 1.0f / ((sz * (float) D) / A.block_size[2]);
+		if (SKIP == VKV_SKIP_ANISOTROPIC_DISTANCE)
+			R.dmap = A.maps[(rdz < 0 ? 1 : 0) + (rdy < 0 ? 2 : 0) + (rdx < 0 ? 4 : 0)];
+		else
+			R.dmap = A.maps[0];
+	}
+	R.i = 0, R.i_min = 0, R.ulx = R.uly = R.ulz = 0;
+	R.occupied  = true;
+	R.first_hit = R.n_steps;
+	return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One iteration of the frag's loop (frag:215-312): either one distance-map probe or one volume sample.
+// Returns true when the ray has ended (ran past n_steps, or early ray termination).
+// ---------------------------------------------------------------------------------------------------------------
+template <int SKIP, bool ERT, int GRAD, bool PACKED>
+__device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const float *s_alpha, const uint32_t *s_bits, bool tf_bits)
+{
+	const int   W = A.W, H = A.H, D = A.D;
+	const int   i  = R.i;
+	const float fi = (float) i;
+	const float posx = __builtin_fmaf(fi, R.sx, R.ex), posy = __builtin_fmaf(fi, R.sy, R.ey), posz = __builtin_fmaf(fi, R.sz, R.ez);
+	int         uix = 0, uiy = 0, uiz = 0;
+	float       ux = 0, uy = 0, uz = 0;
+	if (SKIP != VKV_SKIP_NONE)
+	{        // frag:192, 220-221 (volume_to_distance_map_u is the same for every ray)
+		const float kx = (float) W / A.block_size[0], ky = (float) H / A.block_size[1], kz = (float) D / A.block_size[2];
+		ux = kx * posx, uy = ky * posy, uz = kz * posz;
+		uix = i_clamp((int) ux, 0, A.mw - 1), uiy = i_clamp((int) uy, 0, A.mh - 1), uiz = i_clamp((int) uz, 0, A.md - 1);
+	}
+	if (SKIP != VKV_SKIP_NONE && !R.occupied && (uix != R.ulx || uiy != R.uly || uiz != R.ulz))
+	{        // frag:224-263
+		++R.n_dist;
+		const uint32_t dist = R.dmap[((uint32_t) uiz * (uint32_t) A.mh + (uint32_t) uiy) * (uint32_t) A.mw + (uint32_t) uix];
+		if (dist > 0u)
 		{
-			const float fi   = (float) i_first_hit;
-			const float p[4] = {__builtin_fmaf(fi, sx, ex) - 0.5f, __builtin_fmaf(fi, sy, ey) - 0.5f, __builtin_fmaf(fi, sz, ez) - 0.5f, 1.0f};
+			// r = clamp(u_i - u, -1, 0) (frag:234); the operand is never NaN, so the median-of-three instruction gives the
+			// same value as min(max(x, -1), 0)
+			const float rx = __builtin_amdgcn_fmed3f((float) uix - ux, -1.0f, 0.0f);
+			const float ry = __builtin_amdgcn_fmed3f((float) uiy - uy, -1.0f, 0.0f);
+			const float rz = __builtin_amdgcn_fmed3f((float) uiz - uz, -1.0f, 0.0f);
+			float       ax, ay, az;
+			if (SKIP == VKV_SKIP_BLOCK)
+			{        // frag:239: step(0, s) is 1 for s >= 0 (and for the impossible NaN), 0 for s < 0
+				ax = (((R.six < 0.0f) ? 0.0f : 1.0f) + rx) * R.six;
+				ay = (((R.siy < 0.0f) ? 0.0f : 1.0f) + ry) * R.siy;
+				az = (((R.siz < 0.0f) ? 0.0f : 1.0f) + rz) * R.siz;
+			}
+			else
+			{        // frag:242: step(0, -s) + sign(s) * dist is exactly dist for s > 0 and 1 - dist for s < 0 (s is never 0 or NaN:
+				 // it is the reciprocal of a finite number)
+				const float fd = (float) dist;
+				ax = (((R.six > 0.0f) ? fd : 1.0f - fd) + rx) * R.six;
+				ay = (((R.siy > 0.0f) ? fd : 1.0f - fd) + ry) * R.siy;
+				az = (((R.siz > 0.0f) ? fd : 1.0f - fd) + rz) * R.siz;
+			}
+			if (ax != ax) ax = INFINITY;
+			if (ay != ay) ay = INFINITY;
+			if (az != az) az = INFINITY;
+			float m = g_min(g_min(ax, ay), az);
+			m       = (m < 1073741824.0f) ? m : 1073741824.0f;
+			R.i     = i + max(1, (int) __builtin_ceilf(m));
+		}
+		else
+		{
+			R.occupied = true;
+			R.ulx = uix, R.uly = uiy, R.ulz = uiz;
+			R.i = max(i - (int) __builtin_ceilf(A.sampling_factor), R.i_min);
+		}
+		return R.i >= R.n_steps;
+	}
+
+	// frag:266-310
+	++R.n_vol;
+	float intensity, gradient = 1.0f;
+	if (PACKED)
+	{
+		float unused;
+		if (GRAD == 1)
+			sample_packed<true>(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, intensity, gradient);
+		else
+			sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, intensity, unused);
+	}
+	else
+	{
+		intensity = sample_linear(A.vol, W, H, D, posx, posy, posz);
+		if (GRAD == 1)
+			gradient = sample_linear(A.grad, W, H, D, posx, posy, posz);
+	}
+	if (GRAD == 2)
+	{        // frag:92-97
+		const float dix = 1.0f / (float) W, diy = 1.0f / (float) H, diz = 1.0f / (float) D;
+		float       t1, t2, t3, t4, unused;
+		if (PACKED)
+		{
+			sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx + dix, posy - diy, posz - diz, t1, unused);
+			sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx - dix, posy - diy, posz + diz, t2, unused);
+			sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx - dix, posy + diy, posz - diz, t3, unused);
+			sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx + dix, posy + diy, posz + diz, t4, unused);
+		}
+		else
+		{
+			t1 = sample_linear(A.vol, W, H, D, posx + dix, posy - diy, posz - diz);
+			t2 = sample_linear(A.vol, W, H, D, posx - dix, posy - diy, posz + diz);
+			t3 = sample_linear(A.vol, W, H, D, posx - dix, posy + diy, posz - diz);
+			t4 = sample_linear(A.vol, W, H, D, posx + dix, posy + diy, posz + diz);
+		}
+		const float gx = (((t1 - t2) - t3) + t4) * 0.25f;
+		const float gy = (((-t1 - t2) + t3) + t4) * 0.25f;
+		const float gz = (((-t1 + t2) - t3) + t4) * 0.25f;
+		const float len = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
+		gradient = g_clamp(len * A.grad_modifier, 0.0f, 1.0f);
+	}
+	// get_color (transfer_function.glsl:35-38): NEAREST texel.  With the bit table the occupied test (frag:276) comes
+	// from LDS and only occupied samples pay the dependent RGBA fetch.
+	const uint32_t tidx  = (uint32_t) tf_texel(gradient) * 256u + (uint32_t) tf_texel(intensity);
+	uint32_t       texel = 0;
+	if (tf_bits)
+	{
+		if ((s_bits[tidx >> 5] >> (tidx & 31u)) & 1u)
+			texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
+	}
+	else
+		texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
+	const uint32_t ab = texel >> 24;
+	R.occupied        = ab > 0;
+	bool ended        = false;
+	if (R.occupied)
+	{
+		if (SKIP != VKV_SKIP_NONE)
+			R.ulx = uix, R.uly = uiy, R.ulz = uiz;
+		const float a  = s_alpha[ab];        // frag:283
+		const float r_ = unorm8(texel & 255u) * a, g_ = unorm8((texel >> 8) & 255u) * a, b_ = unorm8((texel >> 16) & 255u) * a;
+		const float om = 1.0f - R.a;         // frag:287
+		R.r = __builtin_fmaf(om, r_, R.r), R.g = __builtin_fmaf(om, g_, R.g), R.b = __builtin_fmaf(om, b_, R.b);
+		R.a = __builtin_fmaf(om, a, R.a);
+		if (a > 0.0f)
+			R.first_hit = i;
+		if (ERT && R.a > 0.99f)
+		{        // frag:293-299
+			R.a   = 1.0f;
+			ended = true;
+		}
+	}
+	else
+		++R.n_empty;
+	if (!ended)
+	{
+		R.i     = i + 1;
+		R.i_min = R.i;
+		ended   = R.i >= R.n_steps;
+	}
+	return ended;
+}
+
+// frag:315-334 + the stores.  `marched` is false for pixels that never entered the loop.
+__device__ __forceinline__ void ray_finish(const RayMarchArgs &A, Ray &R, bool marched)
+{
+	if (marched)
+	{
+		if (A.out_depth && R.a > 0.0f && R.first_hit < R.n_steps)
+		{        // frag:315-321
+			const float fi   = (float) R.first_hit;
+			const float p[4] = {__builtin_fmaf(fi, R.sx, R.ex) - 0.5f, __builtin_fmaf(fi, R.sy, R.ey) - 0.5f, __builtin_fmaf(fi, R.sz, R.ez) - 0.5f, 1.0f};
 			float       a4[4], b4[4], c4[4];
 			mat4_mul_vec4(A.model, p, a4);
 			mat4_mul_vec4(A.view, a4, b4);
 			mat4_mul_vec4(A.proj, b4, c4);
-			out_depth = c4[2] / c4[3];
+			R.depth = c4[2] / c4[3];
 		}
 		if (A.test == VKV_TEST_NUM_TEXTURE_SAMPLES)
 		{        // frag:324-334
-			const uint32_t n_steps_max = (uint32_t) (__builtin_ceilf((float) dim_max * __builtin_sqrtf(3.0f)) * sf);
-			const float    v           = (float) (n_vol + n_dist) / (float) n_steps_max;
-			out_r = out_g = out_b = v;
-			out_a                 = 1.0f;
+			const int      dim_max     = max(max(A.W, A.H), A.D);
+			const uint32_t n_steps_max = (uint32_t) (__builtin_ceilf((float) dim_max * __builtin_sqrtf(3.0f)) * A.sampling_factor);
+			const float    v           = (float) (R.n_vol + R.n_dist) / (float) n_steps_max;
+			R.r = R.g = R.b = v;
+			R.a             = 1.0f;
 		}
-	} while (0);
-
+	}
+	const size_t o = R.o;
 	if (A.out_color)
-		reinterpret_cast<float4 *>(A.out_color)[o] = make_float4(out_r, out_g, out_b, out_a);
+		reinterpret_cast<float4 *>(A.out_color)[o] = make_float4(R.r, R.g, R.b, R.a);
 	if (A.out_rgba8)
-		reinterpret_cast<uint32_t *>(A.out_rgba8)[o] = (uint32_t) quantise_rgba8(out_r) | ((uint32_t) quantise_rgba8(out_g) << 8) |
-		                                               ((uint32_t) quantise_rgba8(out_b) << 16) | ((uint32_t) quantise_rgba8(out_a) << 24);
+		reinterpret_cast<uint32_t *>(A.out_rgba8)[o] = (uint32_t) quantise_rgba8(R.r) | ((uint32_t) quantise_rgba8(R.g) << 8) |
+		                                               ((uint32_t) quantise_rgba8(R.b) << 16) | ((uint32_t) quantise_rgba8(R.a) << 24);
 	if (A.out_counts)
 	{
-		A.out_counts[o * 3 + 0] = n_vol;
-		A.out_counts[o * 3 + 1] = n_dist;
-		A.out_counts[o * 3 + 2] = n_empty;
+		A.out_counts[o * 3 + 0] = R.n_vol;
+		A.out_counts[o * 3 + 1] = R.n_dist;
+		A.out_counts[o * 3 + 2] = R.n_empty;
 	}
 	if (A.out_depth)
-		A.out_depth[o] = out_depth;
+		A.out_depth[o] = R.depth;
+}
+
+// 8x8 work unit `u` (4 per 16x16 block of the tile schedule) + ray slot in the unit -> pixel and output index.
+__device__ __forceinline__ bool unit_pixel(const RayMarchArgs &A, uint32_t u, uint32_t slot, uint32_t &px, uint32_t &py, uint32_t &o)
+{
+	const uint32_t b = u >> 2, w = u & 3u;
+	const uint32_t k = b / A.blocks_per_tile, sb = b % A.blocks_per_tile;
+	const uint32_t t = A.tile_first + k * A.tile_stride;
+	const uint32_t lx = (sb % A.blocks_per_tile_x) * 16 + (w & 1) * 8 + (slot & 7);
+	const uint32_t ly = (sb / A.blocks_per_tile_x) * 16 + (w >> 1) * 8 + (slot >> 3);
+	px = (t % A.tiles_x) * A.tile_w + lx, py = (t / A.tiles_x) * A.tile_h + ly;
+	o  = A.compact ? (k * A.tile_h + ly) * A.tile_w + lx : py * A.img_w + px;
+	return px < A.img_w && py < A.img_h;
+}
+
+__device__ __forceinline__ void stage_tables(const RayMarchArgs &A, float *s_alpha, uint32_t *s_bits)
+{
+	s_alpha[threadIdx.x] = A.alpha_lut[threadIdx.x];
+	if (A.tf_bits)
+		for (int i = threadIdx.x; i < 2048; i += 256)
+			s_bits[i] = A.tf_bits[i];
+	__syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Static scheduler: workgroup = 16x16 pixels, wave = 8x8 pixels.
+// ---------------------------------------------------------------------------------------------------------------
+template <int SKIP, bool ERT, int GRAD, bool PACKED>
+__global__ void __launch_bounds__(256) k_raymarch_tiles(const RayMarchArgs A)
+{
+	__shared__ float    s_alpha[256];
+	__shared__ uint32_t s_bits[2048];
+	stage_tables(A, s_alpha, s_bits);
+	const bool tf_bits = A.tf_bits != nullptr;
+	// Hardware deals workgroup ids round-robin over the 8 XCDs (own L2 each).  XCD x = id & 7 marches the schedule's
+	// tiles k = x, x + 8, x + 16, ... one after the other: neighbouring workgroups of an XCD share a tile (L2 locality)
+	// while the tiles of the frame are spread evenly over the XCDs (ESS makes screen regions differ >10x in cost; a
+	// contiguous band per XCD left most of the chip idle behind the XCD that owned the centre of the image).
+	const uint32_t x = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+	const uint32_t k = (idx / A.blocks_per_tile) * 8u + x, sb = idx % A.blocks_per_tile;
+	if (k >= A.tile_count)
+		return;
+	uint32_t px, py, o;
+	if (!unit_pixel(A, (k * A.blocks_per_tile + sb) * 4 + (threadIdx.x >> 6), threadIdx.x & 63, px, py, o))
+		return;
+	Ray R;
+	R.o = o;
+	const bool marched = ray_setup<SKIP>(A, px, py, R);
+	if (marched)
+		while (!ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_bits, tf_bits))
+		{
+		}
+	ray_finish(A, R, marched);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent scheduler.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kInvalidUnit  = 0xffffffffu;
+constexpr uint32_t kRefillLanes  = 16;        // re-fill a wave once this many lanes are idle
+
+// Queue q owns the schedule's tiles k = q, q + 8, ... (same tile -> XCD mapping as the static scheduler); its v-th
+// work unit is 8x8 sub-tile v % upt of its (v / upt)-th tile, upt = 4 * blocks_per_tile units per tile.
+__device__ __forceinline__ uint32_t queue_units(const RayMarchArgs &A, uint32_t q)
+{
+	const uint32_t tiles = A.tile_count > q ? (A.tile_count - q + 7u) >> 3 : 0u;
+	return tiles * A.blocks_per_tile * 4u;
+}
+
+// Pop one unit for this wave (wave-uniform result).  Starts at the wave's own queue and steals from the others once
+// it is empty.  `q` is updated to the queue that delivered.
+__device__ __forceinline__ uint32_t pop_unit(const RayMarchArgs &A, uint32_t &q)
+{
+	const uint32_t upt = A.blocks_per_tile * 4u;
+	for (uint32_t tries = 0; tries < 8; ++tries)
+	{
+		uint32_t v = 0;
+		if ((threadIdx.x & 63) == 0)
+			v = atomicAdd(&A.queue_heads[q], 1u);
+		v = __builtin_amdgcn_readfirstlane(v);
+		if (v < queue_units(A, q))
+			return ((v / upt) * 8u + q) * upt + v % upt;
+		q = (q + 1) & 7u;
+	}
+	return kInvalidUnit;
+}
+
+template <int SKIP, bool ERT, int GRAD, bool PACKED>
+__global__ void __launch_bounds__(256) k_raymarch_persistent(const RayMarchArgs A)
+{
+	__shared__ float    s_alpha[256];
+	__shared__ uint32_t s_bits[2048];
+	stage_tables(A, s_alpha, s_bits);
+	const bool     tf_bits = A.tf_bits != nullptr;
+	// blocks b and b + 8 share an XCD under the observed round-robin placement (speed only, never correctness)
+	uint32_t q      = blockIdx.x & 7u;
+	uint32_t unit   = pop_unit(A, q);
+	uint32_t cursor = 0;        // next unassigned ray slot of `unit`
+	bool     active = false;
+	Ray      R;
+	R.o = 0;
+
+	for (;;)
+	{
+		uint64_t idle   = __ballot(!active);
+		uint32_t n_idle = (uint32_t) __popcll(idle);
+		// ---- re-fill: idle lanes take the next ray slots of the current unit, in lane order ----
+		while (n_idle >= kRefillLanes && unit != kInvalidUnit)
+		{
+			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
+			const uint32_t take = min(n_idle, 64u - cursor);
+			if (!active && rank < take)
+			{
+				uint32_t px, py, o;
+				if (unit_pixel(A, unit, cursor + rank, px, py, o))
+				{
+					R.o    = o;
+					active = ray_setup<SKIP>(A, px, py, R);
+					if (!active)
+						ray_finish(A, R, false);        // not covered / early-out / entry-exit test: result is final
+				}
+			}
+			cursor += take;
+			if (cursor == 64)
+			{
+				unit   = pop_unit(A, q);
+				cursor = 0;
+			}
+			idle   = __ballot(!active);
+			n_idle = (uint32_t) __popcll(idle);
+		}
+		if (n_idle == 64)
+			break;        // nothing in flight and the queues are empty
+		// ---- one event per active lane ----
+		if (active)
+		{
+			if (ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_bits, tf_bits))
+			{
+				ray_finish(A, R, true);
+				active = false;
+			}
+		}
+	}
 }
 
 namespace vkv
 {
 
-template <int SKIP, bool ERT, bool PACKED>
-static void launch_grad(int grad, const RayMarchArgs &a, hipStream_t s)
+enum Scheduler
 {
-	const dim3 grid(a.nblocks), block(256);
-	if (grad == 0)
-		hipLaunchKernelGGL((k_raymarch<SKIP, ERT, 0, PACKED>), grid, block, 0, s, a);
-	else if (grad == 1)
-		hipLaunchKernelGGL((k_raymarch<SKIP, ERT, 1, PACKED>), grid, block, 0, s, a);
+	kSchedTiles      = 0,
+	kSchedPersistent = 1
+};
+
+template <int SKIP, bool ERT, int GRAD, bool PACKED>
+static int launch_one(vkv_ctx *ctx, int sched, const RayMarchArgs &a, hipStream_t s)
+{
+	if (sched == kSchedPersistent)
+	{
+		static int resident = 0;        // blocks per CU x CUs for this variant (same on every device of a node)
+		if (resident == 0)
+		{
+			int per_cu = 0, dev = 0;
+			hipDeviceProp_t prop;
+			if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+			    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_raymarch_persistent<SKIP, ERT, GRAD, PACKED>, 256, 0) != hipSuccess || per_cu < 1)
+				return set_error(ctx, VKV_E_NO_DEVICE, "render: occupancy query failed");
+			resident = per_cu * prop.multiProcessorCount;
+		}
+		const hipError_t e = hipMemsetAsync(a.queue_heads, 0, 8 * sizeof(uint32_t), s);
+		if (e != hipSuccess)
+			return set_error(ctx, (int) e, "render: queue reset: %s", hipGetErrorString(e));
+		// never more workgroups than there are 8x8 units to hand out (4 waves per workgroup)
+		const uint32_t grid = (uint32_t) resident < a.nblocks ? (uint32_t) resident : a.nblocks;
+		hipLaunchKernelGGL((k_raymarch_persistent<SKIP, ERT, GRAD, PACKED>), dim3(grid), dim3(256), 0, s, a);
+	}
 	else
-		hipLaunchKernelGGL((k_raymarch<SKIP, ERT, 2, PACKED>), grid, block, 0, s, a);
+	{
+		// ids are dealt round-robin to the XCDs, each XCD walking its own tiles: pad the tile count to a multiple of 8
+		const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile;
+		hipLaunchKernelGGL((k_raymarch_tiles<SKIP, ERT, GRAD, PACKED>), dim3(grid), dim3(256), 0, s, a);
+	}
+	return check_launch(ctx, "render");
+}
+
+template <int SKIP, bool ERT, bool PACKED>
+static int launch_grad(vkv_ctx *ctx, int sched, int grad, const RayMarchArgs &a, hipStream_t s)
+{
+	if (grad == 0)
+		return launch_one<SKIP, ERT, 0, PACKED>(ctx, sched, a, s);
+	if (grad == 1)
+		return launch_one<SKIP, ERT, 1, PACKED>(ctx, sched, a, s);
+	return launch_one<SKIP, ERT, 2, PACKED>(ctx, sched, a, s);
 }
 
 template <int SKIP>
-static void launch_ert(bool ert, int grad, const RayMarchArgs &a, hipStream_t s)
+static int launch_ert(vkv_ctx *ctx, int sched, bool ert, int grad, const RayMarchArgs &a, hipStream_t s)
 {
 	if (a.packed)
-	{
-		if (ert)
-			launch_grad<SKIP, true, true>(grad, a, s);
-		else
-			launch_grad<SKIP, false, true>(grad, a, s);
-	}
-	else
-	{
-		if (ert)
-			launch_grad<SKIP, true, false>(grad, a, s);
-		else
-			launch_grad<SKIP, false, false>(grad, a, s);
-	}
+		return ert ? launch_grad<SKIP, true, true>(ctx, sched, grad, a, s) : launch_grad<SKIP, false, true>(ctx, sched, grad, a, s);
+	return ert ? launch_grad<SKIP, true, false>(ctx, sched, grad, a, s) : launch_grad<SKIP, false, false>(ctx, sched, grad, a, s);
 }
 
 int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, hipStream_t s)
@@ -486,24 +677,32 @@ int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut
 	const uint64_t nb   = (uint64_t) a.blocks_per_tile * a.tile_count;
 	if (nb == 0)
 		return VKV_OK;
-	if (nb > 0x7fffffffull)
+	if (nb > 0x3fffffffull)
 		return set_error(ctx, VKV_E_UNSUPPORTED, "render: too many tiles for one launch");
-	a.nblocks = (uint32_t) nb;
-	a.test    = P->options.test;
+	// output indices are 32-bit inside the kernel
+	if ((uint64_t) a.img_w * a.img_h > 0xffffffffull / 4 || nb * 256 > 0xffffffffull / 4)
+		return set_error(ctx, VKV_E_UNSUPPORTED, "render: frame too large for one launch");
+	a.nblocks     = (uint32_t) nb;
+	a.test        = P->options.test;
+	a.queue_heads = reinterpret_cast<uint32_t *>(ctx->d_workspace + kQueueHeadsOffset);
 	for (int i = 0; i < 256; ++i)
 		a.alpha_lut[i] = alpha_lut[i];
+
+	// scheduler: static 8x8 tiles; VKV_RAYMARCH_SCHEDULER=persistent selects the lane-refilling persistent waves
+	// (bit-identical output; measured slower so far: the re-fill breaks the spatial coherence of a wave, profiles/)
+	const char *env   = std::getenv("VKV_RAYMARCH_SCHEDULER");        // read per call so a test can flip it
+	const int   sched = (env && env[0] == 'p') ? (int) kSchedPersistent : (int) kSchedTiles;
 
 	const bool ert  = P->options.early_ray_termination != 0;
 	const int  grad = !P->transfer_function.use_gradient ? 0 : (P->use_precomputed_gradient ? 1 : 2);
 	switch (P->options.skipping_type)
 	{
-		case VKV_SKIP_NONE: launch_ert<VKV_SKIP_NONE>(ert, grad, a, s); break;
-		case VKV_SKIP_BLOCK: launch_ert<VKV_SKIP_BLOCK>(ert, grad, a, s); break;
-		case VKV_SKIP_DISTANCE: launch_ert<VKV_SKIP_DISTANCE>(ert, grad, a, s); break;
-		case VKV_SKIP_ANISOTROPIC_DISTANCE: launch_ert<VKV_SKIP_ANISOTROPIC_DISTANCE>(ert, grad, a, s); break;
+		case VKV_SKIP_NONE: return launch_ert<VKV_SKIP_NONE>(ctx, sched, ert, grad, a, s);
+		case VKV_SKIP_BLOCK: return launch_ert<VKV_SKIP_BLOCK>(ctx, sched, ert, grad, a, s);
+		case VKV_SKIP_DISTANCE: return launch_ert<VKV_SKIP_DISTANCE>(ctx, sched, ert, grad, a, s);
+		case VKV_SKIP_ANISOTROPIC_DISTANCE: return launch_ert<VKV_SKIP_ANISOTROPIC_DISTANCE>(ctx, sched, ert, grad, a, s);
 		default: return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: bad skipping_type %d", P->options.skipping_type);
 	}
-	return check_launch(ctx, "render");
 }
 
 }        // namespace vkv

@@ -114,4 +114,5 @@ int  set_error(vkv_ctx *ctx, int code, const char *fmt, ...);
 int  check_launch(vkv_ctx *ctx, const char *what);
 constexpr size_t kWorkspaceBytes = 64 * 1024;
 constexpr size_t kTfBitsOffset   = 0;        // 256*256 bits = 8 KiB
+constexpr size_t kQueueHeadsOffset = 8192;     // 8 x u32 tile-queue heads of the persistent ray-march scheduler
 }        // namespace vkv
