@@ -216,6 +216,26 @@ int vkv_compute_distance_map(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_
                              VkvExtent3D extent, uint8_t *const d_maps[8], uint8_t *d_swap,
                              VkvExtent3D map_extent, int32_t skipping_type, void *stream);
 
+/* ComputeOccupiedVoxelCount::compute + get_result, src/compute_occupied_voxel_count.cpp:88-156
+ * (shaders/occupied_voxel_count.comp + occupied_voxel_count_reduce.comp): number of voxels whose ANALYTIC
+ * transfer-function alpha (the uniform's min / range_inv fields, not the texture) is > 0, written to *d_count.
+ * One pass: wave ballot + one 64-bit atomic per workgroup instead of the reference's multi-dispatch tree reduce. */
+int vkv_occupied_voxel_count(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_t *d_gradient, const VkvTransferFunctionUniform *tf,
+                             VkvExtent3D extent, uint64_t *d_count, void *stream);
+
+/* LoadVolume::load_header / load_data, src/load_volume.cpp:33-86, :112-172 (host side). */
+typedef struct VkvVolumeHeader
+{
+	VkvExtent3D extent;
+	float       voxel_size[3];
+	float       normalisation_range[2];
+	char        type[16];
+	char        endianness[16];
+	float       image_transform[16];
+} VkvVolumeHeader;
+int vkv_load_header(const char *filename_header, VkvVolumeHeader *out);
+int vkv_load_data(const char *filename_data, const VkvVolumeHeader *header, uint8_t *out_voxels, size_t out_bytes);
+
 /* Device-internal sampling layout of the volume (the counterpart of uploading into a VK_IMAGE_TILING_OPTIMAL image,
  * src/volume_component.cpp:68-83): 4x4x4-voxel bricks with a one-voxel apron, volume and gradient bytes interleaved,
  * clamp-to-edge baked in, bricks grouped 8x8x8.  Every trilinear footprint of both textures then lies inside one

@@ -166,6 +166,37 @@ void vkvo_occupancy_map(const uint8_t *vol, const uint8_t *grad, const uint8_t *
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* Occupied-voxel count — shaders/occupied_voxel_count.comp:28-56 (+ _reduce.comp: a plain sum)  */
+/* ------------------------------------------------------------------------------------------- */
+
+/* analytic get_color, shaders/transfer_function.glsl:41-43 — this statistic does NOT use the TF texture
+ * (occupied_voxel_count.comp:12-15 leaves TRANSFER_FUNCTION_BINDING_TEXTURE undefined) */
+static inline float analytic_alpha(const VkvTransferFunctionUniform *tf, float intensity, float gradient)
+{
+	const float ai = g_clamp((intensity - tf->intensity_min) * tf->intensity_range_inv, 0.0f, 1.0f);
+	const float ag = g_clamp((gradient - tf->gradient_min) * tf->gradient_range_inv, 0.0f, 1.0f);
+	return ai * ag;
+}
+
+uint64_t vkvo_occupied_voxel_count(const uint8_t *vol, const uint8_t *grad, const VkvTransferFunctionUniform *tf, VkvExtent3D e)
+{
+	const int W = (int) e.width, H = (int) e.height, D = (int) e.depth;
+	uint64_t  n = 0;
+	for (int z = 0; z < D; ++z)
+		for (int y = 0; y < H; ++y)
+			for (int x = 0; x < W; ++x)
+			{
+				const float intensity = unorm8(vol[vidx(x, y, z, W, H)]);
+				float       gradient  = 1.0f;
+				if (tf->use_gradient)
+					gradient = grad ? unorm8(grad[vidx(x, y, z, W, H)]) : gradient_on_the_fly(vol, W, H, D, x, y, z, tf->grad_magnitude_modifier);
+				if (analytic_alpha(tf, intensity, gradient) > 0.0f)
+					++n;
+			}
+	return n;
+}
+
+/* ------------------------------------------------------------------------------------------- */
 /* Chebyshev distance transform — shaders/distance_map.comp:44-109                              */
 /* ------------------------------------------------------------------------------------------- */
 

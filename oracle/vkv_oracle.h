@@ -40,6 +40,8 @@ void vkvo_gradient_map(const uint8_t *volume, uint8_t *gradient, VkvExtent3D ext
 /* shaders/occupancy_map.comp:45-73 + src/compute_distance_map.cpp:106-113 */
 void vkvo_occupancy_map(const uint8_t *volume, const uint8_t *gradient_or_null, const uint8_t *tf_rgba8,
                         const VkvTransferFunctionUniform *tf, VkvExtent3D extent, uint8_t *map, VkvExtent3D map_extent);
+/* shaders/occupied_voxel_count.comp:28-56: voxels whose ANALYTIC transfer-function alpha is > 0 */
+uint64_t vkvo_occupied_voxel_count(const uint8_t *volume, const uint8_t *gradient_or_null, const VkvTransferFunctionUniform *tf, VkvExtent3D extent);
 /* shaders/distance_map.comp:44-109 with the dispatch order / aliasing of src/compute_distance_map.cpp:154-172 */
 void vkvo_distance_map(uint8_t *map, uint8_t *swap, VkvExtent3D map_extent);
 /* shaders/distance_map_anisotropic.comp:31-92 with the schedule of src/compute_distance_map.cpp:201-252 */

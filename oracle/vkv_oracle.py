@@ -51,6 +51,8 @@ def lib():
     L.vkvo_gradient_map.argtypes = [vp, vp, abi.Extent3D, C.POINTER(abi.TransferFunctionUniform)]
     L.vkvo_occupancy_map.argtypes = [vp, vp, vp, C.POINTER(abi.TransferFunctionUniform), abi.Extent3D, vp, abi.Extent3D]
     L.vkvo_distance_map.argtypes = [vp, vp, abi.Extent3D]
+    L.vkvo_occupied_voxel_count.argtypes = [vp, vp, C.POINTER(abi.TransferFunctionUniform), abi.Extent3D]
+    L.vkvo_occupied_voxel_count.restype = C.c_uint64
     L.vkvo_distance_map_anisotropic.argtypes = [C.POINTER(vp), vp, abi.Extent3D]
     L.vkvo_compute_distance_map.argtypes = [vp, vp, vp, C.POINTER(abi.TransferFunctionUniform), abi.Extent3D,
                                             C.POINTER(vp), vp, abi.Extent3D, C.c_int32]
@@ -112,6 +114,11 @@ def occupancy_map(vol, grad, tf_tex, tf, block):
     out = np.empty((me.depth, me.height, me.width), np.uint8)
     lib().vkvo_occupancy_map(_ptr(vol), _ptr(grad), _ptr(tf_tex), C.byref(tf), _extent_of(vol), _ptr(out), me)
     return out
+
+
+def occupied_voxel_count(vol, grad, tf):
+    vol = np.ascontiguousarray(vol, np.uint8)
+    return int(lib().vkvo_occupied_voxel_count(_ptr(vol), _ptr(grad), C.byref(tf), _extent_of(vol)))
 
 
 def distance_map(occ):

@@ -1,0 +1,110 @@
+"""GPU: the occupied-voxel statistic and the C++ host mirror (Volume / ComputeGradientMap / ComputeDistanceMap /
+ComputeOccupiedVoxelCount / VolumeRenderSubpass driven by the vkv_offscreen executable) against the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vkv_oracle as O
+from tests import helpers as T
+from vkvolume_amd import abi, lib
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "vkvolume_amd", "csrc", "vkv_offscreen")
+
+
+@pytest.mark.parametrize("opts,use_map", [(T.APP_TF, True), (T.APP_TF, False),
+                                          (dict(intensity_min=0.4, intensity_max=0.8, gradient_min=0.0, gradient_max=0.0), True),
+                                          (dict(intensity_min=0.2, intensity_max=0.8, gradient_min=0.06, gradient_max=0.12), True)])
+@pytest.mark.parametrize("shape", [(64, 64, 64), (70, 33, 19), (1, 1, 1)])
+def test_occupied_voxel_count_parity(ctx, opts, use_map, shape):
+    vol = O.synth_volume(shape, 1, 6)
+    opt = abi.VolumeOptions(use_precomputed_gradient=use_map, **opts)
+    tf = lib.transfer_function_uniform(opt)
+    grad = O.gradient_map(vol, tf) if use_map else None
+    d_vol = torch.from_numpy(vol).cuda()
+    d_grad = torch.from_numpy(grad).cuda() if grad is not None else None
+    d_count = torch.full((1,), 12345, dtype=torch.int64, device="cuda")
+    ctx.occupied_voxel_count(d_vol.data_ptr(), None if d_grad is None else d_grad.data_ptr(), tf, abi.Extent3D(*shape), d_count.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream)
+    assert int(d_count.item()) == O.occupied_voxel_count(vol, grad, tf)
+
+
+def run_offscreen(tmp_path, *flags):
+    assert os.path.exists(EXE), "vkv_offscreen not built (run __graft_entry__.build())"
+    out = subprocess.run([EXE, *flags], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()
+    return out.stdout.decode()
+
+
+@pytest.mark.parametrize("skipmode", [0, 1, 2, 3])
+def test_offscreen_driver_matches_oracle(tmp_path, skipmode):
+    """vkv_offscreen = the reference application's call order in C++.  Its frame must equal the oracle's frame for the exact
+    parameter block its VolumeRenderSubpass::draw built (dumped with --dump-params)."""
+    w, h = 160, 96
+    shape, kind, seed = (72, 60, 48), 1, 11
+    run_offscreen(tmp_path, "--synthetic=%dx%dx%d:%d:%d" % (*shape, kind, seed), "--width=%d" % w, "--height=%d" % h, "--skipmode=%d" % skipmode,
+                  "--azimuth=40", "--elevation=15", "--dump-counts=counts.raw", "--dump-rgba8=rgba8.raw", "--dump-params=params.raw")
+    p = abi.RenderParams.from_buffer_copy(open(tmp_path / "params.raw", "rb").read())
+    assert (p.image_width, p.image_height) == (w, h) and p.options.skipping_type == skipmode
+    assert p.options.early_ray_termination == 1 and p.options.clip_distance == 50.0  # VolumeRenderSubpass::Options defaults
+    assert p.d_packed_volume and p.d_transfer_function_bits
+    vol = O.synth_volume(shape, kind, seed)
+    opt = abi.VolumeOptions(**T.APP_TF)  # the application's flag defaults (src/volume_render.cpp:67-70)
+    tf = O.transfer_function_uniform(opt)
+    assert bytes(tf) == bytes(p.transfer_function)
+    tex = O.transfer_function_texture(opt)
+    grad = O.gradient_map(vol, tf)
+    maps = None if skipmode == 0 else O.compute_distance_map(vol, grad, tex, tf, 4, skipmode)
+    ref = O.render(p, vol, grad, tex, maps, want_rgba8=True)
+    counts = np.fromfile(tmp_path / "counts.raw", np.uint32).reshape(h, w, 3)
+    rgba8 = np.fromfile(tmp_path / "rgba8.raw", np.uint8).reshape(h, w, 4)
+    assert ref.counts[..., 0].sum() > 0
+    assert np.array_equal(counts, ref.counts)
+    assert np.array_equal(rgba8, ref.rgba8)
+
+
+def test_offscreen_benchmark_mode_prints_the_harness_lines(tmp_path):
+    """--benchmark=N: ERT off + count output (src/volume_render.cpp:177-183) and the three lines scripts/benchmark.py parses."""
+    shape = (64, 64, 64)
+    out = run_offscreen(tmp_path, "--synthetic=64x64x64:1:3", "--width=128", "--height=128", "--benchmark=3", "--skipmode=2", "--blocksize=4",
+                        "--imin=0.1", "--imax=1.0", "--gmin=0.0", "--gmax=0.2", "--dump-counts=c.raw", "--dump-params=p.raw")
+    m_fps = re.search(r"ran [\d]+ frames, averaged ([\d\.e\+]+) fps", out)
+    m_map = re.search(r"Updated occupancy/distance map in ([\d\.e\-\+]+)ms", out)
+    m_occ = re.search(r"Occupied voxels: ([\d\.e\-\+]+)%", out)
+    assert m_fps and m_map and m_occ, out
+    vol = O.synth_volume(shape, 1, 3)
+    tf = O.transfer_function_uniform(abi.VolumeOptions(**T.APP_TF))
+    grad = O.gradient_map(vol, tf)
+    expect = 100.0 * np.float32(O.occupied_voxel_count(vol, grad, tf)) / np.float32(vol.size)
+    assert abs(float(m_occ.group(1)) - float(expect)) < 1e-3
+    p = abi.RenderParams.from_buffer_copy(open(tmp_path / "p.raw", "rb").read())
+    assert p.options.early_ray_termination == 0 and p.options.test == abi.TEST_NUM_TEXTURE_SAMPLES and p.options.clip_distance == 1.0
+
+
+def test_offscreen_loads_a_volume_file(tmp_path):
+    """load_from_file: .header side-car + big-endian uint16 raw file (README.md:58-70) through the C++ loader onto the device."""
+    rng = np.random.default_rng(1)
+    vol16 = (O.synth_volume((48, 40, 32), 1, 8).astype(np.uint16) * 8 + 400)
+    vol16.astype(">u2").tofile(tmp_path / "scan.raw")
+    (tmp_path / "scan.raw.header").write_text("48 40 32 # extents\n0.001 0.001 0.002 # voxel size\n400.0 2538.0 # normalisation range\n"
+                                              "uint16_t big # type\n1 0 0 90 # rotation\n")
+    run_offscreen(tmp_path, "scan.raw", "--width=96", "--height=64", "--skipmode=2", "--dump-counts=c.raw", "--dump-params=p.raw")
+    p = abi.RenderParams.from_buffer_copy(open(tmp_path / "p.raw", "rb").read())
+    h = O.load_header(str(tmp_path / "scan.raw.header"))
+    vol = O.load_data(str(tmp_path / "scan.raw"), h)
+    assert (p.volume_extent.width, p.volume_extent.height, p.volume_extent.depth) == (48, 40, 32)
+    opt = abi.VolumeOptions(**T.APP_TF)
+    tf, tex = O.transfer_function_uniform(opt), O.transfer_function_texture(opt)
+    grad = O.gradient_map(vol, tf)
+    maps = O.compute_distance_map(vol, grad, tex, tf, 4, abi.SKIP_DISTANCE)
+    ref = O.render(p, vol, grad, tex, maps)
+    counts = np.fromfile(tmp_path / "c.raw", np.uint32).reshape(64, 96, 3)
+    assert ref.counts[..., 0].sum() > 0 and np.array_equal(counts, ref.counts)
+    del rng

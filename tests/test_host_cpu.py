@@ -131,3 +131,35 @@ def test_null_arguments_are_rejected_on_the_host_side():
     assert L.vkv_render(None, None, None) == abi.VKV_E_INVALID_ARGUMENT
     assert L.vkv_gradient_map(None, None, None, abi.Extent3D(1, 1, 1), None, None) == abi.VKV_E_INVALID_ARGUMENT
     L.vkv_destroy(None)  # no-op
+
+
+def test_loader_c_abi_matches_oracle_loader(tmp_path):
+    """LoadVolume behind vkv_load_header / vkv_load_data (the product's C++ loader) against the oracle's C loader."""
+    rng = np.random.default_rng(9)
+    cases = [("uint8_t", "u1", "little"), ("int8_t", "i1", "big"), ("uint16_t", "u2", "little"), ("uint16_t", "u2", "big"),
+             ("int16_t", "i2", "little"), ("int16_t", "i2", "big")]
+    for ctype, npt, endian in cases:
+        info = np.iinfo(npt)
+        raw = rng.integers(info.min, info.max + 1, size=(7, 5, 9)).astype(npt)
+        f = tmp_path / ("vol_%s_%s.raw" % (ctype, endian))
+        raw.astype(("<" if endian == "little" else ">") + npt).tofile(f)
+        lo, hi = (10.0, 200.0) if npt[1] == "1" else (400.0, 25380.0)
+        (tmp_path / (f.name + ".header")).write_text("9 5 7 # extents\n0.0003 0.0003 0.0007 # voxel size\n%g %g # range\n%s %s # type\n"
+                                                     "1 0 0 90 # rotation\n" % (lo, hi, ctype, endian))
+        h = lib.load_header(str(f) + ".header")
+        ho = O.load_header(str(f) + ".header")
+        assert h.extent.as_tuple() == ho.extent.as_tuple() == (9, 5, 7)
+        assert h.type == ho.type == ctype.encode() and h.endianness == ho.endianness == endian.encode()
+        assert list(h.voxel_size) == list(ho.voxel_size) and list(h.normalisation_range) == list(ho.normalisation_range)
+        assert np.allclose(list(h.image_transform), list(ho.image_transform), rtol=0, atol=1e-7)
+        assert np.array_equal(lib.load_data(str(f), h), O.load_data(str(f), ho))
+    with pytest.raises(RuntimeError, match="Failed to open header file"):
+        lib.load_header(str(tmp_path / "nope.header"))
+    (tmp_path / "bad.raw").write_bytes(b"\0" * 11)
+    (tmp_path / "bad.raw.header").write_text("9 5 7\n1 1 1\n0 255\nuint8_t little\n1 0 0 0\n")
+    with pytest.raises(RuntimeError):
+        lib.load_data(str(tmp_path / "bad.raw"), lib.load_header(str(tmp_path / "bad.raw.header")))  # size mismatch
+    (tmp_path / "f32.raw.header").write_text("1 1 1\n1 1 1\n0 255\nfloat little\n1 0 0 0\n")
+    (tmp_path / "f32.raw").write_bytes(b"\0" * 4)
+    with pytest.raises(RuntimeError):
+        lib.load_data(str(tmp_path / "f32.raw"), lib.load_header(str(tmp_path / "f32.raw.header")))  # unsupported type

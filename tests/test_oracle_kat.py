@@ -206,3 +206,35 @@ def test_loader_roundtrip(tmp_path):
     (tmp_path / "short.raw.header").write_text("6 4 5\n1 1 1\n0 255\nuint8_t little\n1 0 0 0\n")
     with pytest.raises(RuntimeError):
         O.load_data(str(tmp_path / "short.raw"), O.load_header(str(tmp_path / "short.raw.header")))
+
+
+@pytest.mark.parametrize("opts,use_map", [(T.APP_TF, True), (T.APP_TF, False), (dict(intensity_min=0.4, intensity_max=0.8, gradient_min=0.0, gradient_max=0.0), True),
+                                          (dict(intensity_min=0.2, intensity_max=0.8, gradient_min=0.06, gradient_max=0.12), True)])
+def test_occupied_voxel_count_formula(opts, use_map):
+    """shaders/occupied_voxel_count.comp uses the ANALYTIC transfer function (transfer_function.glsl:41-43)."""
+    vol = O.synth_volume((30, 26, 22), 1, 4)
+    opt = abi.VolumeOptions(use_precomputed_gradient=use_map, **opts)
+    tf = O.transfer_function_uniform(opt)
+    grad = O.gradient_map(vol, tf) if use_map else None
+    f = np.float32
+    i = vol.astype(np.float32) / f(255)
+    if not tf.use_gradient:
+        g = np.ones_like(i)
+    elif use_map:
+        g = grad.astype(np.float32) / f(255)
+    else:
+        v = i
+        D, H, W = vol.shape
+        z, y, x = np.indices(vol.shape)
+        c = lambda a, n: np.clip(a, 0, n - 1)  # noqa: E731
+        v1, v2 = v[c(z - 1, D), c(y - 1, H), c(x + 1, W)], v[c(z + 1, D), c(y - 1, H), c(x - 1, W)]
+        v3, v4 = v[c(z - 1, D), c(y + 1, H), c(x - 1, W)], v[c(z + 1, D), c(y + 1, H), c(x + 1, W)]
+        q = f(0.25)
+        gx, gy, gz = q * (((v1 - v2) - v3) + v4), q * (((-v1 - v2) + v3) + v4), q * (((-v1 + v2) - v3) + v4)
+        g = np.clip(np.sqrt((gx * gx + gy * gy) + gz * gz), 0, 1).astype(np.float32)
+    with np.errstate(invalid="ignore", over="ignore"):
+        ai = np.clip((i - f(tf.intensity_min)) * f(tf.intensity_range_inv), 0, 1)
+        ag = np.clip((g - f(tf.gradient_min)) * f(tf.gradient_range_inv), 0, 1)
+        expect = int(((ai * ag) > 0).sum())
+    assert O.occupied_voxel_count(vol, grad, tf) == expect
+    assert 0 < expect < vol.size

@@ -97,6 +97,12 @@ class RenderParams(C.Structure):
                 ("d_out_counts", C.c_void_p), ("d_out_depth", C.c_void_p)]
 
 
+class VolumeHeader(C.Structure):
+    """VkvVolumeHeader (LoadVolume::Header, src/load_volume.h:29-39)"""
+    _fields_ = [("extent", Extent3D), ("voxel_size", C.c_float * 3), ("normalisation_range", C.c_float * 2),
+                ("type", C.c_char * 16), ("endianness", C.c_char * 16), ("image_transform", C.c_float * 16)]
+
+
 def full_frame_tiles(image_width, image_height, tile_width=16, tile_height=16, rank=0, world=1, compact=False):
     """Tile schedule of one rank: every ``world``-th tile starting at ``rank`` (interleaved screen tiles)."""
     tiles_x = (image_width + tile_width - 1) // tile_width

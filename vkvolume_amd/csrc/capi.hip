@@ -7,6 +7,10 @@
 #include <cstring>
 #include <new>
 
+#include <exception>
+#include <string>
+
+#include "../host/load_volume.h"
 #include "../host/vkv_math.hpp"
 #include "vkv_device.hpp"
 
@@ -22,6 +26,7 @@ int launch_scatter_tiles(vkv_ctx *, const void *, void *, uint32_t, uint32_t, ui
 int launch_render(vkv_ctx *, const VkvRenderParams *, const float *, hipStream_t);
 int launch_pack_volume(vkv_ctx *, const uint8_t *, const uint8_t *, VkvExtent3D, void *, hipStream_t);
 int launch_tf_bits(vkv_ctx *, const uint8_t *, uint32_t *, hipStream_t);
+int launch_occupied_voxel_count(vkv_ctx *, const uint8_t *, const uint8_t *, const VkvTransferFunctionUniform *, VkvExtent3D, uint64_t *, hipStream_t);
 
 int set_error(vkv_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -280,6 +285,66 @@ int vkv_compute_distance_map(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_
 	if (skipping_type == VKV_SKIP_DISTANCE)
 		return vkv_distance_map(ctx, d_maps[0], d_swap, map_extent, stream);
 	return VKV_OK;        // None / Block use the raw 0/255 occupancy map (:96-99)
+}
+
+int vkv_occupied_voxel_count(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_t *d_gradient, const VkvTransferFunctionUniform *tf, VkvExtent3D extent,
+                             uint64_t *d_count, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (!d_volume || !tf || !d_count || !extent_ok(extent))
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "occupied_voxel_count: null pointer or zero extent");
+	return launch_occupied_voxel_count(ctx, d_volume, d_gradient, tf, extent, d_count, (hipStream_t) stream);
+}
+
+// ---- loader (host side; the C++ class throws, the C ABI returns codes) ------------------------------------------
+int vkv_load_header(const char *filename_header, VkvVolumeHeader *out)
+{
+	if (!filename_header || !out)
+		return VKV_E_INVALID_ARGUMENT;
+	try
+	{
+		const LoadVolume::Header h = LoadVolume::load_header(filename_header);
+		std::memset(out, 0, sizeof(*out));
+		out->extent = h.extent;
+		out->voxel_size[0] = h.voxel_size.x, out->voxel_size[1] = h.voxel_size.y, out->voxel_size[2] = h.voxel_size.z;
+		out->normalisation_range[0] = h.normalisation_range[0], out->normalisation_range[1] = h.normalisation_range[1];
+		std::strncpy(out->type, h.type.c_str(), sizeof(out->type) - 1);
+		std::strncpy(out->endianness, h.endianness.c_str(), sizeof(out->endianness) - 1);
+		std::memcpy(out->image_transform, h.image_transform.m, sizeof(out->image_transform));
+		return VKV_OK;
+	}
+	catch (const std::exception &)
+	{
+		return VKV_E_IO;
+	}
+}
+
+int vkv_load_data(const char *filename_data, const VkvVolumeHeader *header, uint8_t *out_voxels, size_t out_bytes)
+{
+	if (!filename_data || !header || !out_voxels)
+		return VKV_E_INVALID_ARGUMENT;
+	try
+	{
+		LoadVolume::Header h;
+		h.extent                 = header->extent;
+		h.normalisation_range[0] = header->normalisation_range[0], h.normalisation_range[1] = header->normalisation_range[1];
+		h.type       = std::string(header->type, strnlen(header->type, sizeof(header->type)));
+		h.endianness = std::string(header->endianness, strnlen(header->endianness, sizeof(header->endianness)));
+		const std::vector<uint8_t> v = LoadVolume::load_data(filename_data, h);
+		if (v.size() != out_bytes)
+			return VKV_E_INVALID_ARGUMENT;
+		std::memcpy(out_voxels, v.data(), v.size());
+		return VKV_OK;
+	}
+	catch (const std::runtime_error &e)
+	{
+		return std::string(e.what()) == "unsupported image data type" ? VKV_E_INVALID_ARGUMENT : VKV_E_IO;
+	}
+	catch (const std::exception &)
+	{
+		return VKV_E_IO;
+	}
 }
 
 size_t vkv_packed_volume_bytes(VkvExtent3D e)

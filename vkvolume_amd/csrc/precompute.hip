@@ -104,6 +104,74 @@ __global__ void __launch_bounds__(256) k_occupancy_map(const uint8_t *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// Occupied-voxel count (shaders/occupied_voxel_count.comp + occupied_voxel_count_reduce.comp)
+// ---------------------------------------------------------------------------------------------
+// analytic get_color (transfer_function.glsl:41-43) > 0
+__device__ __forceinline__ bool analytic_occupied(float intensity, float gradient, float imin, float iinv, float gmin, float ginv)
+{
+	const float ai = g_clamp((intensity - imin) * iinv, 0.0f, 1.0f);
+	const float ag = g_clamp((gradient - gmin) * ginv, 0.0f, 1.0f);
+	return ai * ag > 0.0f;
+}
+
+// The statistic's alpha is again a pure function of the (gradient byte, intensity byte) pair when the gradient comes
+// from the R8_UNORM map: reduce the analytic TF to the same 8 KiB bit table the occupancy pass uses.
+__global__ void __launch_bounds__(256) k_tf_bits_analytic(uint32_t *__restrict__ bits, float imin, float iinv, float gmin, float ginv)
+{
+	const uint32_t w = blockIdx.x * 256 + threadIdx.x;        // 2048 words, 32 intensity texels each
+	if (w >= 2048)
+		return;
+	const uint32_t g = w >> 3;
+	uint32_t       v = 0;
+	for (uint32_t i = 0; i < 32; ++i)
+		v |= (analytic_occupied(unorm8((w & 7u) * 32 + i), unorm8(g), imin, iinv, gmin, ginv) ? 1u : 0u) << i;
+	bits[w] = v;
+}
+
+// GRAD as in k_occupancy_map.  Each thread walks voxels with a grid stride of whole x rows; a wave counts with
+// ballot + popcount, a workgroup adds once to the 64-bit total.
+template <int GRAD>
+__global__ void __launch_bounds__(256) k_occupied_voxel_count(const uint8_t *__restrict__ vol, const uint8_t *__restrict__ grad,
+                                                              const uint32_t *__restrict__ tf_bits, unsigned long long *__restrict__ total, int W, int H,
+                                                              int D, float modifier, float imin, float iinv, float gmin, float ginv, uint32_t blocks_x,
+                                                              uint32_t n_row_groups)
+{
+	__shared__ uint32_t s_bits[2048];
+	__shared__ uint32_t s_wave[4];
+	for (int i = threadIdx.x; i < 2048; i += 256)
+		s_bits[i] = tf_bits[i];
+	__syncthreads();
+	const uint32_t bx   = blockIdx.x % blocks_x;
+	const int      x    = (int) (bx * 64 + (threadIdx.x & 63));
+	const uint32_t rows = (uint32_t) H * (uint32_t) D;
+	uint32_t       n    = 0;
+	for (uint32_t rg = blockIdx.x / blocks_x; rg < n_row_groups; rg += gridDim.x / blocks_x)
+	{
+		const uint32_t row = rg * 4 + (threadIdx.x >> 6);
+		bool           occ = false;
+		if (x < W && row < rows)
+		{
+			const int      y = (int) (row % (uint32_t) H), z = (int) (row / (uint32_t) H);
+			const size_t   o = vidx(x, y, z, W, H);
+			const uint32_t v = vol[o];
+			if (GRAD == 2)
+				occ = analytic_occupied(unorm8(v), gradient_on_the_fly(vol, W, H, D, x, y, z, modifier), imin, iinv, gmin, ginv);
+			else
+			{
+				const uint32_t bit = (GRAD == 1 ? (uint32_t) grad[o] : 255u) * 256 + v;
+				occ                = (s_bits[bit >> 5] >> (bit & 31)) & 1u;
+			}
+		}
+		n += (uint32_t) __popcll(__ballot(occ));        // wave-uniform
+	}
+	if ((threadIdx.x & 63) == 0)
+		s_wave[threadIdx.x >> 6] = n;
+	__syncthreads();
+	if (threadIdx.x == 0)
+		atomicAdd(total, (unsigned long long) s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Chebyshev distance transform (shaders/distance_map.comp, distance_map_anisotropic.comp)
 // ---------------------------------------------------------------------------------------------
 // x pass.  One wave stages 64 rows in LDS (coalesced), each lane scans one row serially out of LDS (row stride
@@ -368,6 +436,37 @@ int launch_occupancy_map(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_gr
 		hipLaunchKernelGGL(k_occupancy_map<2>, dim3((uint32_t) nblocks), dim3(256), 0, s, d_vol, d_grad, d_bits, d_map, W, H, D, mw, mh, md, bx, by,
 		                   bz, tf->grad_magnitude_modifier, blocks_x);
 	return check_launch(ctx, "occupancy_map");
+}
+
+int launch_occupied_voxel_count(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_grad, const VkvTransferFunctionUniform *tf, VkvExtent3D e,
+                                uint64_t *d_count, hipStream_t s)
+{
+	uint32_t *d_bits = reinterpret_cast<uint32_t *>(ctx->d_workspace + kTfBitsOffset);
+	hipLaunchKernelGGL(k_tf_bits_analytic, dim3(8), dim3(256), 0, s, d_bits, tf->intensity_min, tf->intensity_range_inv, tf->gradient_min,
+	                   tf->gradient_range_inv);
+	const hipError_t me = hipMemsetAsync(d_count, 0, sizeof(uint64_t), s);
+	if (me != hipSuccess)
+		return set_error(ctx, (int) me, "occupied_voxel_count: %s", hipGetErrorString(me));
+	const uint32_t blocks_x     = (e.width + 63) / 64;
+	const uint64_t rows         = (uint64_t) e.height * e.depth;
+	const uint64_t n_row_groups = (rows + 3) / 4;
+	if (n_row_groups > 0xffffffffull)
+		return set_error(ctx, VKV_E_UNSUPPORTED, "occupied_voxel_count: volume too large");
+	// ~8 workgroups per CU, grid-stride over the row groups: one atomic per workgroup, few thousand in total
+	const uint32_t groups = (uint32_t) (n_row_groups < 2048 / blocks_x + 1 ? n_row_groups : 2048 / blocks_x + 1);
+	const dim3     grid(blocks_x * groups);
+	unsigned long long *total = reinterpret_cast<unsigned long long *>(d_count);
+	const int W = (int) e.width, H = (int) e.height, D = (int) e.depth;
+	if (!tf->use_gradient)
+		hipLaunchKernelGGL(k_occupied_voxel_count<0>, grid, dim3(256), 0, s, d_vol, d_grad, d_bits, total, W, H, D, tf->grad_magnitude_modifier,
+		                   tf->intensity_min, tf->intensity_range_inv, tf->gradient_min, tf->gradient_range_inv, blocks_x, (uint32_t) n_row_groups);
+	else if (d_grad)
+		hipLaunchKernelGGL(k_occupied_voxel_count<1>, grid, dim3(256), 0, s, d_vol, d_grad, d_bits, total, W, H, D, tf->grad_magnitude_modifier,
+		                   tf->intensity_min, tf->intensity_range_inv, tf->gradient_min, tf->gradient_range_inv, blocks_x, (uint32_t) n_row_groups);
+	else
+		hipLaunchKernelGGL(k_occupied_voxel_count<2>, grid, dim3(256), 0, s, d_vol, d_grad, d_bits, total, W, H, D, tf->grad_magnitude_modifier,
+		                   tf->intensity_min, tf->intensity_range_inv, tf->gradient_min, tf->gradient_range_inv, blocks_x, (uint32_t) n_row_groups);
+	return check_launch(ctx, "occupied_voxel_count");
 }
 
 static int row_stride_for(int mw)

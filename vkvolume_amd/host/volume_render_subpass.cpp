@@ -1,0 +1,58 @@
+#include "volume_render_subpass.h"
+
+#include <cstring>
+#include <stdexcept>
+
+VolumeRenderSubpass::VolumeRenderSubpass(DeviceContext &device_context, std::vector<Volume *> volumes_, Camera &cam, Options options_) :
+    dc(device_context), camera(cam), volumes(std::move(volumes_)), options(options_)
+{}
+
+void VolumeRenderSubpass::prepare() {}
+
+VkvRenderParams VolumeRenderSubpass::make_params(Volume &volume, const RenderTarget &target, const VkvTileSchedule *tiles) const
+{
+	VkvRenderParams p;
+	std::memset(&p, 0, sizeof(p));
+	const VkvExtent3D volume_extent = volume.get_volume().extent;
+	const VkvExtent3D map_extent    = volume.get_distance_map_swap().extent;
+	if (vkv_build_uniforms(camera.view.data(), camera.projection.data(), volume.node_transform.data(), volume.get_image_transform().data(),
+	                       options.clip_distance, target.width, target.height, volume_extent, map_extent, &p.camera, &p.ray_cast, &p.ray_gen) != VKV_OK)
+		throw std::runtime_error("VolumeRenderSubpass: bad uniforms");
+	p.transfer_function             = volume.get_transfer_function_uniform();
+	p.options.skipping_type         = static_cast<int32_t>(options.skipping_type);
+	p.options.clip_distance         = options.clip_distance;
+	p.options.early_ray_termination = options.early_ray_termination;
+	p.options.depth_attachment      = options.depth_attachment;
+	p.options.test                  = static_cast<int32_t>(options.test);
+	p.use_precomputed_gradient      = volume.options.use_precomputed_gradient;
+	p.image_width = target.width, p.image_height = target.height;
+	if (tiles)
+		p.tiles = *tiles;
+	else
+	{
+		const uint32_t t = 16;
+		p.tiles          = VkvTileSchedule{t, t, 0, 1, ((target.width + t - 1) / t) * ((target.height + t - 1) / t), 0};
+	}
+	p.volume_extent = volume_extent, p.map_extent = map_extent;
+	p.d_volume            = volume.get_volume().data;
+	p.d_gradient          = volume.options.use_precomputed_gradient ? volume.get_gradient().data : nullptr;
+	p.d_transfer_function = volume.get_transfer_function().data;
+	for (size_t i = 0; i < volume.get_number_of_distance_maps() && i < 8; ++i)
+		p.d_distance_maps[i] = volume.get_distance_map(i).data;
+	p.d_packed_volume          = volume.get_packed_volume();
+	p.d_transfer_function_bits = volume.get_transfer_function_bits();
+	p.d_out_color = target.color, p.d_out_rgba8 = target.rgba8, p.d_out_counts = target.counts, p.d_out_depth = target.depth;
+	return p;
+}
+
+void VolumeRenderSubpass::draw(const RenderTarget &target, const VkvTileSchedule *tiles)
+{
+	for (Volume *volume : volumes)
+	{
+		if (!volume->get_packed_volume())
+			volume->pack(dc);        // no gradient pass ran (gradient_test / no-gradient TF)
+		const VkvRenderParams p = make_params(*volume, target, tiles);
+		if (vkv_render(dc.ctx, &p, dc.stream) != VKV_OK)
+			throw std::runtime_error(std::string("VolumeRenderSubpass::draw: ") + vkv_last_error(dc.ctx));
+	}
+}

@@ -1,0 +1,74 @@
+// volume_render_subpass.h — VolumeRenderSubpass (reference: src/volume_render_subpass.h:55-101) as an offscreen pass:
+// same Options / SkippingType / Test, same uniform structs, draw() renders every volume into caller-owned buffers.
+#pragma once
+
+#include <vector>
+
+#include "volume_component.h"
+
+using CameraUniform  = VkvCameraUniform;         // src/volume_render_subpass.h:32-39
+using RayCastUniform = VkvRayCastUniform;        // src/volume_render_subpass.h:46-53
+
+// vkb::sg::Camera stand-in: view matrix + (vulkan-style) projection
+struct Camera
+{
+	vkv::mat4 view;
+	vkv::mat4 projection;        // as vkb::vulkan_style_projection(camera.get_projection()) returns it
+};
+
+// Output images of one draw (device pointers; any may be null)
+struct RenderTarget
+{
+	uint32_t  width = 0, height = 0;
+	float *   color  = nullptr;        // RGBA32F, premultiplied
+	uint8_t * rgba8  = nullptr;        // RGBA8
+	uint32_t *counts = nullptr;        // 3 x u32 per pixel
+	float *   depth  = nullptr;
+};
+
+class VolumeRenderSubpass
+{
+  public:
+	enum class SkippingType : int
+	{
+		None                = 0,
+		Block               = 1,
+		Distance            = 2,
+		AnisotropicDistance = 3
+	};
+
+	enum class Test : int
+	{
+		None              = 0,
+		RayEntry          = 1,
+		RayExit           = 2,
+		NumTextureSamples = 3
+	};
+
+	struct Options
+	{
+		SkippingType skipping_type         = SkippingType::Distance;
+		float        clip_distance         = 50.0f;
+		bool         early_ray_termination = true;
+		bool         depth_attachment      = false;
+		Test         test                  = Test::None;
+	};
+
+	VolumeRenderSubpass(DeviceContext &device_context, std::vector<Volume *> volumes, Camera &camera, Options options);
+	virtual ~VolumeRenderSubpass() = default;
+
+	void prepare();        // nothing to pre-build: kernel variants are compiled ahead of time
+
+	// src/volume_render_subpass.cpp:159-294: per volume, build the uniforms and march.  `tiles` selects the screen tiles of
+	// this launch (null = the whole frame).
+	void draw(const RenderTarget &target, const VkvTileSchedule *tiles = nullptr);
+
+	// the parameter block of one volume (what draw() binds), exposed for tests / the multi-GPU driver
+	VkvRenderParams make_params(Volume &volume, const RenderTarget &target, const VkvTileSchedule *tiles) const;
+
+  private:
+	DeviceContext &       dc;
+	Camera &              camera;
+	std::vector<Volume *> volumes;
+	Options               options;
+};

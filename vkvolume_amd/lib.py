@@ -17,6 +17,7 @@ EXPORTS = [
     "vkv_gradient_map", "vkv_occupancy_map", "vkv_distance_map", "vkv_distance_map_anisotropic",
     "vkv_compute_distance_map", "vkv_render", "vkv_scatter_tiles", "vkv_synth_volume",
     "vkv_packed_volume_bytes", "vkv_pack_volume", "vkv_transfer_function_bits",
+    "vkv_occupied_voxel_count", "vkv_load_header", "vkv_load_data",
 ]
 
 
@@ -66,6 +67,9 @@ def load():
     L.vkv_packed_volume_bytes.restype = C.c_size_t
     L.vkv_pack_volume.argtypes = [vp, vp, vp, abi.Extent3D, vp, vp]
     L.vkv_transfer_function_bits.argtypes = [vp, vp, vp, vp]
+    L.vkv_occupied_voxel_count.argtypes = [vp, vp, vp, P(abi.TransferFunctionUniform), abi.Extent3D, vp, vp]
+    L.vkv_load_header.argtypes = [C.c_char_p, P(abi.VolumeHeader)]
+    L.vkv_load_data.argtypes = [C.c_char_p, P(abi.VolumeHeader), vp, C.c_size_t]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here means the library does not export what the header declares
     _LIB = L
@@ -142,6 +146,9 @@ class Context:
     def transfer_function_bits(self, d_tf, d_bits, stream=0):
         self.check(self._lib.vkv_transfer_function_bits(self.handle, d_tf, d_bits, stream))
 
+    def occupied_voxel_count(self, d_volume, d_gradient, tf, extent, d_count, stream=0):
+        self.check(self._lib.vkv_occupied_voxel_count(self.handle, d_volume, d_gradient, C.byref(tf), extent, d_count, stream))
+
     def last_error(self):
         return self._lib.vkv_last_error(self.handle).decode(errors="replace")
 
@@ -174,3 +181,22 @@ def build_uniforms(view, proj, node_transform, image_transform, clip_distance, i
     if rc != 0:
         raise VkvError(rc, "vkv_build_uniforms")
     return cam, rc_, rg
+
+
+def load_header(path):
+    """LoadVolume::load_header; raises RuntimeError with the reference's message on failure."""
+    h = abi.VolumeHeader()
+    if load().vkv_load_header(os.fsencode(path), C.byref(h)) != 0:
+        raise RuntimeError("Failed to open header file")
+    return h
+
+
+def load_data(path, header):
+    """LoadVolume::load_data → uint8 array [D, H, W]."""
+    import numpy as np
+    e = header.extent
+    out = np.empty((e.depth, e.height, e.width), np.uint8)
+    rc = load().vkv_load_data(os.fsencode(path), C.byref(header), out.ctypes.data_as(C.c_void_p), out.nbytes)
+    if rc != 0:
+        raise RuntimeError("load_data failed (%d)" % rc)
+    return out
