@@ -63,6 +63,13 @@ def build_scene(ctx, name):
     return v, tf, frame, skip
 
 
+def occupied_voxel_percent(ctx, v, tf):
+    """the reference's benchmark-mode statistic (src/volume_render.cpp:399-414): % voxels with analytic TF alpha > 0"""
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ctx.occupied_voxel_count(v.volume.data_ptr(), v.gradient.data_ptr(), tf, v.extent, count.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return 100.0 * float(count.item()) / float(v.extent.count)
+
+
 def cameras(v, aspect):
     """8 azimuths, elevation 20 deg, radius 1.5 x bounding-sphere radius of the scaled volume."""
     m = (v.node_transform.astype(np.float64).T @ v.image_transform.astype(np.float64).T)[:3, :3]
@@ -204,7 +211,7 @@ def main():
                                "8 orbit views" % (args.workload, *WORKLOADS[args.workload][0], fw, fh,
                                                   {1: "block", 2: "Chebyshev distance-map", 3: "anisotropic"}[skip]),
                    "parallelism": "screen tiles 16x16 round-robin over %d GPU(s), RCCL gather to rank 0" % world if world > 1 else "1 GPU",
-                   "output": "RGBA8"},
+                   "output": "RGBA8", "occupied_voxel_percent": round(occupied_voxel_percent(ctx, v, tf), 4)},
         "covered_Mray_per_s": round(cov_total / elapsed / 1e6, 3), "covered_fraction": round(cov_total / (rays_per_frame_all * args.steps), 4),
         "volume_samples_per_s": round(vs_total / elapsed, 1), "distance_probes_per_s": round(ds_total / elapsed, 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
