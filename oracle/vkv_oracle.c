@@ -434,6 +434,17 @@ typedef struct
 
 /* One pixel: analytic ray setup (DESIGN.md "Ray generation", replaces the two vertex shaders and the
  * rasteriser) followed by main() of volume_render.frag from line 147 on. */
+/* optional per-ray event trace (diagnostics for the scheduling experiments in tools/): 'P' = distance probe that skipped,
+ * 'O' = probe that found an occupied cell, 'S' = empty volume sample, 'A' = volume sample with alpha > 0 */
+static __thread uint8_t *g_trace;
+static __thread uint32_t g_trace_cap, g_trace_len;
+static inline void trace_event(uint8_t c)
+{
+	if (g_trace && g_trace_len < g_trace_cap)
+		g_trace[g_trace_len] = c;
+	++g_trace_len;
+}
+
 static void march_pixel(const VkvRenderParams *P, const float *alpha_lut, int px, int py, PixelOut *out)
 {
 	memset(out, 0, sizeof(*out)); /* out_color = vec4(0) (frag:120); gl_FragDepth = 0 (frag:140) */
@@ -612,12 +623,14 @@ static void march_pixel(const VkvRenderParams *P, const float *alpha_lut, int px
 				float m = g_min(g_min(dx_, dy_), dz_);
 				m       = (m < 1073741824.0f) ? m : 1073741824.0f;
 				i += i_max(1, (int) ceilf(m)); /* frag:244-247 */
+				trace_event('P');
 			}
 			else
 			{ /* frag:253-261 */
 				occupied = 1;
 				ulx = uix, uly = uiy, ulz = uiz;
 				i = i_max(i - back, i_min_);
+				trace_event('O');
 			}
 		}
 		else
@@ -645,6 +658,7 @@ static void march_pixel(const VkvRenderParams *P, const float *alpha_lut, int px
 			/* get_color, transfer_function.glsl:35-38: NEAREST texel of the RGBA8 LUT */
 			const uint8_t *texel = P->d_transfer_function + ((size_t) tf_texel(gradient) * 256 + (size_t) tf_texel(intensity)) * 4;
 			occupied = texel[3] > 0; /* frag:276 */
+			trace_event(occupied ? 'A' : 'S');
 			if (occupied)
 			{
 				if (skip_mode != VKV_SKIP_NONE)
@@ -695,6 +709,19 @@ static void march_pixel(const VkvRenderParams *P, const float *alpha_lut, int px
 	{
 		out->rgba[0] = cr, out->rgba[1] = cg, out->rgba[2] = cb, out->rgba[3] = ca;
 	}
+}
+
+/* diagnostics: event sequence of one pixel's ray; returns its length (may exceed cap) */
+static void build_alpha_lut(const VkvTransferFunctionUniform *tf, float *lut);
+uint32_t vkvo_trace_ray(const VkvRenderParams *P, int px, int py, uint8_t *events, uint32_t cap)
+{
+	float lut[256];
+	build_alpha_lut(&P->transfer_function, lut);
+	PixelOut po;
+	g_trace = events, g_trace_cap = cap, g_trace_len = 0;
+	march_pixel(P, lut, px, py, &po);
+	g_trace = NULL;
+	return g_trace_len;
 }
 
 /* opacity-correction table keyed by the TF alpha byte (frag:283); shared definition with the product:

@@ -50,7 +50,7 @@ def test_synth_volume_matches_oracle(ctx, shape, kind, seed):
 # ------------------------------------------------------------------------------------------------------
 # gradient map
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(64, 64, 64), (37, 29, 23), (130, 5, 3), (1, 1, 1), (65, 1, 9)])
+@pytest.mark.parametrize("shape", [(64, 64, 64), (37, 29, 23), (130, 5, 3), (1, 1, 1), (65, 1, 9), (68, 13, 11), (4, 3, 2), (132, 9, 17), (256, 8, 8)])
 @pytest.mark.parametrize("use_gradient", [True, False])
 def test_gradient_map_parity(ctx, shape, use_gradient):
     vol = T.random_volume(shape, seed=11)

@@ -83,6 +83,7 @@ int vkv_create(int device_ordinal, vkv_ctx **out_ctx)
 	ctx->device          = device_ordinal;
 	ctx->error[0]        = 0;
 	ctx->workspace_bytes = kWorkspaceBytes;
+	ctx->d_trace         = nullptr;
 	e                    = hipMalloc((void **) &ctx->d_workspace, ctx->workspace_bytes);
 	if (e != hipSuccess)
 	{
@@ -100,6 +101,16 @@ void vkv_destroy(vkv_ctx *ctx)
 	if (ctx->d_workspace)
 		(void) hipFree(ctx->d_workspace);
 	delete ctx;
+}
+
+// Diagnostic hook (not part of the public header): per-wave timeline of the next vkv_render launches into d_buffer
+// (4 x u64 per wave of the static scheduler's grid); nullptr switches it off.
+int vkv_debug_trace(vkv_ctx *ctx, void *d_buffer)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	ctx->d_trace = d_buffer;
+	return VKV_OK;
 }
 
 const char *vkv_last_error(const vkv_ctx *ctx) { return ctx ? ctx->error : "null context"; }

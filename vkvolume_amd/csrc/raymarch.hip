@@ -42,6 +42,7 @@ struct RayMarchArgs
 	uint32_t        img_w, img_h, tile_w, tile_h, tiles_x, tile_first, tile_stride, tile_count, compact;
 	uint32_t        blocks_per_tile_x, blocks_per_tile, nblocks;
 	int             test;
+	unsigned long long *trace;      // diagnostic (tools/wave_trace.py): 4 x u64 per wave {t_start, t_end, iterations, unit}, or null
 	uint32_t *      queue_heads;        // persistent scheduler: 8 tile-queue heads (one per XCD label), zeroed per launch
 	float           alpha_lut[256];     // opacity correction keyed by the TF alpha byte (frag:283)
 };
@@ -89,23 +90,25 @@ __device__ __forceinline__ float sample_linear(const uint8_t *__restrict__ tex, 
 // a row is one (2-byte aligned) dword = (v0, g0, v1, g1).  Arithmetic identical to sample_linear, so results are too.
 typedef uint32_t u32_align2 __attribute__((aligned(2)));
 
-template <bool WANT_G>
-__device__ __forceinline__ void sample_packed(const uint8_t *__restrict__ P, int W, int H, int D, int pmx, int pmy, float px, float py, float pz,
-                                              float &out_v, float &out_g)
+// address of the footprint's first dword + the three filter weights
+__device__ __forceinline__ const uint8_t *packed_footprint(const uint8_t *__restrict__ P, int W, int H, int D, int pmx, int pmy, float px, float py, float pz,
+                                                           float &wx, float &wy, float &wz)
 {
 	const float cx = __builtin_fmaf(px, (float) W, -0.5f), cy = __builtin_fmaf(py, (float) H, -0.5f), cz = __builtin_fmaf(pz, (float) D, -0.5f);
 	const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy), fz = __builtin_floorf(cz);
-	const float wx = cx - fx, wy = cy - fy, wz = cz - fz;
-	const int   bx = i_clamp((int) fx, -1, W) + 1, by = i_clamp((int) fy, -1, H) + 1, bz = i_clamp((int) fz, -1, D) + 1;
+	wx = cx - fx, wy = cy - fy, wz = cz - fz;
+	const int bx = i_clamp((int) fx, -1, W) + 1, by = i_clamp((int) fy, -1, H) + 1, bz = i_clamp((int) fz, -1, D) + 1;
 	// 32-bit brick index (macro-brick * 512 + brick-in-macro), one 64-bit shift for the byte offset
 	const uint32_t macro = ((uint32_t) (bz >> 5) * (uint32_t) pmy + (uint32_t) (by >> 5)) * (uint32_t) pmx + (uint32_t) (bx >> 5);
 	const uint32_t sub   = (uint32_t) ((((bz >> 2) & 7) << 6) | (((by >> 2) & 7) << 3) | ((bx >> 2) & 7));
 	const uint32_t in    = (uint32_t) ((((bz & 3) * 5 + (by & 3)) * 5 + (bx & 3)) * 2);
-	const uint8_t *b     = P + (((uint64_t) (macro * 512u + sub)) << 8) + in;
-	const uint32_t q00 = *reinterpret_cast<const u32_align2 *>(b);
-	const uint32_t q10 = *reinterpret_cast<const u32_align2 *>(b + 10);
-	const uint32_t q01 = *reinterpret_cast<const u32_align2 *>(b + 50);
-	const uint32_t q11 = *reinterpret_cast<const u32_align2 *>(b + 60);
+	return P + (((uint64_t) (macro * 512u + sub)) << 8) + in;
+}
+
+// the four x-pair dwords (v0, g0, v1, g1) of rows (y0,z0), (y1,z0), (y0,z1), (y1,z1) -> filtered volume (and gradient) value
+template <bool WANT_G>
+__device__ __forceinline__ void packed_filter(uint32_t q00, uint32_t q10, uint32_t q01, uint32_t q11, float wx, float wy, float wz, float &out_v, float &out_g)
+{
 	{
 		const float b000 = (float) (q00 & 255u), b100 = (float) ((q00 >> 16) & 255u);
 		const float b010 = (float) (q10 & 255u), b110 = (float) ((q10 >> 16) & 255u);
@@ -127,6 +130,19 @@ __device__ __forceinline__ void sample_packed(const uint8_t *__restrict__ P, int
 		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
 		out_g = __builtin_fmaf(wz, c1 - c0, c0) * kInv255;
 	}
+}
+
+template <bool WANT_G>
+__device__ __forceinline__ void sample_packed(const uint8_t *__restrict__ P, int W, int H, int D, int pmx, int pmy, float px, float py, float pz,
+                                              float &out_v, float &out_g)
+{
+	float          wx, wy, wz;
+	const uint8_t *b   = packed_footprint(P, W, H, D, pmx, pmy, px, py, pz, wx, wy, wz);
+	const uint32_t q00 = *reinterpret_cast<const u32_align2 *>(b);
+	const uint32_t q10 = *reinterpret_cast<const u32_align2 *>(b + 10);
+	const uint32_t q01 = *reinterpret_cast<const u32_align2 *>(b + 50);
+	const uint32_t q11 = *reinterpret_cast<const u32_align2 *>(b + 60);
+	packed_filter<WANT_G>(q00, q10, q01, q11, wx, wy, wz, out_v, out_g);
 }
 
 __device__ __forceinline__ void mat4_mul_vec4(const float *m, const float *v, float *r)
@@ -261,7 +277,7 @@ __device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, ui
 // Returns true when the ray has ended (ran past n_steps, or early ray termination).
 // ---------------------------------------------------------------------------------------------------------------
 template <int SKIP, bool ERT, int GRAD, bool PACKED>
-__device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const float *s_alpha, const uint32_t *s_bits, bool tf_bits)
+__device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const float *s_alpha, const float *s_unorm, const uint32_t *s_bits, bool tf_bits)
 {
 	const int   W = A.W, H = A.H, D = A.D;
 	const int   i  = R.i;
@@ -275,10 +291,38 @@ __device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const f
 		ux = kx * posx, uy = ky * posy, uz = kz * posz;
 		uix = i_clamp((int) ux, 0, A.mw - 1), uiy = i_clamp((int) uy, 0, A.mh - 1), uiz = i_clamp((int) uz, 0, A.md - 1);
 	}
-	if (SKIP != VKV_SKIP_NONE && !R.occupied && (uix != R.ulx || uiy != R.uly || uiz != R.ulz))
+	const bool probe = SKIP != VKV_SKIP_NONE && !R.occupied && (uix != R.ulx || uiy != R.uly || uiz != R.ulz);        // frag:224
+
+	// ---- issue phase --------------------------------------------------------------------------------------------
+	// A wave usually holds probing and sampling lanes at once.  Issue this iteration's loads for BOTH kinds before either
+	// is consumed (lanes of the other kind read a dummy address that every lane shares), so the probe's and the sample's
+	// memory latencies overlap instead of adding up on the critical path of the wave.
+	constexpr bool kHoist = PACKED && GRAD != 2 && SKIP != VKV_SKIP_NONE;
+	uint32_t       dist_h = 0, q00 = 0, q10 = 0, q01 = 0, q11 = 0;
+	float          hwx = 0, hwy = 0, hwz = 0;
+	if (kHoist)
+	{
+		const uint32_t cell = ((uint32_t) uiz * (uint32_t) A.mh + (uint32_t) uiy) * (uint32_t) A.mw + (uint32_t) uix;
+		const uint8_t *fp   = packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, hwx, hwy, hwz);
+		const uint8_t *ma   = R.dmap + (probe ? cell : 0u);
+		const uint8_t *ba   = probe ? A.packed : fp;
+		dist_h              = *ma;
+		q00                 = *reinterpret_cast<const u32_align2 *>(ba);
+		q10                 = *reinterpret_cast<const u32_align2 *>(ba + 10);
+		q01                 = *reinterpret_cast<const u32_align2 *>(ba + 50);
+		q11                 = *reinterpret_cast<const u32_align2 *>(ba + 60);
+		// keep the five loads above the divergent consume code (the compiler would otherwise sink each into its branch)
+		asm volatile("" : "+v"(dist_h), "+v"(q00), "+v"(q10), "+v"(q01), "+v"(q11));
+	}
+
+	if (probe)
 	{        // frag:224-263
 		++R.n_dist;
-		const uint32_t dist = R.dmap[((uint32_t) uiz * (uint32_t) A.mh + (uint32_t) uiy) * (uint32_t) A.mw + (uint32_t) uix];
+		uint32_t dist;
+		if (kHoist)
+			dist = dist_h;
+		else
+			dist = R.dmap[((uint32_t) uiz * (uint32_t) A.mh + (uint32_t) uiy) * (uint32_t) A.mw + (uint32_t) uix];
 		if (dist > 0u)
 		{
 			// r = clamp(u_i - u, -1, 0) (frag:234); the operand is never NaN, so the median-of-three instruction gives the
@@ -320,7 +364,15 @@ __device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const f
 	// frag:266-310
 	++R.n_vol;
 	float intensity, gradient = 1.0f;
-	if (PACKED)
+	if (kHoist)
+	{
+		float unused;
+		if (GRAD == 1)
+			packed_filter<true>(q00, q10, q01, q11, hwx, hwy, hwz, intensity, gradient);
+		else
+			packed_filter<false>(q00, q10, q01, q11, hwx, hwy, hwz, intensity, unused);
+	}
+	else if (PACKED)
 	{
 		float unused;
 		if (GRAD == 1)
@@ -377,7 +429,8 @@ __device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const f
 		if (SKIP != VKV_SKIP_NONE)
 			R.ulx = uix, R.uly = uiy, R.ulz = uiz;
 		const float a  = s_alpha[ab];        // frag:283
-		const float r_ = unorm8(texel & 255u) * a, g_ = unorm8((texel >> 8) & 255u) * a, b_ = unorm8((texel >> 16) & 255u) * a;
+		// R8G8B8A8_UNORM -> float is exactly c / 255: read from the LDS table the workgroup filled with that division
+		const float r_ = s_unorm[texel & 255u] * a, g_ = s_unorm[(texel >> 8) & 255u] * a, b_ = s_unorm[(texel >> 16) & 255u] * a;
 		const float om = 1.0f - R.a;         // frag:287
 		R.r = __builtin_fmaf(om, r_, R.r), R.g = __builtin_fmaf(om, g_, R.g), R.b = __builtin_fmaf(om, b_, R.b);
 		R.a = __builtin_fmaf(om, a, R.a);
@@ -453,9 +506,10 @@ __device__ __forceinline__ bool unit_pixel(const RayMarchArgs &A, uint32_t u, ui
 	return px < A.img_w && py < A.img_h;
 }
 
-__device__ __forceinline__ void stage_tables(const RayMarchArgs &A, float *s_alpha, uint32_t *s_bits)
+__device__ __forceinline__ void stage_tables(const RayMarchArgs &A, float *s_alpha, float *s_unorm, uint32_t *s_bits)
 {
 	s_alpha[threadIdx.x] = A.alpha_lut[threadIdx.x];
+	s_unorm[threadIdx.x] = unorm8(threadIdx.x);        // exact IEEE division, once per workgroup
 	if (A.tf_bits)
 		for (int i = threadIdx.x; i < 2048; i += 256)
 			s_bits[i] = A.tf_bits[i];
@@ -468,9 +522,9 @@ __device__ __forceinline__ void stage_tables(const RayMarchArgs &A, float *s_alp
 template <int SKIP, bool ERT, int GRAD, bool PACKED>
 __global__ void __launch_bounds__(256) k_raymarch_tiles(const RayMarchArgs A)
 {
-	__shared__ float    s_alpha[256];
+	__shared__ float    s_alpha[256], s_unorm[256];
 	__shared__ uint32_t s_bits[2048];
-	stage_tables(A, s_alpha, s_bits);
+	stage_tables(A, s_alpha, s_unorm, s_bits);
 	const bool tf_bits = A.tf_bits != nullptr;
 	// Hardware deals workgroup ids round-robin over the 8 XCDs (own L2 each).  XCD x = id & 7 marches the schedule's
 	// tiles k = x, x + 8, x + 16, ... one after the other: neighbouring workgroups of an XCD share a tile (L2 locality)
@@ -485,12 +539,30 @@ __global__ void __launch_bounds__(256) k_raymarch_tiles(const RayMarchArgs A)
 		return;
 	Ray R;
 	R.o = o;
+	const unsigned long long t_start = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	const bool marched = ray_setup<SKIP>(A, px, py, R);
+	uint32_t   iter    = 0;
 	if (marched)
-		while (!ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_bits, tf_bits))
-		{
-		}
+	{
+		// The frame time is the critical path of the wave with the longest ray: once a wave has run 48 events it is one of
+		// those, so let it win instruction arbitration against the younger waves on its SIMD.
+		while (!ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_unorm, s_bits, tf_bits))
+			if (__builtin_amdgcn_readfirstlane(++iter) == 48u)        // provably wave-uniform: a real scalar branch
+				__builtin_amdgcn_s_setprio(3);
+	}
 	ray_finish(A, R, marched);
+	if (A.trace)
+	{        // diagnostic only: per-wave timeline (100 MHz clock); the values never feed an output
+		uint32_t it = iter;
+		for (int o2 = 32; o2 > 0; o2 >>= 1)
+			it = max(it, (uint32_t) __shfl_xor((int) it, o2));
+		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+		if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)))
+		{
+			unsigned long long *rec = A.trace + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+			rec[0] = t_start, rec[1] = t_end, rec[2] = it, rec[3] = ((unsigned long long) __builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (k * A.blocks_per_tile + sb);
+		}
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -528,9 +600,9 @@ __device__ __forceinline__ uint32_t pop_unit(const RayMarchArgs &A, uint32_t &q)
 template <int SKIP, bool ERT, int GRAD, bool PACKED>
 __global__ void __launch_bounds__(256) k_raymarch_persistent(const RayMarchArgs A)
 {
-	__shared__ float    s_alpha[256];
+	__shared__ float    s_alpha[256], s_unorm[256];
 	__shared__ uint32_t s_bits[2048];
-	stage_tables(A, s_alpha, s_bits);
+	stage_tables(A, s_alpha, s_unorm, s_bits);
 	const bool     tf_bits = A.tf_bits != nullptr;
 	// blocks b and b + 8 share an XCD under the observed round-robin placement (speed only, never correctness)
 	uint32_t q      = blockIdx.x & 7u;
@@ -574,7 +646,7 @@ __global__ void __launch_bounds__(256) k_raymarch_persistent(const RayMarchArgs 
 		// ---- one event per active lane ----
 		if (active)
 		{
-			if (ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_bits, tf_bits))
+			if (ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_unorm, s_bits, tf_bits))
 			{
 				ray_finish(A, R, true);
 				active = false;
@@ -685,6 +757,7 @@ int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut
 	a.nblocks     = (uint32_t) nb;
 	a.test        = P->options.test;
 	a.queue_heads = reinterpret_cast<uint32_t *>(ctx->d_workspace + kQueueHeadsOffset);
+	a.trace       = reinterpret_cast<unsigned long long *>(ctx->d_trace);
 	for (int i = 0; i < 256; ++i)
 		a.alpha_lut[i] = alpha_lut[i];
 

@@ -106,6 +106,7 @@ struct vkv_ctx
 	char     error[512];
 	uint8_t *d_workspace;        // small device scratch: TF bit table (8 KiB)
 	size_t   workspace_bytes;
+	void *   d_trace;        // diagnostic wave timeline buffer (vkv_debug_trace), normally null
 };
 
 namespace vkv
