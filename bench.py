@@ -82,9 +82,13 @@ def cameras(v, aspect):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames-in-flight", type=int, default=3, help="render consecutive frames on this many HIP streams (each with its "
+                    "own framebuffer) so the tail of one frame overlaps the start of the next; 1 = strictly one frame at a time")
+    ap.add_argument("--force-gather", action="store_true", help="exercise the tile gather / de-interleave path with a 1-rank process group")
+    ap.add_argument("--verify", action="store_true", help="after timing, check the assembled frame of the last step against a direct render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
@@ -100,9 +104,11 @@ def main():
         raise SystemExit("--gpus must be 1, 2, 4 or 8")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    use_gather = world > 1 or args.force_gather
+    if use_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     ctx = lib.Context(local_rank)  # raises if the HIP library is missing: there is no fallback path
@@ -112,9 +118,9 @@ def main():
     views = cameras(v, frame[0] / frame[1])  # the SAME frustum for every N
     opts = abi.RenderOptions(skipping_type=skip, clip_distance=1.0, early_ray_termination=True)
     sp = V.VolumeRenderSubpass(ctx, v, opts, (fw, fh))
-    tiles = abi.full_frame_tiles(fw, fh, TILE, TILE, rank, world, compact=(world > 1))
+    tiles = abi.full_frame_tiles(fw, fh, TILE, TILE, rank, world, compact=use_gather)
     params = [sp.make_params(view, proj, tiles) for view, proj in views]
-    my_pixels = tiles.tile_count * TILE * TILE if world > 1 else fw * fh
+    my_pixels = tiles.tile_count * TILE * TILE if use_gather else fw * fh
     rays_per_frame_all = fw * fh  # every pixel of the frame is a ray (covered or not), summed over ranks
 
     # ---- pre-pass (untimed): frag counters per view -> algorithmic bytes per launch ------------------------------
@@ -129,43 +135,50 @@ def main():
         n_ds.append(int(s[1]))
         n_cov.append(int(((counts[:, 0] + counts[:, 1]) > 0).sum().item()))
     del counts
-    # ---- outputs: N = 1 renders straight into the frame; N > 1 into double-buffered compact tile buffers -----------
-    gather = image = None
-    if world > 1:
-        gather = multigpu.TileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda")
+    # ---- outputs -------------------------------------------------------------------------------------------------
+    # `fif` frames are in flight: frame k renders on HIP stream k % fif into its own buffer, so the long tail of one
+    # frame (a few waves with 200-300 dependent events) overlaps the bulk of the next — what a swap-chain renderer
+    # (the reference) gets from its per-frame command buffers.  N = 1 renders straight into the frame; N > 1 (or
+    # --force-gather) renders this rank's tiles into a compact buffer that is gathered to rank 0 and de-interleaved.
+    fif = max(1, args.frames_in_flight)
+    gather, images = None, []
+    if use_gather:
+        gather = multigpu.TileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda", n_buffers=fif)
         bufs, my_rays = gather.buffers, gather.my_ray_count()
         if rank == 0:
-            image = torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda")
+            images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(fif)]
     else:
-        bufs, my_rays = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda")], fw * fh
-    n_buf = len(bufs)
+        bufs, my_rays = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(fif)], fw * fh
+    torch.cuda.synchronize()
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(fif - 1)]
 
     ev_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_stop = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    stream = torch.cuda.current_stream()
 
     def collect(b):
-        """finish buffer b's gather (if any) and de-interleave it into the frame on rank 0"""
+        """(on stream b) finish buffer b's gather, if one is pending, and de-interleave it into frame b on rank 0"""
         flat = gather.finish(b)
         if flat is not None:
-            ctx.scatter_tiles(flat.data_ptr(), image.data_ptr(), (fw, fh), (TILE, TILE), world, gather.tiles_per_rank, 4, stream.cuda_stream)
+            ctx.scatter_tiles(flat.data_ptr(), images[b].data_ptr(), (fw, fh), (TILE, TILE), world, gather.tiles_per_rank, 4,
+                              torch.cuda.current_stream().cuda_stream)
 
     def run(n_steps, timed):
         for k in range(n_steps):
-            b = k % n_buf
-            if gather:
-                collect(b)  # buffer b's previous gather must be done before it is overwritten
-            p = params[k % N_VIEWS]
-            if timed:
-                ev_start[k].record(stream)
-            sp.draw(p, rgba8=bufs[b])
-            if timed:
-                ev_stop[k].record(stream)
-            if gather:
-                gather.start(b)  # overlaps the next frame's render
+            b = k % fif
+            with torch.cuda.stream(streams[b]):
+                if gather:
+                    collect(b)  # buffer b's previous gather must have landed before the buffer is overwritten
+                if timed:
+                    ev_start[k].record(streams[b])
+                sp.draw(params[k % N_VIEWS], rgba8=bufs[b])
+                if timed:
+                    ev_stop[k].record(streams[b])
+                if gather:
+                    gather.start(b)  # RCCL gather of frame k overlaps the render of frame k + 1
         if gather:
-            for b in range(n_buf):
-                collect(b)
+            for b in range(fif):
+                with torch.cuda.stream(streams[b]):
+                    collect(b)
 
     def fence():
         if world > 1:
@@ -198,6 +211,8 @@ def main():
         dist.all_reduce(tot)
     vs_total, ds_total, cov_total = float(tot[0].item()), float(tot[1].item()), float(tot[2].item())
 
+    if args.verify:
+        verify(ctx, sp, v, views, params, args.steps, fif, (fw, fh), bufs, images, gather, rank)
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -211,14 +226,17 @@ def main():
                                "8 orbit views" % (args.workload, *WORKLOADS[args.workload][0], fw, fh,
                                                   {1: "block", 2: "Chebyshev distance-map", 3: "anisotropic"}[skip]),
                    "parallelism": "screen tiles 16x16 round-robin over %d GPU(s), RCCL gather to rank 0" % world if world > 1 else "1 GPU",
-                   "output": "RGBA8", "occupied_voxel_percent": round(occupied_voxel_percent(ctx, v, tf), 4)},
+                   "output": "RGBA8", "frames_in_flight": fif, "occupied_voxel_percent": round(occupied_voxel_percent(ctx, v, tf), 4)},
         "covered_Mray_per_s": round(cov_total / elapsed / 1e6, 3), "covered_fraction": round(cov_total / (rays_per_frame_all * args.steps), 4),
         "volume_samples_per_s": round(vs_total / elapsed, 1), "distance_probes_per_s": round(ds_total / elapsed, 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                     "achieved_aggregate": round(sum(alg_bytes) / elapsed / 1e9, 2),
                      "kernel": "k_raymarch", "kernel_ms_avg": round(kernel_ms_avg, 4),
                      "algorithmic_bytes_per_launch": int(alg_avg),
-                     "note": "algorithmic (requested) bytes: 16 B/volume sample + 1 B/distance probe + 4 B/ray; NOT DRAM traffic"},
+                     "note": "algorithmic (requested) bytes: 16 B/volume sample + 1 B/distance probe + 4 B/ray; NOT DRAM traffic. achieved = per "
+                             "launch / HIP-event duration of that launch (launches of consecutive frames overlap when frames_in_flight > 1); "
+                             "achieved_aggregate = this rank's bytes of all timed launches / wall time"},
     }
 
     # HBM traffic cannot be read from inside the process; it comes from separate rocprofv3 --pmc passes over this same
@@ -235,8 +253,23 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(v, params, (fw, fh), args.cpu_seconds)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
+
+
+def verify(ctx, sp, v, views, params, steps, fif, frame, bufs, images, gather, rank):
+    """The frame left in the last step's buffer must equal a direct single-launch render of the same view, bit for bit."""
+    if rank != 0:
+        return
+    k = steps - 1
+    fw, fh = frame
+    direct = torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda")
+    sp.draw(sp.make_params(*views[k % N_VIEWS], abi.full_frame_tiles(fw, fh, TILE, TILE)), rgba8=direct)
+    torch.cuda.synchronize()
+    got = images[k % fif] if gather else bufs[k % fif].view(fh, fw, 4)
+    if not torch.equal(got, direct):
+        raise SystemExit("verify failed: assembled frame differs from the direct render in %d bytes" % int((got != direct).sum().item()))
+    print("verify ok: frame of step %d matches the direct render (%d non-zero bytes)" % (k, int((direct != 0).sum().item())), file=sys.stderr)
 
 
 def cpu_baseline(v, params, frame, target_seconds):

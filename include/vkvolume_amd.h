@@ -33,6 +33,8 @@ extern "C" {
 #define VKV_E_NO_DEVICE (-3)        /* no HIP device / wrong architecture               */
 #define VKV_E_IO (-4)               /* file errors of the loader                        */
 
+#define VKV_TF_BITS_WORDS 2052      /* uint32 words of a vkv_transfer_function_bits() buffer */
+
 /* VkExtent3D stand-in (src/load_volume.h:31, src/volume_component.cpp:91-92). */
 typedef struct VkvExtent3D
 {
@@ -244,9 +246,10 @@ int vkv_load_data(const char *filename_data, const VkvVolumeHeader *header, uint
 size_t vkv_packed_volume_bytes(VkvExtent3D extent);
 int    vkv_pack_volume(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_t *d_gradient, VkvExtent3D extent, void *d_packed, void *stream);
 
-/* 1 bit per texel of the 256x256 TF texture: alpha > 0 (8 KiB, row = gradient).  Lets the integrator decide
+/* 1 bit per texel of the 256x256 TF texture: alpha > 0 (2048 words, row = gradient), followed by word 2048 = the smallest
+ * intensity texel whose column holds any occupied texel; the buffer is VKV_TF_BITS_WORDS = 2052 uint32.  Lets the integrator decide
  * "voxel_occupied" (frag:276) from LDS and fetch the RGBA texel only for occupied samples. */
-int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_transfer_function, uint32_t *d_bits_2048, void *stream);
+int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_transfer_function, uint32_t *d_bits_2052, void *stream);
 
 /* VolumeRenderSubpass::draw, src/volume_render_subpass.cpp:159-294 (shaders/volume_render.frag). */
 int vkv_render(vkv_ctx *ctx, const VkvRenderParams *params, void *stream);

@@ -277,7 +277,8 @@ __device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, ui
 // Returns true when the ray has ended (ran past n_steps, or early ray termination).
 // ---------------------------------------------------------------------------------------------------------------
 template <int SKIP, bool ERT, int GRAD, bool PACKED>
-__device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const float *s_alpha, const float *s_unorm, const uint32_t *s_bits, bool tf_bits)
+__device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const float *s_alpha, const float *s_unorm, const uint32_t *s_bits, bool tf_bits,
+                                          uint32_t colmin)
 {
 	const int   W = A.W, H = A.H, D = A.D;
 	const int   i  = R.i;
@@ -363,6 +364,19 @@ __device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const f
 
 	// frag:266-310
 	++R.n_vol;
+	// Quick reject (kHoist variants): the filtered intensity is a convex combination of the eight corner bytes, so it cannot
+	// exceed the largest of them; if even that byte's texel column of the TF holds no occupied texel (colmin), alpha is 0
+	// for any gradient and neither filter, the texel index nor the table look-up is needed.  Same result, fewer instructions.
+	uint32_t texel = 0;
+	bool     quick = false;
+	if (kHoist)
+	{
+		const uint32_t a0 = max(q00 & 255u, (q00 >> 16) & 255u), a1 = max(q10 & 255u, (q10 >> 16) & 255u);
+		const uint32_t a2 = max(q01 & 255u, (q01 >> 16) & 255u), a3 = max(q11 & 255u, (q11 >> 16) & 255u);
+		quick             = max(max(a0, a1), max(a2, a3)) < colmin;
+	}
+	if (!quick)
+	{
 	float intensity, gradient = 1.0f;
 	if (kHoist)
 	{
@@ -413,7 +427,6 @@ __device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const f
 	// get_color (transfer_function.glsl:35-38): NEAREST texel.  With the bit table the occupied test (frag:276) comes
 	// from LDS and only occupied samples pay the dependent RGBA fetch.
 	const uint32_t tidx  = (uint32_t) tf_texel(gradient) * 256u + (uint32_t) tf_texel(intensity);
-	uint32_t       texel = 0;
 	if (tf_bits)
 	{
 		if ((s_bits[tidx >> 5] >> (tidx & 31u)) & 1u)
@@ -421,6 +434,7 @@ __device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const f
 	}
 	else
 		texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
+	}        // !quick
 	const uint32_t ab = texel >> 24;
 	R.occupied        = ab > 0;
 	bool ended        = false;
@@ -525,7 +539,8 @@ __global__ void __launch_bounds__(256) k_raymarch_tiles(const RayMarchArgs A)
 	__shared__ float    s_alpha[256], s_unorm[256];
 	__shared__ uint32_t s_bits[2048];
 	stage_tables(A, s_alpha, s_unorm, s_bits);
-	const bool tf_bits = A.tf_bits != nullptr;
+	const bool     tf_bits = A.tf_bits != nullptr;
+	const uint32_t colmin  = tf_bits ? A.tf_bits[2048] : 0u;        // wave-uniform (scalar load)
 	// Hardware deals workgroup ids round-robin over the 8 XCDs (own L2 each).  XCD x = id & 7 marches the schedule's
 	// tiles k = x, x + 8, x + 16, ... one after the other: neighbouring workgroups of an XCD share a tile (L2 locality)
 	// while the tiles of the frame are spread evenly over the XCDs (ESS makes screen regions differ >10x in cost; a
@@ -546,7 +561,7 @@ __global__ void __launch_bounds__(256) k_raymarch_tiles(const RayMarchArgs A)
 	{
 		// The frame time is the critical path of the wave with the longest ray: once a wave has run 48 events it is one of
 		// those, so let it win instruction arbitration against the younger waves on its SIMD.
-		while (!ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_unorm, s_bits, tf_bits))
+		while (!ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_unorm, s_bits, tf_bits, colmin))
 			if (__builtin_amdgcn_readfirstlane(++iter) == 48u)        // provably wave-uniform: a real scalar branch
 				__builtin_amdgcn_s_setprio(3);
 	}
@@ -604,6 +619,7 @@ __global__ void __launch_bounds__(256) k_raymarch_persistent(const RayMarchArgs 
 	__shared__ uint32_t s_bits[2048];
 	stage_tables(A, s_alpha, s_unorm, s_bits);
 	const bool     tf_bits = A.tf_bits != nullptr;
+	const uint32_t colmin  = tf_bits ? A.tf_bits[2048] : 0u;
 	// blocks b and b + 8 share an XCD under the observed round-robin placement (speed only, never correctness)
 	uint32_t q      = blockIdx.x & 7u;
 	uint32_t unit   = pop_unit(A, q);
@@ -646,7 +662,7 @@ __global__ void __launch_bounds__(256) k_raymarch_persistent(const RayMarchArgs 
 		// ---- one event per active lane ----
 		if (active)
 		{
-			if (ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_unorm, s_bits, tf_bits))
+			if (ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_unorm, s_bits, tf_bits, colmin))
 			{
 				ray_finish(A, R, true);
 				active = false;

@@ -67,7 +67,7 @@ void Volume::allocate(DeviceContext &dc, VkvExtent3D extent, uint32_t block)
 	transfer_function.extent          = VkvExtent3D{256, 256, 1};        // R8G8B8A8_UNORM 256x256 (src/volume_component.cpp:68-74)
 	transfer_function.bytes_per_texel = 4;
 	transfer_function.data            = device_alloc(transfer_function.size_bytes());
-	transfer_function_bits            = reinterpret_cast<uint32_t *>(device_alloc(2048 * sizeof(uint32_t)));
+	transfer_function_bits            = reinterpret_cast<uint32_t *>(device_alloc(VKV_TF_BITS_WORDS * sizeof(uint32_t)));
 	auto rnd_up                       = [](uint32_t x, uint32_t y) { return (x + y - 1) / y; };
 	distance_map_swap.extent          = VkvExtent3D{rnd_up(extent.width, block), rnd_up(extent.height, block), rnd_up(extent.depth, block)};
 	distance_map_swap.data            = device_alloc(distance_map_swap.size_bytes());

@@ -63,7 +63,7 @@ class Volume:
         if self.options.use_precomputed_gradient:
             self.gradient = torch.empty_like(self.volume)
         self.transfer_function = torch.zeros((256, 256, 4), dtype=torch.uint8, device=self.device)
-        self.transfer_function_bits = torch.zeros(2048, dtype=torch.int32, device=self.device)
+        self.transfer_function_bits = torch.zeros(abi.TF_BITS_WORDS, dtype=torch.int32, device=self.device)
         self.packed = None
         self.distance_map_swap = torch.empty((self.map_extent.depth, self.map_extent.height, self.map_extent.width),
                                              dtype=torch.uint8, device=self.device)
