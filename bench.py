@@ -42,6 +42,7 @@ WORKLOADS = {
     # name: (extent WxHxD, seed, voxel size, axis-angle, frame, skipping type)
     "c3": ((1024, 1024, 795), 0xC0FFEE03, (0.0003, 0.0003, 0.0007), (1.0, 0.0, 0.0, 90.0), (1920, 1080), abi.SKIP_DISTANCE),
     "c2": ((512, 512, 512), 0xC0FFEE02, (1.0, 1.0, 1.0), (1.0, 0.0, 0.0, 0.0), (1920, 1080), abi.SKIP_BLOCK),
+    "c4": ((2048, 2048, 2048), 0xC0FFEE04, (1.0, 1.0, 1.0), (1.0, 0.0, 0.0, 0.0), (3840, 2160), abi.SKIP_ANISOTROPIC_DISTANCE),
     "small": ((128, 128, 100), 0xC0FFEE03, (0.0003, 0.0003, 0.0007), (1.0, 0.0, 0.0, 90.0), (320, 192), abi.SKIP_DISTANCE),
 }
 GRID = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}

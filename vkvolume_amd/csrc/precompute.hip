@@ -16,15 +16,15 @@ using namespace vkv;
 __global__ void __launch_bounds__(256) k_gradient_map(const uint8_t *__restrict__ vol, uint8_t *__restrict__ grad, int W, int H, int D,
                                                       int use_gradient, float modifier, uint32_t blocks_x, uint32_t nblocks)
 {
-	const uint32_t b  = xcd_remap(blockIdx.x, nblocks);
-	const uint32_t bx = b % blocks_x;
-	const uint32_t r  = b / blocks_x;        // (y, z) row group: 4 rows per block
+	// grid.x = column blocks x 4-row groups of one z slice, grid.y = z (keeps every grid dimension x block size below 2^32
+	// for 2048^3 and larger volumes)
+	(void) nblocks;
+	const uint32_t bx = blockIdx.x % blocks_x;
 	const int      x  = (int) (bx * 64 + (threadIdx.x & 63));
-	const uint32_t row = r * 4 + (threadIdx.x >> 6);
-	if (x >= W || row >= (uint32_t) H * (uint32_t) D)
+	const int      y  = (int) ((blockIdx.x / blocks_x) * 4 + (threadIdx.x >> 6)), z = (int) blockIdx.y;
+	if (x >= W || y >= H)
 		return;
-	const int y = (int) (row % (uint32_t) H), z = (int) (row / (uint32_t) H);
-	float     g = 1.0f;        // get_gradient_compute.glsl:6-7
+	float g = 1.0f;        // get_gradient_compute.glsl:6-7
 	if (use_gradient)
 		g = gradient_on_the_fly(vol, W, H, D, x, y, z, modifier);
 	grad[vidx(x, y, z, W, H)] = store_unorm8(g);
@@ -151,10 +151,8 @@ __global__ void __launch_bounds__(256) k_occupancy_map(const uint8_t *__restrict
 	s_cell[threadIdx.x] = 0;
 	__syncthreads();
 
-	const uint32_t b   = blockIdx.x;
-	const uint32_t bxi = b % blocks_x;
-	const uint32_t r   = b / blocks_x;
-	const int      cy = (int) (r % (uint32_t) mh), cz = (int) (r / (uint32_t) mh);
+	const uint32_t bxi = blockIdx.x % blocks_x;
+	const int      cy = (int) (blockIdx.x / blocks_x), cz = (int) blockIdx.y;        // grid = (x blocks * cell rows, cell slices)
 	// the block covers cells [c0, c0 + cells_per_block) of this cell row
 	const int cells_per_block = 256 / bx > 0 ? 256 / bx : 1;
 	const int c0              = (int) bxi * cells_per_block;
@@ -375,11 +373,11 @@ __global__ void __launch_bounds__(256) k_dm_axis(const uint8_t *__restrict__ src
 __global__ void __launch_bounds__(256) k_pack_volume(const uint8_t *__restrict__ vol, const uint8_t *__restrict__ grad, uint8_t *__restrict__ packed,
                                                      int W, int H, int D, PackedDims pd, uint32_t n_bricks)
 {
-	const uint32_t brick = blockIdx.x * 2 + (threadIdx.x >> 7);        // linear over (bz, by, bx)
+	const uint32_t brick = blockIdx.x * 2 + (threadIdx.x >> 7);        // linear over (by, bx) of brick layer bz = blockIdx.y
 	const int      t     = threadIdx.x & 127;
 	if (brick >= n_bricks)
 		return;
-	const int bx = (int) (brick % (uint32_t) pd.bx), by = (int) ((brick / (uint32_t) pd.bx) % (uint32_t) pd.by), bz = (int) (brick / ((uint32_t) pd.bx * (uint32_t) pd.by));
+	const int bx = (int) (brick % (uint32_t) pd.bx), by = (int) (brick / (uint32_t) pd.bx), bz = (int) blockIdx.y;
 	uint16_t *dst = reinterpret_cast<uint16_t *>(packed + packed_brick_offset(bx, by, bz, pd.mx, pd.my));
 	if (t >= 125)
 	{
@@ -419,12 +417,11 @@ __device__ __forceinline__ uint32_t synth_hash(uint32_t seed, uint32_t x, uint32
 
 __global__ void __launch_bounds__(256) k_synth_sphere(uint8_t *__restrict__ vol, int W, int H, int D, uint32_t blocks_x)
 {
-	const uint32_t bx  = blockIdx.x % blocks_x;
-	const uint32_t row = (blockIdx.x / blocks_x) * 4 + (threadIdx.x >> 6);
-	const int      x   = (int) (bx * 64 + (threadIdx.x & 63));
-	if (x >= W || row >= (uint32_t) H * (uint32_t) D)
+	const uint32_t bx = blockIdx.x % blocks_x;
+	const int      x  = (int) (bx * 64 + (threadIdx.x & 63));
+	const int      y  = (int) ((blockIdx.x / blocks_x) * 4 + (threadIdx.x >> 6)), z = (int) blockIdx.y;        // grid.y = z
+	if (x >= W || y >= H)
 		return;
-	const int   y = (int) (row % (uint32_t) H), z = (int) (row / (uint32_t) H);
 	const float dm = (float) max(max(W, H), D);
 	const float R0 = 0.375f * dm, R1 = 0.25f * dm;
 	const float cx = ((float) W - 1.0f) * 0.5f, cy = ((float) H - 1.0f) * 0.5f, cz = ((float) D - 1.0f) * 0.5f;
@@ -440,13 +437,12 @@ __global__ void __launch_bounds__(256) k_synth_shells(uint8_t *__restrict__ vol,
 	for (int i = threadIdx.x; i < kSynthShells * 10; i += 256)
 		reinterpret_cast<float *>(s_sh)[i] = reinterpret_cast<const float *>(args.sh)[i];
 	__syncthreads();
-	const uint32_t bx  = blockIdx.x % blocks_x;
-	const uint32_t row = (blockIdx.x / blocks_x) * 4 + (threadIdx.x >> 6);
-	const int      x   = (int) (bx * 64 + (threadIdx.x & 63));
-	if (x >= W || row >= (uint32_t) H * (uint32_t) D)
+	const uint32_t bx = blockIdx.x % blocks_x;
+	const int      x  = (int) (bx * 64 + (threadIdx.x & 63));
+	const int      y  = (int) ((blockIdx.x / blocks_x) * 4 + (threadIdx.x >> 6)), z = (int) blockIdx.y;        // grid.y = z
+	if (x >= W || y >= H)
 		return;
-	const int y = (int) (row % (uint32_t) H), z = (int) (row / (uint32_t) H);
-	float     best = 0.0f;
+	float best = 0.0f;
 	for (int k = 0; k < kSynthShells; ++k)
 	{
 		const float dx = ((float) x - s_sh[k].cx) * s_sh[k].irx;
@@ -493,9 +489,7 @@ namespace vkv
 int launch_gradient_map(vkv_ctx *ctx, const uint8_t *d_vol, uint8_t *d_grad, VkvExtent3D e, const VkvTransferFunctionUniform *tf, hipStream_t s)
 {
 	const uint32_t blocks_x = (e.width + 63) / 64;
-	const uint64_t rows     = (uint64_t) e.height * e.depth;
-	const uint64_t nblocks  = blocks_x * ((rows + 3) / 4);
-	if (nblocks > 0x7fffffffull)
+	if (e.depth > 65535u || (uint64_t) blocks_x * ((e.height + 3) / 4) > 0xffffffull)
 		return set_error(ctx, VKV_E_UNSUPPORTED, "gradient_map: volume too large for one launch");
 	if (tf->use_gradient && (e.width & 3u) == 0 && (((uintptr_t) d_vol) & 3u) == 0)
 	{
@@ -508,8 +502,8 @@ int launch_gradient_map(vkv_ctx *ctx, const uint8_t *d_vol, uint8_t *d_grad, Vkv
 			return check_launch(ctx, "gradient_map");
 		}
 	}
-	hipLaunchKernelGGL(k_gradient_map, dim3((uint32_t) nblocks), dim3(256), 0, s, d_vol, d_grad, (int) e.width, (int) e.height, (int) e.depth,
-	                   (int) (tf->use_gradient != 0), tf->grad_magnitude_modifier, blocks_x, (uint32_t) nblocks);
+	hipLaunchKernelGGL(k_gradient_map, dim3(blocks_x * ((e.height + 3) / 4), e.depth), dim3(256), 0, s, d_vol, d_grad, (int) e.width, (int) e.height,
+	                   (int) e.depth, (int) (tf->use_gradient != 0), tf->grad_magnitude_modifier, blocks_x, 0u);
 	return check_launch(ctx, "gradient_map");
 }
 
@@ -523,18 +517,18 @@ int launch_occupancy_map(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_gr
 	          bz = (int) ((e.depth + me.depth - 1) / me.depth);
 	const int      cells_per_block = 256 / bx > 0 ? 256 / bx : 1;
 	const uint32_t blocks_x        = (me.width + cells_per_block - 1) / cells_per_block;
-	const uint64_t nblocks         = (uint64_t) blocks_x * me.height * me.depth;
-	if (nblocks > 0x7fffffffull)
+	if ((uint64_t) blocks_x * me.height > 0xffffffull || me.depth > 65535u)
 		return set_error(ctx, VKV_E_UNSUPPORTED, "occupancy_map: map too large for one launch");
+	const dim3 grid(blocks_x * me.height, me.depth);
 	const int W = (int) e.width, H = (int) e.height, D = (int) e.depth, mw = (int) me.width, mh = (int) me.height, md = (int) me.depth;
 	if (!tf->use_gradient)
-		hipLaunchKernelGGL(k_occupancy_map<0>, dim3((uint32_t) nblocks), dim3(256), 0, s, d_vol, d_grad, d_bits, d_map, W, H, D, mw, mh, md, bx, by,
+		hipLaunchKernelGGL(k_occupancy_map<0>, grid, dim3(256), 0, s, d_vol, d_grad, d_bits, d_map, W, H, D, mw, mh, md, bx, by,
 		                   bz, tf->grad_magnitude_modifier, blocks_x);
 	else if (d_grad)
-		hipLaunchKernelGGL(k_occupancy_map<1>, dim3((uint32_t) nblocks), dim3(256), 0, s, d_vol, d_grad, d_bits, d_map, W, H, D, mw, mh, md, bx, by,
+		hipLaunchKernelGGL(k_occupancy_map<1>, grid, dim3(256), 0, s, d_vol, d_grad, d_bits, d_map, W, H, D, mw, mh, md, bx, by,
 		                   bz, tf->grad_magnitude_modifier, blocks_x);
 	else
-		hipLaunchKernelGGL(k_occupancy_map<2>, dim3((uint32_t) nblocks), dim3(256), 0, s, d_vol, d_grad, d_bits, d_map, W, H, D, mw, mh, md, bx, by,
+		hipLaunchKernelGGL(k_occupancy_map<2>, grid, dim3(256), 0, s, d_vol, d_grad, d_bits, d_map, W, H, D, mw, mh, md, bx, by,
 		                   bz, tf->grad_magnitude_modifier, blocks_x);
 	return check_launch(ctx, "occupancy_map");
 }
@@ -649,12 +643,12 @@ int launch_distance_map_anisotropic(vkv_ctx *ctx, uint8_t *const m[8], uint8_t *
 int launch_pack_volume(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_grad, VkvExtent3D e, void *d_packed, hipStream_t s)
 {
 	const PackedDims pd = packed_dims((int) e.width, (int) e.height, (int) e.depth);
-	const uint64_t   nb = (uint64_t) pd.bx * pd.by * pd.bz;
-	if (nb > 0xfffffffeull)
+	const uint64_t   nb = (uint64_t) pd.bx * pd.by;        // bricks per z layer
+	if (nb > 0xffffffull || pd.bz > 65535 || (uint64_t) pd.mx * pd.my * pd.mz * 512 > 0xffffffffull)
 		return set_error(ctx, VKV_E_UNSUPPORTED, "pack_volume: volume too large");
 	// macro-brick padding (bricks that exist only because of the 8x8x8 grouping) is never addressed by the sampler
-	hipLaunchKernelGGL(k_pack_volume, dim3((uint32_t) ((nb + 1) / 2)), dim3(256), 0, s, d_vol, d_grad, (uint8_t *) d_packed, (int) e.width, (int) e.height,
-	                   (int) e.depth, pd, (uint32_t) nb);
+	hipLaunchKernelGGL(k_pack_volume, dim3((uint32_t) ((nb + 1) / 2), (uint32_t) pd.bz), dim3(256), 0, s, d_vol, d_grad, (uint8_t *) d_packed, (int) e.width,
+	                   (int) e.height, (int) e.depth, pd, (uint32_t) nb);
 	return check_launch(ctx, "pack_volume");
 }
 
@@ -678,14 +672,13 @@ static float u01(uint64_t *s) { return (float) (splitmix64(s) >> 40) * (1.0f / 1
 int launch_synth_volume(vkv_ctx *ctx, uint8_t *d_vol, VkvExtent3D e, uint32_t kind, uint32_t seed, hipStream_t s)
 {
 	const uint32_t blocks_x = (e.width + 63) / 64;
-	const uint64_t rows     = (uint64_t) e.height * e.depth;
-	const uint64_t nblocks  = blocks_x * ((rows + 3) / 4);
-	if (nblocks > 0x7fffffffull)
+	if (e.depth > 65535u || (uint64_t) blocks_x * ((e.height + 3) / 4) > 0xffffffull)
 		return set_error(ctx, VKV_E_UNSUPPORTED, "synth_volume: volume too large for one launch");
-	const int W = (int) e.width, H = (int) e.height, D = (int) e.depth;
+	const dim3 grid(blocks_x * ((e.height + 3) / 4), e.depth);
+	const int  W = (int) e.width, H = (int) e.height, D = (int) e.depth;
 	if (kind == 0)
 	{
-		hipLaunchKernelGGL(k_synth_sphere, dim3((uint32_t) nblocks), dim3(256), 0, s, d_vol, W, H, D, blocks_x);
+		hipLaunchKernelGGL(k_synth_sphere, grid, dim3(256), 0, s, d_vol, W, H, D, blocks_x);
 		return check_launch(ctx, "synth_volume");
 	}
 	if (kind != 1)
@@ -713,7 +706,7 @@ int launch_synth_volume(vkv_ctx *ctx, uint8_t *d_vol, VkvExtent3D e, uint32_t ki
 		sh.lo2 = lo > 0.0f ? lo * lo : 0.0f;
 		sh.hi2 = hi * hi;
 	}
-	hipLaunchKernelGGL(k_synth_shells, dim3((uint32_t) nblocks), dim3(256), 0, s, d_vol, W, H, D, seed, blocks_x, args);
+	hipLaunchKernelGGL(k_synth_shells, grid, dim3(256), 0, s, d_vol, W, H, D, seed, blocks_x, args);
 	return check_launch(ctx, "synth_volume");
 }
 
