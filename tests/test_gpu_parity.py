@@ -100,7 +100,8 @@ def sparse_occupancy(shape_dhw, seed, p):
 
 
 @pytest.mark.parametrize("shape_dhw,p", [((16, 16, 16), 0.02), ((9, 10, 13), 0.01), ((5, 70, 3), 0.01), ((40, 33, 130), 0.0005),
-                                         ((1, 1, 1), 1.0), ((7, 7, 7), 0.0), ((3, 300, 2), 0.002)])
+                                         ((1, 1, 1), 1.0), ((7, 7, 7), 0.0), ((3, 300, 2), 0.002), ((600, 2, 3), 0.0006), ((2, 700, 1), 0.0015),
+                                         ((300, 290, 70), 0.00001), ((64, 64, 64), 0.3)])
 def test_distance_map_parity(ctx, shape_dhw, p):
     occ = sparse_occupancy(shape_dhw, 3, p)
     d, h, w = shape_dhw
@@ -113,7 +114,7 @@ def test_distance_map_parity(ctx, shape_dhw, p):
 
 
 @pytest.mark.parametrize("shape_dhw,p", [((16, 16, 16), 0.02), ((9, 10, 13), 0.01), ((5, 70, 3), 0.01), ((40, 33, 130), 0.0005),
-                                         ((1, 1, 1), 1.0), ((6, 6, 6), 0.0)])
+                                         ((1, 1, 1), 1.0), ((6, 6, 6), 0.0), ((600, 2, 3), 0.0006), ((2, 700, 1), 0.0015), ((90, 280, 70), 0.00002)])
 def test_distance_map_anisotropic_parity(ctx, shape_dhw, p):
     occ = sparse_occupancy(shape_dhw, 4, p)
     d, h, w = shape_dhw

@@ -3,6 +3,8 @@
 // Replaces ComputeGradientMap / ComputeDistanceMap (src/compute_gradient_map.cpp, src/compute_distance_map.cpp)
 // and their shaders (gradient_map.comp, occupancy_map.comp, distance_map.comp, distance_map_anisotropic.comp).
 // All kernels are integer/byte streaming work bound by HBM / LDS bandwidth; no MFMA.
+#include <cstdlib>
+
 #include "vkv_device.hpp"
 
 using namespace vkv;
@@ -392,6 +394,92 @@ __global__ void __launch_bounds__(256) k_pack_volume(const uint8_t *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// O(N) axis pass.  out(p) = min over the candidates q of max(|q - p|, g(q)) is the lower envelope of "flat-bottomed V"
+// functions.  Sweeping p away from the candidates, a candidate can be dropped for good (a) when a nearer one has a
+// smaller-or-equal g, and (b) when its value is not below that of the next nearer one (its distance term dominates and
+// grows faster).  What survives is a deque with g strictly decreasing towards the far end whose far end is the minimum:
+// every cell is pushed and popped at most once, independent of the data (the reference's zig-zag search, and the first
+// version here, do up to 2 x 255 reads per cell in empty regions).  Candidates further than 255 cells away can never win
+// (results are capped at 255 and the cell itself is always a candidate), so positions are kept modulo 256 and one deque
+// entry is 16 bits: 256 entries x 64 lanes = 32 KiB of LDS per wave, lanes = 64 consecutive x columns (coalesced rows).
+// MODE +1 / -1: one-sided (distance_map_anisotropic.comp:55-91), candidates at higher / lower index.
+// MODE 0: two-sided (distance_map.comp:72-107) = min of the two one-sided sweeps.
+// ---------------------------------------------------------------------------------------------
+struct DmDeque
+{
+	uint16_t *ring;        // [256][64] entries: (logical step & 255) << 8 | g
+	uint32_t  head, tail;  // monotonically increasing; slot = index & 255; count = tail - head <= 256
+	uint32_t  lane;
+
+	__device__ __forceinline__ uint32_t at(uint32_t idx) const { return ring[(idx & 255u) * 64u + lane]; }
+	__device__ __forceinline__ static uint32_t value(uint32_t entry, uint32_t s) { return max((s - (entry >> 8)) & 255u, entry & 255u); }
+
+	// one sweep step at logical step s with input gp; returns out(p)
+	__device__ __forceinline__ uint32_t step(uint32_t s, uint32_t gp)
+	{
+		while (tail != head && (at(tail - 1) & 255u) >= gp)        // (a) dominated by the new, nearer candidate
+			--tail;
+		ring[(tail & 255u) * 64u + lane] = (uint16_t) (((s & 255u) << 8) | gp);
+		++tail;
+		if (tail - head >= 2 && (((s - (at(head) >> 8)) & 255u) == 0u))        // far end is now 256 cells away
+			++head;
+		while (tail - head >= 2 && value(at(head), s) >= value(at(head + 1), s))        // (b)
+			++head;
+		return value(at(head), s);
+	}
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(64) k_dm_sweep(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int mw, int len, size_t axis_stride,
+                                                 size_t other_stride, uint32_t chunks_x)
+{
+	__shared__ uint16_t s_ring[256 * 64];
+	const uint32_t cx = blockIdx.x % chunks_x, other = blockIdx.x / chunks_x;
+	const int      x  = (int) cx * 64 + (int) threadIdx.x;
+	if (x >= mw)
+		return;
+	const size_t base = (size_t) other * other_stride + (size_t) x;
+	DmDeque      dq{s_ring, 0u, 0u, threadIdx.x};
+	constexpr int kAhead = 8;        // rows fetched ahead of the serial deque work
+	if (MODE <= 0)
+	{        // candidates at lower index: ascending sweep
+		for (int s0 = 0; s0 < len; s0 += kAhead)
+		{
+			uint32_t g[kAhead];
+#pragma unroll
+			for (int j = 0; j < kAhead; ++j)
+				g[j] = (s0 + j < len) ? src[base + (size_t) (s0 + j) * axis_stride] : 255u;
+#pragma unroll
+			for (int j = 0; j < kAhead; ++j)
+				if (s0 + j < len)
+					dst[base + (size_t) (s0 + j) * axis_stride] = (uint8_t) dq.step((uint32_t) (s0 + j), g[j]);
+		}
+	}
+	if (MODE >= 0)
+	{        // candidates at higher index: descending sweep; MODE 0 combines with the first sweep's result
+		dq.head = dq.tail = 0u;
+		for (int s0 = 0; s0 < len; s0 += kAhead)
+		{
+			uint32_t g[kAhead], prev[kAhead];
+#pragma unroll
+			for (int j = 0; j < kAhead; ++j)
+			{
+				const int p = len - 1 - (s0 + j);
+				g[j]        = (p >= 0) ? src[base + (size_t) p * axis_stride] : 255u;
+				prev[j]     = (MODE == 0 && p >= 0) ? dst[base + (size_t) p * axis_stride] : 255u;
+			}
+#pragma unroll
+			for (int j = 0; j < kAhead; ++j)
+			{
+				const int p = len - 1 - (s0 + j);
+				if (p >= 0)
+					dst[base + (size_t) p * axis_stride] = (uint8_t) min(dq.step((uint32_t) (s0 + j), g[j]), prev[j]);
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
 // Synthetic volumes (DESIGN.md "Synthetic inputs")
 // ---------------------------------------------------------------------------------------------
 struct SynthShell
@@ -592,10 +680,17 @@ static int launch_dm_axis(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *d
 	const size_t   sy = me.width, sz = (size_t) me.width * me.height;
 	const int      len   = axis == 1 ? (int) me.height : (int) me.depth;
 	const uint32_t other = axis == 1 ? me.depth : me.height;
-	if ((size_t) len * 64 > 64 * 1024)
-		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dm_axis<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, len * 64);
-	hipLaunchKernelGGL(k_dm_axis<MODE>, dim3(chunks_x * other), dim3(256), (size_t) len * 64, s, src, dst, (int) me.width, len, axis == 1 ? sy : sz,
-	                   axis == 1 ? sz : sy, chunks_x);
+	static const bool brute = [] { const char *e = std::getenv("VKV_DM_BRUTE_FORCE"); return e && e[0] == '1'; }();
+	if (brute)
+	{        // first version (data-dependent search out of an LDS strip), kept for A/B and as a cross-check in the tests
+		if ((size_t) len * 64 > 64 * 1024)
+			(void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dm_axis<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, len * 64);
+		hipLaunchKernelGGL(k_dm_axis<MODE>, dim3(chunks_x * other), dim3(256), (size_t) len * 64, s, src, dst, (int) me.width, len, axis == 1 ? sy : sz,
+		                   axis == 1 ? sz : sy, chunks_x);
+	}
+	else
+		hipLaunchKernelGGL(k_dm_sweep<MODE>, dim3(chunks_x * other), dim3(64), 0, s, src, dst, (int) me.width, len, axis == 1 ? sy : sz, axis == 1 ? sz : sy,
+		                   chunks_x);
 	return check_launch(ctx, "distance_map axis pass");
 }
 
