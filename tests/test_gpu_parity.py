@@ -75,7 +75,8 @@ def test_gradient_map_smooth_volume(ctx):
 # occupancy + distance maps
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape,block", [((64, 64, 64), 4), ((61, 45, 30), 4), ((50, 33, 21), 3), ((40, 40, 40), 2),
-                                         ((67, 31, 18), 5), ((48, 48, 48), 6), ((20, 9, 7), 1)])
+                                         ((67, 31, 18), 5), ((48, 48, 48), 6), ((20, 9, 7), 1), ((68, 30, 21), 4), ((132, 17, 9), 2), ((12, 5, 3), 1),
+                                         ((1028, 9, 6), 4)])
 @pytest.mark.parametrize("variant", ["precomputed", "on_the_fly", "no_gradient"])
 def test_occupancy_map_parity(ctx, shape, block, variant):
     vol = T.random_volume(shape, seed=5, sparsity=0.97)

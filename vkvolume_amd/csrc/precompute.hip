@@ -193,6 +193,47 @@ __global__ void __launch_bounds__(256) k_occupancy_map(const uint8_t *__restrict
 		map[vidx(c, cy, cz, mw, mh)] = s_cell[threadIdx.x] ? 0 : 255;        // OCCUPIED = 0, EMPTY = 255
 }
 
+// Dword path of the occupancy pass for the common block sizes whose x extent divides a dword (bx = 1, 2, 4) on dword-aligned
+// rows (W % 4 == 0): one thread owns 4 consecutive voxels in x, i.e. 4 / bx whole cells, and walks the by * bz voxel rows of its
+// cell row with one volume dword (+ one gradient dword) per row — 256 contiguous bytes per wave-load instead of 64 — and no
+// LDS flags or second barrier.  GRAD 0 / 1 only (the on-the-fly gradient variant stays on the byte path).
+template <int GRAD, int BX>
+__global__ void __launch_bounds__(256) k_occupancy_map_dword(const uint8_t *__restrict__ vol, const uint8_t *__restrict__ grad,
+                                                             const uint32_t *__restrict__ tf_bits, uint8_t *__restrict__ map, int W, int H, int D, int mw,
+                                                             int mh, int by, int bz, uint32_t blocks_x)
+{
+	__shared__ uint32_t s_bits[2048];
+	for (int i = threadIdx.x; i < 2048; i += 256)
+		s_bits[i] = tf_bits[i];
+	__syncthreads();
+	const int xd = (int) (blockIdx.x % blocks_x) * 256 + (int) threadIdx.x;        // dword column
+	const int cy = (int) (blockIdx.x / blocks_x), cz = (int) blockIdx.y;
+	if (xd * 4 >= W)
+		return;
+	const int y_end = min((cy + 1) * by, H), z_end = min((cz + 1) * bz, D);
+	uint32_t  occ   = 0;        // bit i: voxel 4*xd + i of some row is occupied
+	for (int z = cz * bz; z < z_end; ++z)
+		for (int y = cy * by; y < y_end; ++y)
+		{
+			const size_t   row = ((size_t) z * H + y) * (size_t) W;
+			const uint32_t v4  = reinterpret_cast<const uint32_t *>(vol + row)[xd];
+			const uint32_t g4  = GRAD == 1 ? reinterpret_cast<const uint32_t *>(grad + row)[xd] : 0xffffffffu;        // gradient 1.0 -> texel 255
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+			{
+				const uint32_t bit = ((g4 >> (8 * i)) & 255u) * 256u + ((v4 >> (8 * i)) & 255u);
+				occ |= ((s_bits[bit >> 5] >> (bit & 31u)) & 1u) << i;
+			}
+		}
+	constexpr int      kCells = 4 / BX;
+	constexpr uint32_t kMask  = (1u << BX) - 1u;
+	uint8_t *          out    = map + ((size_t) cz * mh + cy) * (size_t) mw + (size_t) xd * kCells;
+#pragma unroll
+	for (int c = 0; c < kCells; ++c)
+		if (xd * kCells + c < mw)
+			out[c] = ((occ >> (c * BX)) & kMask) ? 0 : 255;        // OCCUPIED = 0, EMPTY = 255
+}
+
 // ---------------------------------------------------------------------------------------------
 // Occupied-voxel count (shaders/occupied_voxel_count.comp + occupied_voxel_count_reduce.comp)
 // ---------------------------------------------------------------------------------------------
@@ -609,6 +650,24 @@ int launch_occupancy_map(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_gr
 		return set_error(ctx, VKV_E_UNSUPPORTED, "occupancy_map: map too large for one launch");
 	const dim3 grid(blocks_x * me.height, me.depth);
 	const int W = (int) e.width, H = (int) e.height, D = (int) e.depth, mw = (int) me.width, mh = (int) me.height, md = (int) me.depth;
+	const bool precomputed = tf->use_gradient && d_grad;
+	if ((bx == 1 || bx == 2 || bx == 4) && (e.width & 3u) == 0 && (!tf->use_gradient || precomputed) && (((uintptr_t) d_vol | (uintptr_t) d_grad) & 3u) == 0)
+	{
+		const uint32_t dblocks = (e.width / 4 + 255) / 256;
+		const dim3     dgrid(dblocks * me.height, me.depth);
+#define VKV_OCC_DWORD(G, B)                                                                                                                            \
+	hipLaunchKernelGGL((k_occupancy_map_dword<G, B>), dgrid, dim3(256), 0, s, d_vol, d_grad, d_bits, d_map, W, H, D, mw, mh, by, bz, dblocks)
+		if (precomputed)
+		{
+			if (bx == 1) VKV_OCC_DWORD(1, 1); else if (bx == 2) VKV_OCC_DWORD(1, 2); else VKV_OCC_DWORD(1, 4);
+		}
+		else
+		{
+			if (bx == 1) VKV_OCC_DWORD(0, 1); else if (bx == 2) VKV_OCC_DWORD(0, 2); else VKV_OCC_DWORD(0, 4);
+		}
+#undef VKV_OCC_DWORD
+		return check_launch(ctx, "occupancy_map");
+	}
 	if (!tf->use_gradient)
 		hipLaunchKernelGGL(k_occupancy_map<0>, grid, dim3(256), 0, s, d_vol, d_grad, d_bits, d_map, W, H, D, mw, mh, md, bx, by,
 		                   bz, tf->grad_magnitude_modifier, blocks_x);
