@@ -416,11 +416,20 @@ __global__ void __launch_bounds__(256) k_dm_axis(const uint8_t *__restrict__ src
 __global__ void __launch_bounds__(256) k_pack_volume(const uint8_t *__restrict__ vol, const uint8_t *__restrict__ grad, uint8_t *__restrict__ packed,
                                                      int W, int H, int D, PackedDims pd, uint32_t n_bricks)
 {
-	const uint32_t brick = blockIdx.x * 2 + (threadIdx.x >> 7);        // linear over (by, bx) of brick layer bz = blockIdx.y
-	const int      t     = threadIdx.x & 127;
-	if (brick >= n_bricks)
+	// a workgroup packs 2 bricks that are neighbours in x; consecutive workgroups walk a 4 x 4 x 4 group of brick pairs
+	// (8 x 4 x 4 bricks = 32 x 16 x 16 voxels) before moving on, so the overlapping 5^3 neighbourhoods are re-read from L1 / L2
+	// and not from HBM (the first version walked whole brick rows and fetched every byte ~5x)
+	(void) n_bricks;
+	const uint32_t gx = (uint32_t) (pd.bx + 7) / 8, gy = (uint32_t) (pd.by + 3) / 4;        // groups per axis
+	// workgroup ids are dealt round-robin to the 8 XCDs: XCD (id & 7) takes groups id&7, id&7 + 8, ... so a group stays in one L2;
+	// grid.y = group layer in z (keeps grid.x * 256 below 2^32 for 2048^3)
+	const uint32_t grp = ((blockIdx.x >> 3) >> 6) * 8u + (blockIdx.x & 7u), in = (blockIdx.x >> 3) & 63u;
+	const int      bx = (int) ((grp % gx) * 8 + (in & 3u) * 2 + (threadIdx.x >> 7));
+	const int      by = (int) ((grp / gx) * 4 + ((in >> 2) & 3u));
+	const int      bz = (int) (blockIdx.y * 4 + (in >> 4));
+	const int      t  = threadIdx.x & 127;
+	if (bx >= pd.bx || by >= pd.by || bz >= pd.bz || grp >= gx * gy)
 		return;
-	const int bx = (int) (brick % (uint32_t) pd.bx), by = (int) (brick / (uint32_t) pd.bx), bz = (int) blockIdx.y;
 	uint16_t *dst = reinterpret_cast<uint16_t *>(packed + packed_brick_offset(bx, by, bz, pd.mx, pd.my));
 	if (t >= 125)
 	{
@@ -801,8 +810,11 @@ int launch_pack_volume(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_grad
 	if (nb > 0xffffffull || pd.bz > 65535 || (uint64_t) pd.mx * pd.my * pd.mz * 512 > 0xffffffffull)
 		return set_error(ctx, VKV_E_UNSUPPORTED, "pack_volume: volume too large");
 	// macro-brick padding (bricks that exist only because of the 8x8x8 grouping) is never addressed by the sampler
-	hipLaunchKernelGGL(k_pack_volume, dim3((uint32_t) ((nb + 1) / 2), (uint32_t) pd.bz), dim3(256), 0, s, d_vol, d_grad, (uint8_t *) d_packed, (int) e.width,
-	                   (int) e.height, (int) e.depth, pd, (uint32_t) nb);
+	const uint64_t groups = (uint64_t) ((pd.bx + 7) / 8) * ((pd.by + 3) / 4);        // per layer of 4 bricks in z
+	if ((groups + 8) * 64 * 256 > 0xffffffffull || (pd.bz + 3) / 4 > 65535)
+		return set_error(ctx, VKV_E_UNSUPPORTED, "pack_volume: volume too large");
+	hipLaunchKernelGGL(k_pack_volume, dim3((uint32_t) (((groups + 7) / 8) * 8 * 64), (uint32_t) ((pd.bz + 3) / 4)), dim3(256), 0, s, d_vol, d_grad, (uint8_t *) d_packed, (int) e.width, (int) e.height,
+	                   (int) e.depth, pd, (uint32_t) nb);
 	return check_launch(ctx, "pack_volume");
 }
 
