@@ -238,6 +238,19 @@ typedef struct VkvVolumeHeader
 int vkv_load_header(const char *filename_header, VkvVolumeHeader *out);
 int vkv_load_data(const char *filename_data, const VkvVolumeHeader *header, uint8_t *out_voxels, size_t out_bytes);
 
+/* Device half of LoadVolume::load_data_impl (src/load_volume.cpp:151-169) for volumes whose raw file has been uploaded as
+ * is: endianness conversion and normalisation to uint8, `(uint8) (255 * max(0, min(1, (v - min) / (max - min))))`, truncating.
+ * d_raw holds n_voxels elements of `type`. */
+enum VkvVoxelType
+{
+	VKV_VOXEL_UINT8  = 0,
+	VKV_VOXEL_INT8   = 1,
+	VKV_VOXEL_UINT16 = 2,
+	VKV_VOXEL_INT16  = 3
+};
+int vkv_convert_volume(vkv_ctx *ctx, const void *d_raw, int32_t type, int32_t big_endian, float range_min, float range_max, uint64_t n_voxels,
+                       uint8_t *d_out, void *stream);
+
 /* Device-internal sampling layout of the volume (the counterpart of uploading into a VK_IMAGE_TILING_OPTIMAL image,
  * src/volume_component.cpp:68-83): 4x4x4-voxel bricks with a one-voxel apron, volume and gradient bytes interleaved,
  * clamp-to-edge baked in, bricks grouped 8x8x8.  Every trilinear footprint of both textures then lies inside one

@@ -99,6 +99,13 @@ def check_maps_and_frames(ctx, v, tf, size, label):
         assert float((diff > 2).float().mean()) < 2e-3, label + ": ESS mode %d changes more than bleed" % mode
 
 
+def test_c2_512_cubed_block_ess(ctx):
+    """BASELINE.json configs[1]: 512^3, 1920x1080, occupancy-grid (block) ESS only."""
+    v, tf = build(ctx, (512, 512, 512), 0xC0FFEE02, abi.SKIP_BLOCK)
+    assert v.map_extent.as_tuple() == (128, 128, 128)
+    check_maps_and_frames(ctx, v, tf, (1920, 1080), "C2")
+
+
 def test_c3_full_size_properties(ctx):
     """BASELINE.json configs[2]: 1024x1024x795, 1920x1080."""
     v, tf = build(ctx, (1024, 1024, 795), 0xC0FFEE03, abi.SKIP_DISTANCE, (0.0003, 0.0003, 0.0007), (1.0, 0.0, 0.0, 90.0))

@@ -36,6 +36,28 @@ def test_occupied_voxel_count_parity(ctx, opts, use_map, shape):
     assert int(d_count.item()) == O.occupied_voxel_count(vol, grad, tf)
 
 
+@pytest.mark.parametrize("ctype,npt", [("uint8_t", "u1"), ("int8_t", "i1"), ("uint16_t", "u2"), ("int16_t", "i2")])
+@pytest.mark.parametrize("endian", ["little", "big"])
+@pytest.mark.parametrize("n_shape", [(33, 21, 17), (64, 16, 4), (1, 1, 1)])
+def test_device_loader_conversion_matches_oracle_loader(ctx, tmp_path, ctype, npt, endian, n_shape):
+    """vkv_convert_volume (the loader's normalisation on the device) against the oracle's CPU loader on the same raw file."""
+    rng = np.random.default_rng(5)
+    info = np.iinfo(npt)
+    w, h, d = n_shape
+    raw = rng.integers(info.min, info.max + 1, size=(d, h, w)).astype(npt)
+    f = tmp_path / "v.raw"
+    file_bytes = raw.astype(("<" if endian == "little" else ">") + npt)
+    file_bytes.tofile(f)
+    lo, hi = (-20.0, 100.0) if npt[1] == "1" else (-400.0, 25380.0)
+    (tmp_path / "v.raw.header").write_text("%d %d %d\n1 1 1\n%g %g\n%s %s\n1 0 0 0\n" % (w, h, d, lo, hi, ctype, endian))
+    expect = O.load_data(str(f), O.load_header(str(f) + ".header"))
+    d_raw = torch.from_numpy(np.frombuffer(file_bytes.tobytes(), np.uint8).copy()).cuda()
+    d_out = torch.full((d, h, w), 7, dtype=torch.uint8, device="cuda")
+    ctx.convert_volume(d_raw.data_ptr(), abi.VOXEL_TYPES[ctype], endian == "big", lo, hi, w * h * d, d_out.data_ptr(),
+                       torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(d_out.cpu().numpy(), expect)
+
+
 def run_offscreen(tmp_path, *flags):
     assert os.path.exists(EXE), "vkv_offscreen not built (run __graft_entry__.build())"
     out = subprocess.run([EXE, *flags], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)

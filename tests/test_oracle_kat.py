@@ -238,3 +238,26 @@ def test_occupied_voxel_count_formula(opts, use_map):
         expect = int(((ai * ag) > 0).sum())
     assert O.occupied_voxel_count(vol, grad, tf) == expect
     assert 0 < expect < vol.size
+
+
+def test_c1_sphere_256_plumbing():
+    """BASELINE.json configs[0]: 64^3 synthetic sphere, 256x256 offscreen, no ESS — the CPU scalar ray-marcher end to end
+    (load -> gradient -> TF -> render), with closed-form checks: the image is symmetric under the sphere's symmetry about
+    the view axis (left-right mirror for a camera in the x = 0 plane) and opaque in the middle, empty in the corners."""
+    vol = O.synth_volume((64, 64, 64), 0, 1)
+    assert vol[32, 32, 32] == 255 and vol[0, 0, 0] == 0 and np.array_equal(vol, vol[::-1, ::-1, ::-1])
+    scene = T.OracleScene(vol, abi.VolumeOptions(**T.APP_TF), 4)
+    size = (256, 256)
+    view, proj = T.orbit(0.0, elevation=0.0, radius=150.0, image_size=size)
+    cam = O.build_uniforms(view, proj, scene.node_transform, scene.image_transform, 1.0, size, scene.extent, scene.map_extent)
+    p = scene.params(view, proj, size, abi.RenderOptions(skipping_type=abi.SKIP_NONE, clip_distance=1.0), uniforms=cam)
+    r = scene.render(p)
+    assert r.rays == 256 * 256
+    a = r.color[..., 3]
+    assert a[128, 128] == 1.0 and a[0, 0] == 0.0 and a[255, 255] == 0.0  # ERT clamps alpha to exactly 1 in the centre
+    assert 0.1 < (a > 0).mean() < 0.6
+    # mirror symmetry of the silhouette; the alpha values themselves differ a little because the 4-tap tetrahedron gradient
+    # (get_gradient_compute.glsl:12-18) is not mirror-symmetric
+    assert np.abs(a - a[:, ::-1]).max() < 0.1 and np.abs(a - a[::-1, :]).max() < 0.1
+    assert ((a > 0) != (a[:, ::-1] > 0)).mean() < 2e-3
+    assert (r.counts[..., 1] == 0).all() and r.counts[..., 0].max() <= 111  # n_steps_max = ceil(64 * sqrt(3)) (SURVEY.md §8a a1)

@@ -13,6 +13,7 @@ TF_BITS_WORDS = 2052  # VKV_TF_BITS_WORDS
 
 # VolumeRenderSubpass::SkippingType / Test (src/volume_render_subpass.h:58-72)
 SKIP_NONE, SKIP_BLOCK, SKIP_DISTANCE, SKIP_ANISOTROPIC_DISTANCE = 0, 1, 2, 3
+VOXEL_TYPES = {"uint8_t": 0, "int8_t": 1, "uint16_t": 2, "int16_t": 3}  # VkvVoxelType by LoadVolume::Header::type
 TEST_NONE, TEST_RAY_ENTRY, TEST_RAY_EXIT, TEST_NUM_TEXTURE_SAMPLES = 0, 1, 2, 3
 
 

@@ -26,6 +26,7 @@ int launch_scatter_tiles(vkv_ctx *, const void *, void *, uint32_t, uint32_t, ui
 int launch_render(vkv_ctx *, const VkvRenderParams *, const float *, hipStream_t);
 int launch_pack_volume(vkv_ctx *, const uint8_t *, const uint8_t *, VkvExtent3D, void *, hipStream_t);
 int launch_tf_bits(vkv_ctx *, const uint8_t *, uint32_t *, hipStream_t);
+int launch_convert_volume(vkv_ctx *, const void *, int, bool, float, float, uint64_t, uint8_t *, hipStream_t);
 int launch_occupied_voxel_count(vkv_ctx *, const uint8_t *, const uint8_t *, const VkvTransferFunctionUniform *, VkvExtent3D, uint64_t *, hipStream_t);
 
 int set_error(vkv_ctx *ctx, int code, const char *fmt, ...)
@@ -356,6 +357,18 @@ int vkv_load_data(const char *filename_data, const VkvVolumeHeader *header, uint
 	{
 		return VKV_E_IO;
 	}
+}
+
+int vkv_convert_volume(vkv_ctx *ctx, const void *d_raw, int32_t type, int32_t big_endian, float range_min, float range_max, uint64_t n_voxels,
+                       uint8_t *d_out, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (!d_raw || !d_out)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "convert_volume: null pointer");
+	if ((type == VKV_VOXEL_UINT16 || type == VKV_VOXEL_INT16) && (((uintptr_t) d_raw) & 1u))
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "convert_volume: 16-bit input must be 2-byte aligned");
+	return launch_convert_volume(ctx, d_raw, type, big_endian != 0, range_min, range_max, n_voxels, d_out, (hipStream_t) stream);
 }
 
 size_t vkv_packed_volume_bytes(VkvExtent3D e)

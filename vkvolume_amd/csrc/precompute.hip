@@ -601,6 +601,46 @@ __global__ void __launch_bounds__(256) k_synth_shells(uint8_t *__restrict__ vol,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Loader conversion on the device (src/load_volume.cpp:151-169): 16 input bytes per thread
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ uint8_t normalise_voxel(T raw, bool swap, float lo, float hi)
+{
+	if (sizeof(T) == 2 && swap)
+		raw = (T) (uint16_t) ((((uint16_t) raw) >> 8) | (((uint16_t) raw) << 8));
+	const float x = ((float) raw - lo) / (hi - lo);
+	const float a = (x < 1.0f) ? x : 1.0f;          // std::min(1.0f, x)
+	const float t = (0.0f < a) ? a : 0.0f;          // std::max(0.0f, .)
+	return (uint8_t) (255 * t);                      // truncation (load_volume.cpp:169)
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_convert_volume(const T *__restrict__ raw, uint8_t *__restrict__ out, unsigned long long n, bool swap, float lo, float hi)
+{
+	constexpr int kPer = 16 / (int) sizeof(T);        // elements per 16-byte load
+	const unsigned long long first = ((unsigned long long) blockIdx.x * 256 + threadIdx.x) * kPer;
+	if (first >= n)
+		return;
+	if (first + kPer <= n && (((uintptr_t) raw) & 15u) == 0 && (((uintptr_t) out) & (kPer - 1)) == 0)
+	{
+		const uint4 q = *reinterpret_cast<const uint4 *>(raw + first);
+		T           e[kPer];
+		__builtin_memcpy(e, &q, 16);
+		uint8_t o[kPer];
+#pragma unroll
+		for (int i = 0; i < kPer; ++i)
+			o[i] = normalise_voxel<T>(e[i], swap, lo, hi);
+		if (kPer == 16)
+			*reinterpret_cast<uint4 *>(out + first) = *reinterpret_cast<const uint4 *>(o);
+		else
+			*reinterpret_cast<uint2 *>(out + first) = *reinterpret_cast<const uint2 *>(o);
+	}
+	else
+		for (unsigned long long i = first; i < n && i < first + kPer; ++i)
+			out[i] = normalise_voxel<T>(raw[i], swap, lo, hi);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Multi-GPU: de-interleave gathered compact tile buffers into the final image (one thread per pixel)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -874,6 +914,29 @@ int launch_synth_volume(vkv_ctx *ctx, uint8_t *d_vol, VkvExtent3D e, uint32_t ki
 	}
 	hipLaunchKernelGGL(k_synth_shells, grid, dim3(256), 0, s, d_vol, W, H, D, seed, blocks_x, args);
 	return check_launch(ctx, "synth_volume");
+}
+
+int launch_convert_volume(vkv_ctx *ctx, const void *d_raw, int type, bool big_endian, float lo, float hi, uint64_t n, uint8_t *d_out, hipStream_t s)
+{
+	const uint16_t probe          = 1;
+	const bool     host_is_little = *reinterpret_cast<const uint8_t *>(&probe) == 1;        // the device shares the host's byte order
+	const bool     swap           = big_endian == host_is_little;
+	const int      per            = (type == VKV_VOXEL_UINT16 || type == VKV_VOXEL_INT16) ? 8 : 16;
+	const uint64_t blocks         = (n + (uint64_t) per * 256 - 1) / ((uint64_t) per * 256);
+	if (blocks == 0)
+		return VKV_OK;
+	if (blocks > 0xffffffull)
+		return set_error(ctx, VKV_E_UNSUPPORTED, "convert_volume: volume too large for one launch");
+	const unsigned long long nn = n;
+	switch (type)
+	{
+		case VKV_VOXEL_UINT8: hipLaunchKernelGGL(k_convert_volume<uint8_t>, dim3((uint32_t) blocks), dim3(256), 0, s, (const uint8_t *) d_raw, d_out, nn, swap, lo, hi); break;
+		case VKV_VOXEL_INT8: hipLaunchKernelGGL(k_convert_volume<int8_t>, dim3((uint32_t) blocks), dim3(256), 0, s, (const int8_t *) d_raw, d_out, nn, swap, lo, hi); break;
+		case VKV_VOXEL_UINT16: hipLaunchKernelGGL(k_convert_volume<uint16_t>, dim3((uint32_t) blocks), dim3(256), 0, s, (const uint16_t *) d_raw, d_out, nn, swap, lo, hi); break;
+		case VKV_VOXEL_INT16: hipLaunchKernelGGL(k_convert_volume<int16_t>, dim3((uint32_t) blocks), dim3(256), 0, s, (const int16_t *) d_raw, d_out, nn, swap, lo, hi); break;
+		default: return set_error(ctx, VKV_E_INVALID_ARGUMENT, "convert_volume: unsupported image data type %d", type);
+	}
+	return check_launch(ctx, "convert_volume");
 }
 
 int launch_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, uint32_t iw, uint32_t ih, uint32_t tw, uint32_t th, uint32_t n_ranks,

@@ -75,6 +75,33 @@ std::vector<uint8_t> LoadVolume::load_data(std::string filename_data, const Head
 	throw std::runtime_error("unsupported image data type");
 }
 
+int LoadVolume::voxel_type(const Header &header)
+{
+	if (header.type == "uint8_t") return VKV_VOXEL_UINT8;
+	if (header.type == "int8_t") return VKV_VOXEL_INT8;
+	if (header.type == "uint16_t") return VKV_VOXEL_UINT16;
+	if (header.type == "int16_t") return VKV_VOXEL_INT16;
+	throw std::runtime_error("unsupported image data type");
+}
+
+std::vector<uint8_t> LoadVolume::load_raw(std::string filename_data, const Header &header)
+{
+	const int    type      = voxel_type(header);
+	const size_t n_voxels  = (size_t) header.extent.width * (size_t) header.extent.height * (size_t) header.extent.depth;
+	const size_t file_size = n_voxels * ((type == VKV_VOXEL_UINT16 || type == VKV_VOXEL_INT16) ? 2 : 1);
+	std::ifstream file(filename_data, std::ios::binary | std::ios::ate);
+	if (!file.is_open())
+		throw std::runtime_error("Failed to open data file");
+	if ((size_t) file.tellg() != file_size)
+		throw std::runtime_error("File size does not match expected size for the given image format/dimensions");
+	file.seekg(0, std::ios::beg);
+	std::vector<uint8_t> raw(file_size);
+	file.read(reinterpret_cast<char *>(raw.data()), (std::streamsize) file_size);
+	if (!file)
+		throw std::runtime_error("File error");
+	return raw;
+}
+
 template <typename T>
 std::vector<uint8_t> LoadVolume::load_data_impl(std::string filename_data, const Header &header)
 {

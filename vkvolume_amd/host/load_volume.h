@@ -32,6 +32,11 @@ class LoadVolume
 	// (src/load_volume.cpp:112-172).  Throws std::runtime_error with the reference's messages.
 	static std::vector<uint8_t> load_data(std::string filename_data, const Header &header);
 
+	// The raw file bytes, size-checked against the header (same errors as load_data); normalisation is then done on the device
+	// by vkv_convert_volume (Volume::load_from_file).  Not in the reference: its loader converts on the CPU.
+	static std::vector<uint8_t> load_raw(std::string filename_data, const Header &header);
+	static int                  voxel_type(const Header &header);        // VkvVoxelType, or throws "unsupported image data type"
+
   private:
 	template <typename T>
 	static std::vector<uint8_t> load_data_impl(std::string filename_data, const Header &header);

@@ -75,10 +75,28 @@ void Volume::allocate(DeviceContext &dc, VkvExtent3D extent, uint32_t block)
 
 bool Volume::load_from_file(DeviceContext &dc, std::string filename, uint32_t distance_map_block_size)
 {
-	auto                 header = LoadVolume::load_header(filename + ".header");
-	std::vector<uint8_t> data   = LoadVolume::load_data(filename, header);
+	auto header = LoadVolume::load_header(filename + ".header");
 	set_image_transform(header.image_transform);
-	return load_from_memory(dc, data.data(), header.extent, distance_map_block_size);
+	// the raw file goes to the device as it is; endianness + normalisation to uint8 run there (vkv_convert_volume), at HBM speed
+	const int            type = LoadVolume::voxel_type(header);
+	std::vector<uint8_t> raw  = LoadVolume::load_raw(filename, header);
+	allocate(dc, header.extent, distance_map_block_size);
+	uint8_t *d_raw = device_alloc(raw.size());
+	try
+	{
+		hip_check(hipMemcpyAsync(d_raw, raw.data(), raw.size(), hipMemcpyHostToDevice, (hipStream_t) dc.stream), "raw volume upload");
+		vkv_check(dc, vkv_convert_volume(dc.ctx, d_raw, type, header.endianness == "big", header.normalisation_range[0], header.normalisation_range[1],
+		                                 (uint64_t) header.extent.width * header.extent.height * header.extent.depth, volume.data, dc.stream),
+		          "volume conversion");
+		hip_check(hipStreamSynchronize((hipStream_t) dc.stream), "volume upload");
+	}
+	catch (...)
+	{
+		(void) hipFree(d_raw);
+		throw;
+	}
+	(void) hipFree(d_raw);
+	return true;
 }
 
 bool Volume::load_from_memory(DeviceContext &dc, const uint8_t *voxels, VkvExtent3D extent, uint32_t distance_map_block_size)

@@ -17,7 +17,7 @@ EXPORTS = [
     "vkv_gradient_map", "vkv_occupancy_map", "vkv_distance_map", "vkv_distance_map_anisotropic",
     "vkv_compute_distance_map", "vkv_render", "vkv_scatter_tiles", "vkv_synth_volume",
     "vkv_packed_volume_bytes", "vkv_pack_volume", "vkv_transfer_function_bits",
-    "vkv_occupied_voxel_count", "vkv_load_header", "vkv_load_data",
+    "vkv_occupied_voxel_count", "vkv_load_header", "vkv_load_data", "vkv_convert_volume",
 ]
 
 
@@ -68,6 +68,7 @@ def load():
     L.vkv_pack_volume.argtypes = [vp, vp, vp, abi.Extent3D, vp, vp]
     L.vkv_transfer_function_bits.argtypes = [vp, vp, vp, vp]
     L.vkv_occupied_voxel_count.argtypes = [vp, vp, vp, P(abi.TransferFunctionUniform), abi.Extent3D, vp, vp]
+    L.vkv_convert_volume.argtypes = [vp, vp, i32, i32, C.c_float, C.c_float, C.c_uint64, vp, vp]
     L.vkv_load_header.argtypes = [C.c_char_p, P(abi.VolumeHeader)]
     L.vkv_load_data.argtypes = [C.c_char_p, P(abi.VolumeHeader), vp, C.c_size_t]
     for name in EXPORTS:
@@ -148,6 +149,9 @@ class Context:
 
     def occupied_voxel_count(self, d_volume, d_gradient, tf, extent, d_count, stream=0):
         self.check(self._lib.vkv_occupied_voxel_count(self.handle, d_volume, d_gradient, C.byref(tf), extent, d_count, stream))
+
+    def convert_volume(self, d_raw, voxel_type, big_endian, range_min, range_max, n_voxels, d_out, stream=0):
+        self.check(self._lib.vkv_convert_volume(self.handle, d_raw, voxel_type, 1 if big_endian else 0, range_min, range_max, n_voxels, d_out, stream))
 
     def last_error(self):
         return self._lib.vkv_last_error(self.handle).decode(errors="replace")
