@@ -29,7 +29,7 @@ extern "C" {
 
 #define VKV_OK 0
 #define VKV_E_INVALID_ARGUMENT (-1) /* null pointer, zero extent, bad enum              */
-#define VKV_E_UNSUPPORTED (-2)      /* e.g. depth_attachment input, map axis > 2048      */
+#define VKV_E_UNSUPPORTED (-2)      /* e.g. map axis > 2048, volume too large for a launch */
 #define VKV_E_NO_DEVICE (-3)        /* no HIP device / wrong architecture               */
 #define VKV_E_IO (-4)               /* file errors of the loader                        */
 
@@ -121,7 +121,7 @@ typedef struct VkvRenderOptions
 	int32_t skipping_type;         /* VKV_SKIP_DISTANCE */
 	float   clip_distance;         /* 50.0 */
 	int32_t early_ray_termination; /* true */
-	int32_t depth_attachment;      /* false; true is VKV_E_UNSUPPORTED */
+	int32_t depth_attachment;      /* false; true = DEPTH_ATTACHMENT variant: needs VkvRenderParams.d_in_depth */
 	int32_t test;                  /* VKV_TEST_NONE */
 } VkvRenderOptions;
 
@@ -162,6 +162,12 @@ typedef struct VkvRenderParams
 	uint8_t *                  d_out_rgba8;                /* RGBA8 round-to-nearest of the above, or NULL */
 	uint32_t *                 d_out_counts;               /* 3 x u32 per pixel: volume samples, distance probes, empty samples; or NULL */
 	float *                    d_out_depth;                /* gl_FragDepth (reverse-Z, 0 = far), or NULL */
+	const float *              d_in_depth;                 /* options.depth_attachment: the scene depth the subpass reads as input attachment 0
+	                                                          (frag:26, 122-165; reverse-Z), indexed like the outputs */
+	uint32_t                   blend_over_target;          /* != 0: d_out_color / d_out_rgba8 hold the destination colour and the fragment is blended
+	                                                          onto it with the subpass's blend state (volume_render_subpass.cpp:176-190):
+	                                                          rgb = src + (1 - src.a) * dst, a = src.a * (1 - src.a); pixels without a fragment stay
+	                                                          untouched.  0: every pixel of the schedule is overwritten (cleared to 0 first). */
 } VkvRenderParams;
 
 typedef struct vkv_ctx vkv_ctx;

@@ -430,6 +430,7 @@ typedef struct
 	float    rgba[4];
 	uint32_t counts[3]; /* volume samples, distance probes, empty samples */
 	float    depth;
+	int      fragment; /* 0: the pixel has no fragment (not covered by the clipped box, or discarded by the depth test) */
 } PixelOut;
 
 /* One pixel: analytic ray setup (DESIGN.md "Ray generation", replaces the two vertex shaders and the
@@ -445,7 +446,7 @@ static inline void trace_event(uint8_t c)
 	++g_trace_len;
 }
 
-static void march_pixel(const VkvRenderParams *P, const float *alpha_lut, int px, int py, PixelOut *out)
+static void march_pixel(const VkvRenderParams *P, const float *alpha_lut, int px, int py, const float *in_depth, PixelOut *out)
 {
 	memset(out, 0, sizeof(*out)); /* out_color = vec4(0) (frag:120); gl_FragDepth = 0 (frag:140) */
 
@@ -497,6 +498,27 @@ static void march_pixel(const VkvRenderParams *P, const float *alpha_lut, int px
 	ray_entry.x = fmaf(t0, d.x, o[0]);
 	ray_entry.y = fmaf(t0, d.y, o[1]);
 	ray_entry.z = fmaf(t0, d.z, o[2]);
+	out->fragment = 1;
+
+	/* ---- DEPTH_ATTACHMENT, frag:122-136: manual z-test of the front face against the scene depth (reverse-Z) ---- */
+	float frag_depth = 0.0f, frag_depth_front = 0.0f, position[4] = {0, 0, 0, 0};
+	if (P->options.depth_attachment)
+	{
+		/* position = proj * view * model * vec4(ray_entry - 0.5, 1) (the vertex shaders' position_out, clipped.vert:62) */
+		const float pm[4] = {ray_entry.x - 0.5f, ray_entry.y - 0.5f, ray_entry.z - 0.5f, 1.0f};
+		float       a4[4], b4[4];
+		mat4_mul_vec4(P->camera.model, pm, a4);
+		mat4_mul_vec4(P->camera.camera_view, a4, b4);
+		mat4_mul_vec4(P->camera.camera_proj, b4, position);
+		frag_depth       = *in_depth;
+		frag_depth_front = position[2] / position[3];
+		if (frag_depth > frag_depth_front)
+		{ /* discard: the front face is behind the scene */
+			out->fragment = 0;
+			return;
+		}
+		out->depth = frag_depth; /* gl_FragDepth = frag_depth (frag:135) */
+	}
 
 	/* ---- frag:147-149 ---- */
 	v3 ray_dir;
@@ -518,6 +540,23 @@ static void march_pixel(const VkvRenderParams *P, const float *alpha_lut, int px
 		ray_exit.z = fmaf(tFar, ray_dir.z, ray_entry.z);
 		const float ex = ray_entry.x - ray_exit.x, ey = ray_entry.y - ray_exit.y, ez = ray_entry.z - ray_exit.z;
 		ray_distance = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+	}
+	if (P->options.depth_attachment)
+	{ /* frag:152-164: stop the ray where it meets the depth buffer */
+		const float clip[4] = {(position[0] * frag_depth) / frag_depth_front, (position[1] * frag_depth) / frag_depth_front,
+		                       (position[2] * frag_depth) / frag_depth_front, position[3]};
+		float       w4[4], m4[4];
+		mat4_mul_vec4(P->camera.camera_view_proj_inv, clip, w4);
+		w4[0] /= w4[3], w4[1] /= w4[3], w4[2] /= w4[3], w4[3] /= w4[3];
+		mat4_mul_vec4(P->camera.model_inv, w4, m4);
+		const float ix = m4[0] + 0.5f, iy = m4[1] + 0.5f, iz = m4[2] + 0.5f;
+		const float ex = ray_entry.x - ix, ey = ray_entry.y - iy, ez = ray_entry.z - iz;
+		const float dd = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+		if (dd < ray_distance)
+		{
+			ray_exit.x = ix, ray_exit.y = iy, ray_exit.z = iz;
+			ray_distance = dd;
+		}
 	}
 
 	/* ---- tests, frag:168-173 ---- */
@@ -719,7 +758,8 @@ uint32_t vkvo_trace_ray(const VkvRenderParams *P, int px, int py, uint8_t *event
 	build_alpha_lut(&P->transfer_function, lut);
 	PixelOut po;
 	g_trace = events, g_trace_cap = cap, g_trace_len = 0;
-	march_pixel(P, lut, px, py, &po);
+	float far_depth = 0.0f;
+	march_pixel(P, lut, px, py, P->d_in_depth ? P->d_in_depth + ((size_t) py * P->image_width + px) : &far_depth, &po);
 	g_trace = NULL;
 	return g_trace_len;
 }
@@ -769,10 +809,45 @@ static void *render_worker(void *arg)
 				const uint32_t x = x0 + lx;
 				if (x >= P->image_width || (x % job->stride) != 0)
 					continue;
-				PixelOut po;
-				march_pixel(P, job->lut, (int) x, (int) y, &po);
-				++rays;
+				PixelOut     po;
 				const size_t o = P->tiles.compact ? ((size_t) k * th + ly) * tw + lx : (size_t) y * P->image_width + x;
+				const float  far_depth = 0.0f;
+				march_pixel(P, job->lut, (int) x, (int) y, P->d_in_depth ? P->d_in_depth + o : &far_depth, &po);
+				++rays;
+				if (!po.fragment)
+				{ /* no fragment: an existing target stays as it is, a fresh one holds the clear values */
+					if (P->blend_over_target)
+					{
+						if (P->d_out_counts)
+							memcpy(P->d_out_counts + o * 3, po.counts, sizeof(po.counts));
+						continue;
+					}
+					if (P->options.depth_attachment && P->d_in_depth)
+						po.depth = P->d_in_depth[o];
+				}
+				else if (P->blend_over_target)
+				{ /* blend state of the subpass (src/volume_render_subpass.cpp:176-190) */
+					const float om = 1.0f - po.rgba[3];
+					if (P->d_out_color)
+					{
+						float *dst = P->d_out_color + o * 4;
+						for (int c = 0; c < 3; ++c)
+							dst[c] = fmaf(om, dst[c], po.rgba[c]);
+						dst[3] = po.rgba[3] * om;
+					}
+					if (P->d_out_rgba8)
+					{
+						uint8_t *dst = P->d_out_rgba8 + o * 4;
+						for (int c = 0; c < 3; ++c)
+							dst[c] = quantise_rgba8(fmaf(om, unorm8(dst[c]), po.rgba[c]));
+						dst[3] = quantise_rgba8(po.rgba[3] * om);
+					}
+					if (P->d_out_counts)
+						memcpy(P->d_out_counts + o * 3, po.counts, sizeof(po.counts));
+					if (P->d_out_depth)
+						P->d_out_depth[o] = po.depth;
+					continue;
+				}
 				if (P->d_out_color)
 					memcpy(P->d_out_color + o * 4, po.rgba, sizeof(po.rgba));
 				if (P->d_out_rgba8)

@@ -164,9 +164,11 @@ class RenderResult:
         self.color, self.counts, self.depth, self.rgba8, self.rays = color, counts, depth, rgba8, rays
 
 
-def render(params, vol, grad, tf_tex, maps, n_threads=None, pixel_stride=1, want_rgba8=False):
+def render(params, vol, grad, tf_tex, maps, n_threads=None, pixel_stride=1, want_rgba8=False, in_depth=None, target_color=None,
+           target_rgba8=None):
     """Run the oracle ray-marcher. ``params`` is an ``abi.RenderParams`` whose pointer fields are overwritten with
-    host arrays; outputs are image-shaped (or compact, following ``params.tiles``)."""
+    host arrays; outputs are image-shaped (or compact, following ``params.tiles``).  ``in_depth`` feeds the DEPTH_ATTACHMENT
+    variant; ``target_color`` / ``target_rgba8`` are existing frames to blend onto (sets ``blend_over_target``)."""
     p = abi.RenderParams.from_buffer_copy(params)
     vol = np.ascontiguousarray(vol, np.uint8)
     tf_tex = np.ascontiguousarray(tf_tex, np.uint8)
@@ -190,10 +192,20 @@ def render(params, vol, grad, tf_tex, maps, n_threads=None, pixel_stride=1, want
         shape = (npix,)
     else:
         shape = (p.image_height, p.image_width)
-    color = np.zeros(shape + (4,), np.float32)
+    blend = target_color is not None or target_rgba8 is not None
+    color = np.zeros(shape + (4,), np.float32) if target_color is None else np.ascontiguousarray(target_color, np.float32).copy()
     counts = np.zeros(shape + (3,), np.uint32)
     depth = np.zeros(shape, np.float32)
-    rgba8 = np.zeros(shape + (4,), np.uint8) if want_rgba8 else None
+    want_rgba8 = want_rgba8 or target_rgba8 is not None
+    rgba8 = None
+    if want_rgba8:
+        rgba8 = np.zeros(shape + (4,), np.uint8) if target_rgba8 is None else np.ascontiguousarray(target_rgba8, np.uint8).copy()
+    p.blend_over_target = 1 if blend else 0
+    p.d_in_depth = None
+    if in_depth is not None:
+        in_depth = np.ascontiguousarray(in_depth, np.float32)
+        keep.append(in_depth)
+        p.d_in_depth = in_depth.ctypes.data
     p.d_out_color, p.d_out_counts, p.d_out_depth = color.ctypes.data, counts.ctypes.data, depth.ctypes.data
     p.d_out_rgba8 = rgba8.ctypes.data if want_rgba8 else None
     if n_threads is None:

@@ -12,6 +12,6 @@ int main(void)
 	O(VkvRenderParams, use_precomputed_gradient); O(VkvRenderParams, image_width); O(VkvRenderParams, tiles);
 	O(VkvRenderParams, volume_extent); O(VkvRenderParams, map_extent); O(VkvRenderParams, d_volume); O(VkvRenderParams, d_gradient);
 	O(VkvRenderParams, d_transfer_function); O(VkvRenderParams, d_distance_maps); O(VkvRenderParams, d_packed_volume); O(VkvRenderParams, d_transfer_function_bits); O(VkvRenderParams, d_out_color);
-	O(VkvRenderParams, d_out_rgba8); O(VkvRenderParams, d_out_counts); O(VkvRenderParams, d_out_depth);
+	O(VkvRenderParams, d_out_rgba8); O(VkvRenderParams, d_out_counts); O(VkvRenderParams, d_out_depth); O(VkvRenderParams, d_in_depth); O(VkvRenderParams, blend_over_target);
 	return 0;
 }

@@ -319,7 +319,7 @@ def test_render_error_paths(ctx, shell_scene):
     assert ctx.render_rc(p) == 0
     bad = abi.RenderParams.from_buffer_copy(p)
     bad.options.depth_attachment = 1
-    assert ctx.render_rc(bad) == abi.VKV_E_UNSUPPORTED and "depth_attachment" in ctx.last_error()
+    assert ctx.render_rc(bad) == abi.VKV_E_INVALID_ARGUMENT and "depth_attachment" in ctx.last_error()  # needs d_in_depth
     bad = abi.RenderParams.from_buffer_copy(p)
     bad.d_volume = None
     assert ctx.render_rc(bad) == abi.VKV_E_INVALID_ARGUMENT
@@ -336,3 +336,62 @@ def test_render_error_paths(ctx, shell_scene):
         ctx.distance_map(out.data_ptr(), out.data_ptr(), abi.Extent3D(4, 4, 4))  # aliased buffers
     with pytest.raises(lib.VkvError):
         ctx.distance_map(out.data_ptr(), out.data_ptr() + 64, abi.Extent3D(4096, 4, 4))  # axis > 2048
+
+
+# ------------------------------------------------------------------------------------------------------
+# depth attachment + compositing (frag:122-165, blend state volume_render_subpass.cpp:176-190)
+# ------------------------------------------------------------------------------------------------------
+def scene_depth_plane(params, size, cut):
+    """A synthetic scene depth buffer (reverse-Z): a wall in front of part of the volume.  Depth of a point at view distance
+    d with near n (far >> n) is ~ n / d; left third: nothing (0 = far), middle: a wall through the volume, right: a wall in
+    front of the whole volume (every fragment there is discarded)."""
+    w, h = size
+    depth = np.zeros((h, w), np.float32)
+    depth[:, w // 3: 2 * w // 3] = cut
+    depth[:, 2 * w // 3:] = 0.5
+    return depth
+
+
+@pytest.mark.parametrize("skipping_type", [abi.SKIP_NONE, abi.SKIP_DISTANCE])
+@pytest.mark.parametrize("blend", [False, True])
+def test_render_depth_attachment_and_blending(ctx, shell_scene, skipping_type, blend):
+    scene, v, tf, cdm = shell_scene
+    cdm.compute(v, tf, skipping_type)
+    size = (144, 80)
+    view, proj = T.orbit(25.0, image_size=size)
+    opts = abi.RenderOptions(skipping_type=skipping_type, clip_distance=1.0, depth_attachment=True)
+    params = scene.params(view, proj, size, opts)
+    # reverse-Z depth of the volume centre is near / distance = 0.1 / 150
+    in_depth = scene_depth_plane(params, size, 0.1 / 150.0)
+    rng = np.random.default_rng(2)
+    tgt_color = rng.random((size[1], size[0], 4), dtype=np.float32) if blend else None
+    tgt_rgba8 = rng.integers(0, 256, (size[1], size[0], 4), dtype=np.uint8) if blend else None
+    ref = scene.render(params, in_depth=in_depth, target_color=tgt_color, target_rgba8=tgt_rgba8, want_rgba8=True)
+    plain = scene.render(scene.params(view, proj, size, abi.RenderOptions(skipping_type=skipping_type, clip_distance=1.0)))
+    third = size[0] // 3
+    # left third: scene depth = far, nothing is clipped -> same sample counters as without the depth attachment
+    assert np.array_equal(ref.counts[:, :third], plain.counts[:, :third])
+    # middle: rays stop at the wall -> fewer or equal samples, strictly fewer in total; right: every fragment discarded
+    # (only in aggregate: the reference reconstructs the depth-buffer point with x and y scaled by the depth ratio (frag:153), so
+    # it is not on the pixel's own ray and single rays can even get a few more steps)
+    assert ref.counts[:, third:2 * third, 0].sum() < 0.7 * plain.counts[:, third:2 * third, 0].sum()
+    assert ref.counts[:, 2 * third:].sum() == 0
+    if blend:
+        assert np.array_equal(ref.color[:, 2 * third:], tgt_color[:, 2 * third:])  # untouched where there is no fragment
+        assert np.array_equal(ref.rgba8[:, 2 * third:], tgt_rgba8[:, 2 * third:])
+    sp = V.VolumeRenderSubpass(ctx, v, opts, size)
+    p = sp.bind(params)
+    color = torch.from_numpy(tgt_color).cuda() if blend else torch.full((size[1], size[0], 4), -1.0, dtype=torch.float32, device="cuda")
+    rgba8 = torch.from_numpy(tgt_rgba8).cuda() if blend else torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda")
+    counts = torch.full((size[1], size[0], 3), 77, dtype=torch.int32, device="cuda")
+    depth = torch.full((size[1], size[0]), -1.0, dtype=torch.float32, device="cuda")
+    sp.draw(p, color, rgba8, counts, depth, in_depth=dev(in_depth), blend=blend)
+    torch.cuda.synchronize()
+    assert np.array_equal(counts.cpu().numpy().astype(np.uint32), ref.counts)
+    assert np.abs(color.cpu().numpy() - ref.color).max() <= COLOR_TOL
+    assert np.array_equal(rgba8.cpu().numpy(), ref.rgba8)
+    got_depth = depth.cpu().numpy()
+    frag = got_depth != -1.0
+    assert np.abs(got_depth[frag] - ref.depth[frag]).max() <= DEPTH_TOL
+    if not blend:
+        assert frag.all() and np.array_equal(got_depth[:, 2 * third:], in_depth[:, 2 * third:])  # pass-through where discarded

@@ -96,7 +96,8 @@ class RenderParams(C.Structure):
                 ("d_volume", C.c_void_p), ("d_gradient", C.c_void_p), ("d_transfer_function", C.c_void_p),
                 ("d_distance_maps", C.c_void_p * 8), ("d_packed_volume", C.c_void_p),
                 ("d_transfer_function_bits", C.c_void_p), ("d_out_color", C.c_void_p), ("d_out_rgba8", C.c_void_p),
-                ("d_out_counts", C.c_void_p), ("d_out_depth", C.c_void_p)]
+                ("d_out_counts", C.c_void_p), ("d_out_depth", C.c_void_p), ("d_in_depth", C.c_void_p),
+                ("blend_over_target", C.c_uint32)]
 
 
 class VolumeHeader(C.Structure):

@@ -405,8 +405,8 @@ int vkv_render(vkv_ctx *ctx, const VkvRenderParams *P, void *stream)
 	if (!P)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: null params");
 	const VkvRenderOptions &o = P->options;
-	if (o.depth_attachment)
-		return set_error(ctx, VKV_E_UNSUPPORTED, "render: depth_attachment input is not implemented (SURVEY.md 8f row 4)");
+	if (o.depth_attachment && !P->d_in_depth)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: options.depth_attachment needs d_in_depth");
 	if (o.test < VKV_TEST_NONE || o.test > VKV_TEST_NUM_TEXTURE_SAMPLES)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: bad test mode %d", o.test);
 	if (o.skipping_type < VKV_SKIP_NONE || o.skipping_type > VKV_SKIP_ANISOTROPIC_DISTANCE)

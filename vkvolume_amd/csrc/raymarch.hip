@@ -26,6 +26,7 @@ struct RayMarchArgs
 	float block_size[3];
 	// CameraUniform matrices needed for gl_FragDepth (frag:319)
 	float model[16], view[16], proj[16];
+	float view_proj_inv[16], model_inv[16];        // DEPTH_ATTACHMENT only (frag:154-156)
 	// TransferFunctionUniform
 	float sampling_factor, grad_modifier;
 	// extents
@@ -39,6 +40,8 @@ struct RayMarchArgs
 	uint8_t *       out_rgba8;
 	uint32_t *      out_counts;
 	float *         out_depth;
+	const float *   in_depth;           // scene depth (options.depth_attachment) or null
+	uint32_t        depth_attachment, blend;
 	uint32_t        img_w, img_h, tile_w, tile_h, tiles_x, tile_first, tile_stride, tile_count, compact;
 	uint32_t        blocks_per_tile_x, blocks_per_tile, nblocks;
 	int             test;
@@ -62,6 +65,7 @@ struct Ray
 	float          depth;
 	uint32_t       n_vol, n_dist, n_empty;
 	uint32_t       o;                  // output index of the pixel
+	bool           fragment;           // false: no fragment for this pixel (not covered, or discarded by the depth test)
 };
 
 // Linear filter, clamp-to-edge (sampler: src/volume_component.cpp:139-148); see DESIGN.md "Pinned numerics".
@@ -165,6 +169,7 @@ __device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, ui
 	R.depth = 0.0f;                      // gl_FragDepth = 0 (frag:140)
 	R.n_vol = R.n_dist = R.n_empty = 0;
 	R.n_steps = 0, R.i = 0, R.i_min = 0, R.first_hit = 0;
+	R.fragment = false;
 	const int W = A.W, H = A.H, D = A.D;
 
 	// ---- ray generation (replaces volume_render_clipped.vert + volume_render_plane_intersection.vert) ----------
@@ -209,6 +214,26 @@ __device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, ui
 	if (!(t0 < t_far))
 		return false;
 	const float ex = __builtin_fmaf(t0, dx, ox), ey = __builtin_fmaf(t0, dy, oy), ez = __builtin_fmaf(t0, dz, oz);        // ray_entry
+	R.fragment = true;
+
+	// ---- DEPTH_ATTACHMENT, frag:122-136: manual z-test of the front face against the scene depth (reverse-Z) ----
+	float frag_depth = 0.0f, frag_depth_front = 0.0f, position[4] = {0, 0, 0, 0};
+	if (A.depth_attachment)
+	{
+		const float pm[4] = {ex - 0.5f, ey - 0.5f, ez - 0.5f, 1.0f};        // position = proj * view * model * (ray_entry - 0.5) (clipped.vert:62)
+		float       a4[4], b4[4];
+		mat4_mul_vec4(A.model, pm, a4);
+		mat4_mul_vec4(A.view, a4, b4);
+		mat4_mul_vec4(A.proj, b4, position);
+		frag_depth       = A.in_depth[R.o];
+		frag_depth_front = position[2] / position[3];
+		if (frag_depth > frag_depth_front)
+		{        // discard
+			R.fragment = false;
+			return false;
+		}
+		R.depth = frag_depth;        // gl_FragDepth = frag_depth (frag:135)
+	}
 
 	// ---- frag:147-149 --------------------------------------------------------------------------------------
 	float rdx, rdy, rdz;
@@ -227,6 +252,23 @@ __device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, ui
 		xx = __builtin_fmaf(tFar, rdx, ex), xy = __builtin_fmaf(tFar, rdy, ey), xz = __builtin_fmaf(tFar, rdz, ez);
 		const float vx = ex - xx, vy = ey - xy, vz = ez - xz;
 		ray_distance = __builtin_sqrtf(__builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx)));
+	}
+	if (A.depth_attachment)
+	{        // frag:152-164: stop the ray where it meets the depth buffer
+		const float clip[4] = {(position[0] * frag_depth) / frag_depth_front, (position[1] * frag_depth) / frag_depth_front,
+		                       (position[2] * frag_depth) / frag_depth_front, position[3]};
+		float       w4[4], m4[4];
+		mat4_mul_vec4(A.view_proj_inv, clip, w4);
+		w4[0] /= w4[3], w4[1] /= w4[3], w4[2] /= w4[3], w4[3] /= w4[3];
+		mat4_mul_vec4(A.model_inv, w4, m4);
+		const float ix = m4[0] + 0.5f, iy = m4[1] + 0.5f, iz = m4[2] + 0.5f;
+		const float vx = ex - ix, vy = ey - iy, vz = ez - iz;
+		const float dd = __builtin_sqrtf(__builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx)));
+		if (dd < ray_distance)
+		{
+			xx = ix, xy = iy, xz = iz;
+			ray_distance = dd;
+		}
 	}
 	if (A.test == VKV_TEST_RAY_ENTRY)
 	{
@@ -492,6 +534,44 @@ __device__ __forceinline__ void ray_finish(const RayMarchArgs &A, Ray &R, bool m
 		}
 	}
 	const size_t o = R.o;
+	if (!R.fragment)
+	{        // no fragment: an existing target stays as it is, a fresh one holds the clear values
+		if (A.blend)
+		{
+			if (A.out_counts)
+				A.out_counts[o * 3 + 0] = A.out_counts[o * 3 + 1] = A.out_counts[o * 3 + 2] = 0;
+			return;
+		}
+		if (A.depth_attachment)
+			R.depth = A.in_depth[o];
+	}
+	else if (A.blend)
+	{        // blend state of the subpass (src/volume_render_subpass.cpp:176-190): rgb = src + (1 - src.a) * dst, a = src.a * (1 - src.a)
+		const float om = 1.0f - R.a;
+		if (A.out_color)
+		{
+			float4 d = reinterpret_cast<float4 *>(A.out_color)[o];
+			d.x = __builtin_fmaf(om, d.x, R.r), d.y = __builtin_fmaf(om, d.y, R.g), d.z = __builtin_fmaf(om, d.z, R.b), d.w = R.a * om;
+			reinterpret_cast<float4 *>(A.out_color)[o] = d;
+		}
+		if (A.out_rgba8)
+		{
+			const uint32_t d = reinterpret_cast<uint32_t *>(A.out_rgba8)[o];
+			const float    r = __builtin_fmaf(om, unorm8(d & 255u), R.r), g = __builtin_fmaf(om, unorm8((d >> 8) & 255u), R.g),
+			            b = __builtin_fmaf(om, unorm8((d >> 16) & 255u), R.b);
+			reinterpret_cast<uint32_t *>(A.out_rgba8)[o] = (uint32_t) quantise_rgba8(r) | ((uint32_t) quantise_rgba8(g) << 8) |
+			                                               ((uint32_t) quantise_rgba8(b) << 16) | ((uint32_t) quantise_rgba8(R.a * om) << 24);
+		}
+		if (A.out_counts)
+		{
+			A.out_counts[o * 3 + 0] = R.n_vol;
+			A.out_counts[o * 3 + 1] = R.n_dist;
+			A.out_counts[o * 3 + 2] = R.n_empty;
+		}
+		if (A.out_depth)
+			A.out_depth[o] = R.depth;
+		return;
+	}
 	if (A.out_color)
 		reinterpret_cast<float4 *>(A.out_color)[o] = make_float4(R.r, R.g, R.b, R.a);
 	if (A.out_rgba8)
@@ -741,7 +821,8 @@ int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut
 	for (int i = 0; i < 4; ++i)
 		a.plane_tex[i] = P->ray_cast.plane_tex[i];
 	for (int i = 0; i < 16; ++i)
-		a.model[i] = P->camera.model[i], a.view[i] = P->camera.camera_view[i], a.proj[i] = P->camera.camera_proj[i];
+		a.model[i] = P->camera.model[i], a.view[i] = P->camera.camera_view[i], a.proj[i] = P->camera.camera_proj[i],
+		a.view_proj_inv[i] = P->camera.camera_view_proj_inv[i], a.model_inv[i] = P->camera.model_inv[i];
 	a.sampling_factor = P->transfer_function.sampling_factor;
 	a.grad_modifier   = P->transfer_function.grad_magnitude_modifier;
 	a.W = (int) P->volume_extent.width, a.H = (int) P->volume_extent.height, a.D = (int) P->volume_extent.depth;
@@ -756,6 +837,8 @@ int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut
 	for (int i = 0; i < 8; ++i)
 		a.maps[i] = P->d_distance_maps[i];
 	a.out_color = P->d_out_color, a.out_rgba8 = P->d_out_rgba8, a.out_counts = P->d_out_counts, a.out_depth = P->d_out_depth;
+	a.in_depth         = P->d_in_depth;
+	a.depth_attachment = P->options.depth_attachment != 0, a.blend = P->blend_over_target != 0;
 	a.img_w = P->image_width, a.img_h = P->image_height;
 	a.tile_w = P->tiles.tile_width, a.tile_h = P->tiles.tile_height;
 	a.tiles_x    = (a.img_w + a.tile_w - 1) / a.tile_w;

@@ -9,7 +9,7 @@ VolumeRenderSubpass::VolumeRenderSubpass(DeviceContext &device_context, std::vec
 
 void VolumeRenderSubpass::prepare() {}
 
-VkvRenderParams VolumeRenderSubpass::make_params(Volume &volume, const RenderTarget &target, const VkvTileSchedule *tiles) const
+VkvRenderParams VolumeRenderSubpass::make_params(Volume &volume, const RenderTarget &target, const VkvTileSchedule *tiles, bool blend) const
 {
 	VkvRenderParams p;
 	std::memset(&p, 0, sizeof(p));
@@ -42,16 +42,20 @@ VkvRenderParams VolumeRenderSubpass::make_params(Volume &volume, const RenderTar
 	p.d_packed_volume          = volume.get_packed_volume();
 	p.d_transfer_function_bits = volume.get_transfer_function_bits();
 	p.d_out_color = target.color, p.d_out_rgba8 = target.rgba8, p.d_out_counts = target.counts, p.d_out_depth = target.depth;
+	p.d_in_depth        = target.in_depth;
+	p.blend_over_target = blend ? 1u : 0u;
 	return p;
 }
 
 void VolumeRenderSubpass::draw(const RenderTarget &target, const VkvTileSchedule *tiles)
 {
+	bool blend = target.blend;
 	for (Volume *volume : volumes)
 	{
 		if (!volume->get_packed_volume())
 			volume->pack(dc);        // no gradient pass ran (gradient_test / no-gradient TF)
-		const VkvRenderParams p = make_params(*volume, target, tiles);
+		const VkvRenderParams p = make_params(*volume, target, tiles, blend);
+		blend                   = true;        // every further volume is blended onto the result (volume_render_subpass.cpp:176-181, :219)
 		if (vkv_render(dc.ctx, &p, dc.stream) != VKV_OK)
 			throw std::runtime_error(std::string("VolumeRenderSubpass::draw: ") + vkv_last_error(dc.ctx));
 	}

@@ -24,6 +24,9 @@ struct RenderTarget
 	uint8_t * rgba8  = nullptr;        // RGBA8
 	uint32_t *counts = nullptr;        // 3 x u32 per pixel
 	float *   depth  = nullptr;
+	const float *in_depth = nullptr;        // scene depth for Options::depth_attachment (input attachment 0 of the reference subpass)
+	bool         blend    = false;          // true: blend onto the existing contents of color / rgba8 (the subpass's blend state);
+	                                        // false: the first volume overwrites the (cleared) target, further volumes blend onto it
 };
 
 class VolumeRenderSubpass
@@ -64,7 +67,7 @@ class VolumeRenderSubpass
 	void draw(const RenderTarget &target, const VkvTileSchedule *tiles = nullptr);
 
 	// the parameter block of one volume (what draw() binds), exposed for tests / the multi-GPU driver
-	VkvRenderParams make_params(Volume &volume, const RenderTarget &target, const VkvTileSchedule *tiles) const;
+	VkvRenderParams make_params(Volume &volume, const RenderTarget &target, const VkvTileSchedule *tiles, bool blend = false) const;
 
   private:
 	DeviceContext &       dc;

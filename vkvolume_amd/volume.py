@@ -163,9 +163,12 @@ class VolumeRenderSubpass:
         p.d_transfer_function_bits = _ptr(v.transfer_function_bits) if v.use_packed else None
         return p
 
-    def draw(self, params, color=None, rgba8=None, counts=None, depth=None):
+    def draw(self, params, color=None, rgba8=None, counts=None, depth=None, in_depth=None, blend=False):
+        """``in_depth``: scene depth for options.depth_attachment; ``blend``: blend onto the contents of color / rgba8
+        (the subpass's blend state) instead of overwriting them."""
         params.d_out_color, params.d_out_rgba8 = _ptr(color), _ptr(rgba8)
         params.d_out_counts, params.d_out_depth = _ptr(counts), _ptr(depth)
+        params.d_in_depth, params.blend_over_target = _ptr(in_depth), 1 if blend else 0
         self.ctx.render(params, _stream())
 
 
