@@ -319,8 +319,7 @@ __device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, ui
 // Returns true when the ray has ended (ran past n_steps, or early ray termination).
 // ---------------------------------------------------------------------------------------------------------------
 template <int SKIP, bool ERT, int GRAD, bool PACKED>
-__device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const float *s_alpha, const float *s_unorm, const uint32_t *s_bits, bool tf_bits,
-                                          uint32_t colmin)
+__device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const float *s_alpha, const float *s_unorm, const uint32_t *s_bits, bool tf_bits)
 {
 	const int   W = A.W, H = A.H, D = A.D;
 	const int   i  = R.i;
@@ -366,58 +365,45 @@ __device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const f
 			dist = dist_h;
 		else
 			dist = R.dmap[((uint32_t) uiz * (uint32_t) A.mh + (uint32_t) uiy) * (uint32_t) A.mw + (uint32_t) uix];
-		if (dist > 0u)
-		{
-			// r = clamp(u_i - u, -1, 0) (frag:234); the operand is never NaN, so the median-of-three instruction gives the
-			// same value as min(max(x, -1), 0)
-			const float rx = __builtin_amdgcn_fmed3f((float) uix - ux, -1.0f, 0.0f);
-			const float ry = __builtin_amdgcn_fmed3f((float) uiy - uy, -1.0f, 0.0f);
-			const float rz = __builtin_amdgcn_fmed3f((float) uiz - uz, -1.0f, 0.0f);
-			float       ax, ay, az;
-			if (SKIP == VKV_SKIP_BLOCK)
-			{        // frag:239: step(0, s) is 1 for s >= 0 (and for the impossible NaN), 0 for s < 0
-				ax = (((R.six < 0.0f) ? 0.0f : 1.0f) + rx) * R.six;
-				ay = (((R.siy < 0.0f) ? 0.0f : 1.0f) + ry) * R.siy;
-				az = (((R.siz < 0.0f) ? 0.0f : 1.0f) + rz) * R.siz;
-			}
-			else
-			{        // frag:242: step(0, -s) + sign(s) * dist is exactly dist for s > 0 and 1 - dist for s < 0 (s is never 0 or NaN:
-				 // it is the reciprocal of a finite number)
-				const float fd = (float) dist;
-				ax = (((R.six > 0.0f) ? fd : 1.0f - fd) + rx) * R.six;
-				ay = (((R.siy > 0.0f) ? fd : 1.0f - fd) + ry) * R.siy;
-				az = (((R.siz > 0.0f) ? fd : 1.0f - fd) + rz) * R.siz;
-			}
-			if (ax != ax) ax = INFINITY;
-			if (ay != ay) ay = INFINITY;
-			if (az != az) az = INFINITY;
-			float m = g_min(g_min(ax, ay), az);
-			m       = (m < 1073741824.0f) ? m : 1073741824.0f;
-			R.i     = i + max(1, (int) __builtin_ceilf(m));
+		// Both outcomes of the probe are computed and selected (no nested branch: the two groups of lanes would serialise):
+		// dist > 0 skips forward (frag:236-247), dist == 0 marks the cell occupied and steps back (frag:248-262).
+		// r = clamp(u_i - u, -1, 0) (frag:234); the operand is never NaN, so the median-of-three instruction gives the same
+		// value as min(max(x, -1), 0)
+		const float rx = __builtin_amdgcn_fmed3f((float) uix - ux, -1.0f, 0.0f);
+		const float ry = __builtin_amdgcn_fmed3f((float) uiy - uy, -1.0f, 0.0f);
+		const float rz = __builtin_amdgcn_fmed3f((float) uiz - uz, -1.0f, 0.0f);
+		float       ax, ay, az;
+		if (SKIP == VKV_SKIP_BLOCK)
+		{        // frag:239: step(0, s) is 1 for s >= 0 (and for the impossible NaN), 0 for s < 0
+			ax = (((R.six < 0.0f) ? 0.0f : 1.0f) + rx) * R.six;
+			ay = (((R.siy < 0.0f) ? 0.0f : 1.0f) + ry) * R.siy;
+			az = (((R.siz < 0.0f) ? 0.0f : 1.0f) + rz) * R.siz;
 		}
 		else
-		{
-			R.occupied = true;
-			R.ulx = uix, R.uly = uiy, R.ulz = uiz;
-			R.i = max(i - (int) __builtin_ceilf(A.sampling_factor), R.i_min);
+		{        // frag:242: step(0, -s) + sign(s) * dist is exactly dist for s > 0 and 1 - dist for s < 0 (s is never 0 or NaN:
+			 // it is the reciprocal of a finite number)
+			const float fd = (float) dist;
+			ax = (((R.six > 0.0f) ? fd : 1.0f - fd) + rx) * R.six;
+			ay = (((R.siy > 0.0f) ? fd : 1.0f - fd) + ry) * R.siy;
+			az = (((R.siz > 0.0f) ? fd : 1.0f - fd) + rz) * R.siz;
 		}
+		if (ax != ax) ax = INFINITY;
+		if (ay != ay) ay = INFINITY;
+		if (az != az) az = INFINITY;
+		float m = g_min(g_min(ax, ay), az);
+		m       = (m < 1073741824.0f) ? m : 1073741824.0f;
+		const int  i_skip = i + max(1, (int) __builtin_ceilf(m));
+		const int  i_back = max(i - (int) __builtin_ceilf(A.sampling_factor), R.i_min);
+		const bool empty  = dist > 0u;
+		R.i               = empty ? i_skip : i_back;
+		R.occupied        = !empty;
+		R.ulx = empty ? R.ulx : uix, R.uly = empty ? R.uly : uiy, R.ulz = empty ? R.ulz : uiz;
 		return R.i >= R.n_steps;
 	}
 
 	// frag:266-310
 	++R.n_vol;
-	// Quick reject (kHoist variants): the filtered intensity is a convex combination of the eight corner bytes, so it cannot
-	// exceed the largest of them; if even that byte's texel column of the TF holds no occupied texel (colmin), alpha is 0
-	// for any gradient and neither filter, the texel index nor the table look-up is needed.  Same result, fewer instructions.
 	uint32_t texel = 0;
-	bool     quick = false;
-	if (kHoist)
-	{
-		const uint32_t a0 = max(q00 & 255u, (q00 >> 16) & 255u), a1 = max(q10 & 255u, (q10 >> 16) & 255u);
-		const uint32_t a2 = max(q01 & 255u, (q01 >> 16) & 255u), a3 = max(q11 & 255u, (q11 >> 16) & 255u);
-		quick             = max(max(a0, a1), max(a2, a3)) < colmin;
-	}
-	if (!quick)
 	{
 	float intensity, gradient = 1.0f;
 	if (kHoist)
@@ -476,7 +462,7 @@ __device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const f
 	}
 	else
 		texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
-	}        // !quick
+	}
 	const uint32_t ab = texel >> 24;
 	R.occupied        = ab > 0;
 	bool ended        = false;
@@ -620,7 +606,6 @@ __global__ void __launch_bounds__(256) k_raymarch_tiles(const RayMarchArgs A)
 	__shared__ uint32_t s_bits[2048];
 	stage_tables(A, s_alpha, s_unorm, s_bits);
 	const bool     tf_bits = A.tf_bits != nullptr;
-	const uint32_t colmin  = tf_bits ? A.tf_bits[2048] : 0u;        // wave-uniform (scalar load)
 	// Hardware deals workgroup ids round-robin over the 8 XCDs (own L2 each).  XCD x = id & 7 marches the schedule's
 	// tiles k = x, x + 8, x + 16, ... one after the other: neighbouring workgroups of an XCD share a tile (L2 locality)
 	// while the tiles of the frame are spread evenly over the XCDs (ESS makes screen regions differ >10x in cost; a
@@ -641,7 +626,7 @@ __global__ void __launch_bounds__(256) k_raymarch_tiles(const RayMarchArgs A)
 	{
 		// The frame time is the critical path of the wave with the longest ray: once a wave has run 48 events it is one of
 		// those, so let it win instruction arbitration against the younger waves on its SIMD.
-		while (!ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_unorm, s_bits, tf_bits, colmin))
+		while (!ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_unorm, s_bits, tf_bits))
 			if (__builtin_amdgcn_readfirstlane(++iter) == 48u)        // provably wave-uniform: a real scalar branch
 				__builtin_amdgcn_s_setprio(3);
 	}
@@ -699,7 +684,6 @@ __global__ void __launch_bounds__(256) k_raymarch_persistent(const RayMarchArgs 
 	__shared__ uint32_t s_bits[2048];
 	stage_tables(A, s_alpha, s_unorm, s_bits);
 	const bool     tf_bits = A.tf_bits != nullptr;
-	const uint32_t colmin  = tf_bits ? A.tf_bits[2048] : 0u;
 	// blocks b and b + 8 share an XCD under the observed round-robin placement (speed only, never correctness)
 	uint32_t q      = blockIdx.x & 7u;
 	uint32_t unit   = pop_unit(A, q);
@@ -742,7 +726,7 @@ __global__ void __launch_bounds__(256) k_raymarch_persistent(const RayMarchArgs 
 		// ---- one event per active lane ----
 		if (active)
 		{
-			if (ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_unorm, s_bits, tf_bits, colmin))
+			if (ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_unorm, s_bits, tf_bits))
 			{
 				ray_finish(A, R, true);
 				active = false;
