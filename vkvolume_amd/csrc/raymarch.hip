@@ -588,10 +588,13 @@ __device__ __forceinline__ bool unit_pixel(const RayMarchArgs &A, uint32_t u, ui
 
 __device__ __forceinline__ void stage_tables(const RayMarchArgs &A, float *s_alpha, float *s_unorm, uint32_t *s_bits)
 {
-	s_alpha[threadIdx.x] = A.alpha_lut[threadIdx.x];
-	s_unorm[threadIdx.x] = unorm8(threadIdx.x);        // exact IEEE division, once per workgroup
+	for (int i = threadIdx.x; i < 256; i += blockDim.x)
+	{
+		s_alpha[i] = A.alpha_lut[i];
+		s_unorm[i] = unorm8(i);        // exact IEEE division, once per workgroup
+	}
 	if (A.tf_bits)
-		for (int i = threadIdx.x; i < 2048; i += 256)
+		for (int i = threadIdx.x; i < 2048; i += blockDim.x)
 			s_bits[i] = A.tf_bits[i];
 	__syncthreads();
 }
@@ -599,8 +602,10 @@ __device__ __forceinline__ void stage_tables(const RayMarchArgs &A, float *s_alp
 // ---------------------------------------------------------------------------------------------------------------
 // Static scheduler: workgroup = 16x16 pixels, wave = 8x8 pixels.
 // ---------------------------------------------------------------------------------------------------------------
-template <int SKIP, bool ERT, int GRAD, bool PACKED>
-__global__ void __launch_bounds__(256) k_raymarch_tiles(const RayMarchArgs A)
+// WPB = waves per workgroup: 4 (one workgroup = one 16x16 pixel block) or 2 (half a block: wave slots and LDS are handed back
+// at a finer grain while the long rays of the other half are still running).
+template <int SKIP, bool ERT, int GRAD, bool PACKED, int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_raymarch_tiles(const RayMarchArgs A)
 {
 	__shared__ float    s_alpha[256], s_unorm[256];
 	__shared__ uint32_t s_bits[2048];
@@ -610,12 +615,14 @@ __global__ void __launch_bounds__(256) k_raymarch_tiles(const RayMarchArgs A)
 	// tiles k = x, x + 8, x + 16, ... one after the other: neighbouring workgroups of an XCD share a tile (L2 locality)
 	// while the tiles of the frame are spread evenly over the XCDs (ESS makes screen regions differ >10x in cost; a
 	// contiguous band per XCD left most of the chip idle behind the XCD that owned the centre of the image).
+	constexpr uint32_t kParts = 4 / WPB;        // workgroups per 16x16 block
 	const uint32_t x = blockIdx.x & 7u, idx = blockIdx.x >> 3;
-	const uint32_t k = (idx / A.blocks_per_tile) * 8u + x, sb = idx % A.blocks_per_tile;
+	const uint32_t k = (idx / (A.blocks_per_tile * kParts)) * 8u + x, sbp = idx % (A.blocks_per_tile * kParts);
+	const uint32_t sb = sbp / kParts, part = sbp % kParts;
 	if (k >= A.tile_count)
 		return;
 	uint32_t px, py, o;
-	if (!unit_pixel(A, (k * A.blocks_per_tile + sb) * 4 + (threadIdx.x >> 6), threadIdx.x & 63, px, py, o))
+	if (!unit_pixel(A, (k * A.blocks_per_tile + sb) * 4 + part * WPB + (threadIdx.x >> 6), threadIdx.x & 63, px, py, o))
 		return;
 	Ray R;
 	R.o = o;
@@ -639,7 +646,7 @@ __global__ void __launch_bounds__(256) k_raymarch_tiles(const RayMarchArgs A)
 		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
 		if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)))
 		{
-			unsigned long long *rec = A.trace + ((size_t) blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+			unsigned long long *rec = A.trace + ((size_t) blockIdx.x * WPB + (threadIdx.x >> 6)) * 4;
 			rec[0] = t_start, rec[1] = t_end, rec[2] = it, rec[3] = ((unsigned long long) __builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (k * A.blocks_per_tile + sb);
 		}
 	}
@@ -770,7 +777,11 @@ static int launch_one(vkv_ctx *ctx, int sched, const RayMarchArgs &a, hipStream_
 	{
 		// ids are dealt round-robin to the XCDs, each XCD walking its own tiles: pad the tile count to a multiple of 8
 		const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile;
-		hipLaunchKernelGGL((k_raymarch_tiles<SKIP, ERT, GRAD, PACKED>), dim3(grid), dim3(256), 0, s, a);
+		static const bool half = [] { const char *e = std::getenv("VKV_RAYMARCH_WPB"); return e && e[0] == '2'; }();
+		if (half)
+			hipLaunchKernelGGL((k_raymarch_tiles<SKIP, ERT, GRAD, PACKED, 2>), dim3(grid * 2), dim3(128), 0, s, a);
+		else
+			hipLaunchKernelGGL((k_raymarch_tiles<SKIP, ERT, GRAD, PACKED, 4>), dim3(grid), dim3(256), 0, s, a);
 	}
 	return check_launch(ctx, "render");
 }

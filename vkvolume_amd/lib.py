@@ -8,7 +8,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvkvolume_amd.so")
+LIB_PATH = os.environ.get("VKV_LIB_PATH") or os.path.join(_HERE, "csrc", "libvkvolume_amd.so")  # override: kernel experiments only
 
 # every symbol include/vkvolume_amd.h declares
 EXPORTS = [
