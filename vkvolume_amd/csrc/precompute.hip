@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) k_tf_bits_analytic(uint32_t *__restrict__
 
 // GRAD as in k_occupancy_map.  Each thread walks voxels with a grid stride of whole x rows; a wave counts with
 // ballot + popcount, a workgroup adds once to the 64-bit total.
-template <int GRAD>
+template <int GRAD, bool DWORDS>
 __global__ void __launch_bounds__(256) k_occupied_voxel_count(const uint8_t *__restrict__ vol, const uint8_t *__restrict__ grad,
                                                               const uint32_t *__restrict__ tf_bits, unsigned long long *__restrict__ total, int W, int H,
                                                               int D, float modifier, float imin, float iinv, float gmin, float ginv, uint32_t blocks_x,
@@ -273,9 +273,35 @@ __global__ void __launch_bounds__(256) k_occupied_voxel_count(const uint8_t *__r
 		s_bits[i] = tf_bits[i];
 	__syncthreads();
 	const uint32_t bx   = blockIdx.x % blocks_x;
-	const int      x    = (int) (bx * 64 + (threadIdx.x & 63));
 	const uint32_t rows = (uint32_t) H * (uint32_t) D;
 	uint32_t       n    = 0;
+	if (GRAD != 2 && DWORDS)
+	{        // dword-aligned rows: one lane tests 4 voxels per load (256 contiguous bytes per wave-load)
+		const int xd = (int) (bx * 64 + (threadIdx.x & 63));        // dword column
+		for (uint32_t rg = blockIdx.x / blocks_x; rg < n_row_groups; rg += gridDim.x / blocks_x)
+		{
+			const uint32_t row = rg * 4 + (threadIdx.x >> 6);
+			uint32_t       c   = 0;
+			if (xd * 4 < W && row < rows)
+			{
+				const size_t   o  = (size_t) row * (size_t) W;
+				const uint32_t v4 = reinterpret_cast<const uint32_t *>(vol + o)[xd];
+				const uint32_t g4 = GRAD == 1 ? reinterpret_cast<const uint32_t *>(grad + o)[xd] : 0xffffffffu;
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+				{
+					const uint32_t bit = ((g4 >> (8 * i)) & 255u) * 256u + ((v4 >> (8 * i)) & 255u);
+					c += (s_bits[bit >> 5] >> (bit & 31u)) & 1u;
+				}
+			}
+			n += c;        // per-lane partial sums, reduced below
+		}
+		for (int o2 = 32; o2 > 0; o2 >>= 1)
+			n += (uint32_t) __shfl_xor((int) n, o2);
+	}
+	else
+	{
+	const int x = (int) (bx * 64 + (threadIdx.x & 63));
 	for (uint32_t rg = blockIdx.x / blocks_x; rg < n_row_groups; rg += gridDim.x / blocks_x)
 	{
 		const uint32_t row = rg * 4 + (threadIdx.x >> 6);
@@ -294,6 +320,7 @@ __global__ void __launch_bounds__(256) k_occupied_voxel_count(const uint8_t *__r
 			}
 		}
 		n += (uint32_t) __popcll(__ballot(occ));        // wave-uniform
+	}
 	}
 	if ((threadIdx.x & 63) == 0)
 		s_wave[threadIdx.x >> 6] = n;
@@ -529,6 +556,69 @@ __global__ void __launch_bounds__(64) k_dm_sweep(const uint8_t *__restrict__ src
 	}
 }
 
+// LDS-staged version for dword-aligned rows (W % 4 == 0): a workgroup packs 8 x 2 x 2 bricks from a 33 x 9 x 9 texel tile that it
+// stages with coalesced dword loads (volume and gradient once each), then writes the 32 bricks as whole 256-byte lines.
+__global__ void __launch_bounds__(256) k_pack_volume_tiled(const uint8_t *__restrict__ vol, const uint8_t *__restrict__ grad, uint8_t *__restrict__ packed,
+                                                           int W, int H, int D, PackedDims pd, uint32_t groups_x)
+{
+	constexpr int kTX = 36, kRows = 81;        // tile: [9][9][36] texels of (v | g << 8); 33 used in x
+	__shared__ uint16_t s_tile[kRows * kTX];
+	const int bx0 = (int) (blockIdx.x % groups_x) * 8, by0 = (int) (blockIdx.x / groups_x) * 2, bz0 = (int) blockIdx.y * 2;
+	const int wd  = W >> 2;
+	// ---- stage: row = (jz, jy) of the padded tile, 9 dwords per row starting one dword left of the tile
+	for (int it = threadIdx.x; it < kRows * 9; it += 256)
+	{
+		const int row = it / 9, c = it - row * 9;
+		const int y = min(max(by0 * 4 + row % 9 - 1, 0), H - 1), z = min(max(bz0 * 4 + row / 9 - 1, 0), D - 1);
+		const int dc = min(max(bx0 - 1 + c, 0), wd - 1);
+		const size_t   o  = ((size_t) z * H + y) * (size_t) W;
+		const uint32_t v4 = reinterpret_cast<const uint32_t *>(vol + o)[dc];
+		const uint32_t g4 = grad ? reinterpret_cast<const uint32_t *>(grad + o)[dc] : 0u;
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+		{
+			const int jx = 4 * c - 3 + k;        // padded tile column of voxel x = 4 * (bx0 - 1 + c) + k
+			if (jx >= 0 && jx <= 32)
+				s_tile[row * kTX + jx] = (uint16_t) (((v4 >> (8 * k)) & 255u) | (((g4 >> (8 * k)) & 255u) << 8));
+		}
+	}
+	__syncthreads();
+	// ---- clamp-to-edge in x (dword columns were clamped as a whole): x = -1 -> voxel 0, x >= W -> voxel W - 1
+	if (bx0 == 0 || bx0 * 4 + 31 >= W)
+	{
+		for (int it = threadIdx.x; it < kRows * 33; it += 256)
+		{
+			const int row = it / 33, jx = it - row * 33;
+			const int x = bx0 * 4 + jx - 1;
+			if (x < 0)
+				s_tile[row * kTX + jx] = s_tile[row * kTX + 1 - bx0 * 4];
+			else if (x >= W)
+				s_tile[row * kTX + jx] = s_tile[row * kTX + W - bx0 * 4];
+		}
+		__syncthreads();
+	}
+	// ---- write: 32 bricks x 64 dwords
+	for (int it = threadIdx.x; it < 32 * 64; it += 256)
+	{
+		const int b = it >> 6, d = it & 63;
+		const int bx = bx0 + (b & 7), by = by0 + ((b >> 3) & 1), bz = bz0 + (b >> 4);
+		if (bx >= pd.bx || by >= pd.by || bz >= pd.bz)
+			continue;
+		uint32_t word = 0;
+#pragma unroll
+		for (int h = 0; h < 2; ++h)
+		{
+			const int t = 2 * d + h;
+			if (t < 125)
+			{
+				const int lx = t % 5, ly = (t / 5) % 5, lz = t / 25;
+				word |= (uint32_t) s_tile[(((b >> 4) * 4 + lz) * 9 + ((b >> 3) & 1) * 4 + ly) * kTX + (b & 7) * 4 + lx] << (16 * h);
+			}
+		}
+		reinterpret_cast<uint32_t *>(packed + packed_brick_offset(bx, by, bz, pd.mx, pd.my))[d] = word;
+	}
+}
+
 // ---------------------------------------------------------------------------------------------
 // Synthetic volumes (DESIGN.md "Synthetic inputs")
 // ---------------------------------------------------------------------------------------------
@@ -738,7 +828,8 @@ int launch_occupied_voxel_count(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_
 	const hipError_t me = hipMemsetAsync(d_count, 0, sizeof(uint64_t), s);
 	if (me != hipSuccess)
 		return set_error(ctx, (int) me, "occupied_voxel_count: %s", hipGetErrorString(me));
-	const uint32_t blocks_x     = (e.width + 63) / 64;
+	const bool     dwords       = (e.width & 3u) == 0 && ((((uintptr_t) d_vol) | ((uintptr_t) d_grad)) & 3u) == 0 && (!tf->use_gradient || d_grad);
+	const uint32_t blocks_x     = dwords ? (e.width / 4 + 63) / 64 : (e.width + 63) / 64;
 	const uint64_t rows         = (uint64_t) e.height * e.depth;
 	const uint64_t n_row_groups = (rows + 3) / 4;
 	if (n_row_groups > 0xffffffffull)
@@ -748,15 +839,20 @@ int launch_occupied_voxel_count(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_
 	const dim3     grid(blocks_x * groups);
 	unsigned long long *total = reinterpret_cast<unsigned long long *>(d_count);
 	const int W = (int) e.width, H = (int) e.height, D = (int) e.depth;
+#define VKV_COUNT(G, DW)                                                                                                                                  \
+	hipLaunchKernelGGL((k_occupied_voxel_count<G, DW>), grid, dim3(256), 0, s, d_vol, d_grad, d_bits, total, W, H, D, tf->grad_magnitude_modifier,        \
+	                   tf->intensity_min, tf->intensity_range_inv, tf->gradient_min, tf->gradient_range_inv, blocks_x, (uint32_t) n_row_groups)
 	if (!tf->use_gradient)
-		hipLaunchKernelGGL(k_occupied_voxel_count<0>, grid, dim3(256), 0, s, d_vol, d_grad, d_bits, total, W, H, D, tf->grad_magnitude_modifier,
-		                   tf->intensity_min, tf->intensity_range_inv, tf->gradient_min, tf->gradient_range_inv, blocks_x, (uint32_t) n_row_groups);
+	{
+		if (dwords) VKV_COUNT(0, true); else VKV_COUNT(0, false);
+	}
 	else if (d_grad)
-		hipLaunchKernelGGL(k_occupied_voxel_count<1>, grid, dim3(256), 0, s, d_vol, d_grad, d_bits, total, W, H, D, tf->grad_magnitude_modifier,
-		                   tf->intensity_min, tf->intensity_range_inv, tf->gradient_min, tf->gradient_range_inv, blocks_x, (uint32_t) n_row_groups);
+	{
+		if (dwords) VKV_COUNT(1, true); else VKV_COUNT(1, false);
+	}
 	else
-		hipLaunchKernelGGL(k_occupied_voxel_count<2>, grid, dim3(256), 0, s, d_vol, d_grad, d_bits, total, W, H, D, tf->grad_magnitude_modifier,
-		                   tf->intensity_min, tf->intensity_range_inv, tf->gradient_min, tf->gradient_range_inv, blocks_x, (uint32_t) n_row_groups);
+		VKV_COUNT(2, false);
+#undef VKV_COUNT
 	return check_launch(ctx, "occupied_voxel_count");
 }
 
@@ -846,6 +942,16 @@ int launch_distance_map_anisotropic(vkv_ctx *ctx, uint8_t *const m[8], uint8_t *
 int launch_pack_volume(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_grad, VkvExtent3D e, void *d_packed, hipStream_t s)
 {
 	const PackedDims pd = packed_dims((int) e.width, (int) e.height, (int) e.depth);
+	if ((e.width & 3u) == 0 && ((((uintptr_t) d_vol) | ((uintptr_t) d_grad)) & 3u) == 0)
+	{
+		const uint32_t gx = (uint32_t) (pd.bx + 7) / 8, gy = (uint32_t) (pd.by + 1) / 2, gz = (uint32_t) (pd.bz + 1) / 2;
+		if ((uint64_t) gx * gy <= 0xffffffull && gz <= 65535u && (uint64_t) pd.mx * pd.my * pd.mz * 512 <= 0xffffffffull)
+		{
+			hipLaunchKernelGGL(k_pack_volume_tiled, dim3(gx * gy, gz), dim3(256), 0, s, d_vol, d_grad, (uint8_t *) d_packed, (int) e.width, (int) e.height,
+			                   (int) e.depth, pd, gx);
+			return check_launch(ctx, "pack_volume");
+		}
+	}
 	const uint64_t   nb = (uint64_t) pd.bx * pd.by;        // bricks per z layer
 	if (nb > 0xffffffull || pd.bz > 65535 || (uint64_t) pd.mx * pd.my * pd.mz * 512 > 0xffffffffull)
 		return set_error(ctx, VKV_E_UNSUPPORTED, "pack_volume: volume too large");
