@@ -423,6 +423,8 @@ int vkv_render(vkv_ctx *ctx, const VkvRenderParams *P, void *stream)
 	{
 		if (!map_extent_ok(P->volume_extent, P->map_extent))
 			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: bad map extent");
+		if ((uint64_t) P->map_extent.width * P->map_extent.height * P->map_extent.depth > 0xffffffffull)
+			return set_error(ctx, VKV_E_UNSUPPORTED, "render: distance maps with more than 2^32 cells are not supported");
 		const int n = o.skipping_type == VKV_SKIP_ANISOTROPIC_DISTANCE ? 8 : 1;
 		for (int i = 0; i < n; ++i)
 			if (!P->d_distance_maps[i])
