@@ -265,8 +265,8 @@ int vkv_convert_volume(vkv_ctx *ctx, const void *d_raw, int32_t type, int32_t bi
 size_t vkv_packed_volume_bytes(VkvExtent3D extent);
 int    vkv_pack_volume(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_t *d_gradient, VkvExtent3D extent, void *d_packed, void *stream);
 
-/* 1 bit per texel of the 256x256 TF texture: alpha > 0 (2048 words, row = gradient), followed by word 2048 = the smallest
- * intensity texel whose column holds any occupied texel; the buffer is VKV_TF_BITS_WORDS = 2052 uint32.  Lets the integrator decide
+/* 1 bit per texel of the 256x256 TF texture: alpha > 0 (2048 words, row = gradient); the buffer is VKV_TF_BITS_WORDS = 2052
+ * uint32 (the last four words are reserved).  Lets the integrator decide
  * "voxel_occupied" (frag:276) from LDS and fetch the RGBA texel only for occupied samples. */
 int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_transfer_function, uint32_t *d_bits_2052, void *stream);
 

@@ -118,26 +118,6 @@ __global__ void __launch_bounds__(256) k_tf_bits(const uint8_t *__restrict__ tf_
 	bits[w] = v;
 }
 
-// Word 2048 of the bit table: the smallest intensity texel whose column holds any occupied texel (256 if none).  The
-// integrator uses it to classify a sample as empty from the raw bytes: a filtered value never exceeds the largest
-// of its eight corner bytes, so if that byte's texel is below this bound the sample's alpha is 0 whatever the gradient.
-__global__ void __launch_bounds__(256) k_tf_colmin(uint32_t *__restrict__ bits)
-{
-	__shared__ uint32_t s_min;
-	if (threadIdx.x == 0)
-		s_min = 256u;
-	__syncthreads();
-	const uint32_t c = threadIdx.x;
-	uint32_t any = 0;
-	for (uint32_t g = 0; g < 256; ++g)
-		any |= (bits[(g * 256 + c) >> 5] >> (c & 31u)) & 1u;
-	if (any)
-		atomicMin(&s_min, c);
-	__syncthreads();
-	if (threadIdx.x == 0)
-		bits[2048] = s_min;
-}
-
 // Block = 256 threads = 256 consecutive voxels in x of one cell row (cy, cz); it walks the by*bz voxel rows of
 // that cell row, every load being a coalesced 64-byte segment per wave, ORs "occupied" into one LDS flag per cell.
 // GRAD: 0 = use_gradient false (gradient = 1.0), 1 = precomputed map, 2 = on-the-fly tetrahedron.
@@ -967,7 +947,6 @@ int launch_pack_volume(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_grad
 int launch_tf_bits(vkv_ctx *ctx, const uint8_t *d_tf, uint32_t *d_bits, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_tf_bits, dim3(8), dim3(256), 0, s, d_tf, d_bits);
-	hipLaunchKernelGGL(k_tf_colmin, dim3(1), dim3(256), 0, s, d_bits);
 	return check_launch(ctx, "transfer_function_bits");
 }
 
