@@ -222,7 +222,7 @@ def main():
     out = {
         "metric": "Mray/s", "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (u8 voxels)", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %dx%dx%d uint8 synthetic shells, %dx%d frame, %s ESS + ERT, block 4, TF imin 0.1 imax 1 gmin 0 gmax 0.2, "
                                "8 orbit views" % (args.workload, *WORKLOADS[args.workload][0], fw, fh,
                                                   {1: "block", 2: "Chebyshev distance-map", 3: "anisotropic"}[skip]),
