@@ -370,53 +370,6 @@ __global__ void __launch_bounds__(64) k_dm_x(const uint8_t *src, uint8_t *dst, i
 	}
 }
 
-// y / z pass: D(p) = min_n max(|n|, g(p + n)) along one axis (two-sided, MODE 0: distance_map.comp:72-107) or over
-// n >= 0 in direction MODE = ±1 (distance_map_anisotropic.comp:55-91).  A block stages a strip of 64 x-columns by
-// the whole axis in LDS (64-byte rows: every global access is coalesced, LDS reads of a wave hit 16 consecutive
-// banks with 4-lane broadcast) and 256 threads split the axis in four.
-template <int MODE>
-__global__ void __launch_bounds__(256) k_dm_axis(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int mw, int len, size_t axis_stride,
-                                                 size_t other_stride, uint32_t chunks_x)
-{
-	extern __shared__ __align__(16) uint8_t s_strip[];        // [len][64]
-	const uint32_t cx    = blockIdx.x % chunks_x;
-	const uint32_t other = blockIdx.x / chunks_x;
-	const int      lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-	const int      x    = (int) cx * 64 + lane;
-	const bool     live = x < mw;
-	const size_t   base = (size_t) other * other_stride + (size_t) x;
-	for (int p = part; p < len; p += 4)
-		s_strip[p * 64 + lane] = live ? src[base + (size_t) p * axis_stride] : 255;
-	__syncthreads();
-	if (!live)
-		return;
-	for (int p = part; p < len; p += 4)
-	{
-		uint32_t m = s_strip[p * 64 + lane];
-		if (MODE == 0)
-		{
-			for (int n = 1; (uint32_t) n < m; ++n)
-			{
-				if (p >= n)
-					m = min(m, max((uint32_t) n, (uint32_t) s_strip[(p - n) * 64 + lane]));
-				if (p + n < len && (uint32_t) n < m)
-					m = min(m, max((uint32_t) n, (uint32_t) s_strip[(p + n) * 64 + lane]));
-			}
-		}
-		else
-		{
-			for (int n = 1; (uint32_t) n < m && n < 255; ++n)
-			{
-				const int q = p + MODE * n;
-				if (q < 0 || q >= len)
-					break;
-				m = min(m, max((uint32_t) n, (uint32_t) s_strip[q * 64 + lane]));
-			}
-		}
-		dst[base + (size_t) p * axis_stride] = (uint8_t) m;
-	}
-}
-
 // ---------------------------------------------------------------------------------------------
 // Packed sampling layout (see vkv_device.hpp): one 128-thread half-block per brick, thread = one of the 5^3 texels
 // ---------------------------------------------------------------------------------------------
@@ -451,88 +404,199 @@ __global__ void __launch_bounds__(256) k_pack_volume(const uint8_t *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// O(N) axis pass.  out(p) = min over the candidates q of max(|q - p|, g(q)) is the lower envelope of "flat-bottomed V"
-// functions.  Sweeping p away from the candidates, a candidate can be dropped for good (a) when a nearer one has a
-// smaller-or-equal g, and (b) when its value is not below that of the next nearer one (its distance term dominates and
-// grows faster).  What survives is a deque with g strictly decreasing towards the far end whose far end is the minimum:
-// every cell is pushed and popped at most once, independent of the data (the reference's zig-zag search, and the first
-// version here, do up to 2 x 255 reads per cell in empty regions).  Candidates further than 255 cells away can never win
-// (results are capped at 255 and the cell itself is always a candidate), so positions are kept modulo 256 and one deque
-// entry is 16 bits: 256 entries x 64 lanes = 32 KiB of LDS per wave, lanes = 64 consecutive x columns (coalesced rows).
-// MODE +1 / -1: one-sided (distance_map_anisotropic.comp:55-91), candidates at higher / lower index.
-// MODE 0: two-sided (distance_map.comp:72-107) = min of the two one-sided sweeps.
+// Axis pass of the distance transform (x, y or z), every cell an independent lane of work.
+// With m_r(p) = min of g over the candidates within r cells of p (a window that only grows with r),
+//     out(p) = min over q of max(|q - p|, g(q)) = the smallest r with m_r(p) <= r
+// (below that r every max(r, m_r) equals m_r > r; at it the value is r itself).  This is what the reference's zig-zag search
+// (distance_map.comp:72-107, up to 2 x 255 reads per cell) and the anisotropic one-sided search (distance_map_anisotropic.comp:
+// 55-91) compute.  The predicate is monotone in r and true at r = g(p), so 8 bisection steps settle a cell, each one a
+// range-minimum query answered with two byte reads from a sparse table (level k = minima of 2^k consecutive cells) that the
+// workgroup builds in LDS four cells per operation.  Results of neighbouring cells differ by at most one (two-sided) or follow
+// from the neighbour with one window test (one-sided), so a thread bisects only the first cell of its run and walks the rest.
+// History: a data-dependent search out of an LDS strip (1.4 ms for the three C3 passes), then an O(N) monotone-deque sweep per
+// column (0.66 ms: 51 K serial sweeps whose LDS round trips sit on one dependency chain), now 0.17 ms.
+// A workgroup takes XT lines and a run of the axis: the whole line when it fits SEG cells, else `ch` outputs plus 255 cells of
+// halo on both sides (a candidate further away can never win: the result never exceeds g(p) <= 255).
+// MODE 0: two-sided, +1 / -1: candidates at higher / lower index, 2: both one-sided results from one table (dst = +1,
+// dst2 = -1; the anisotropic schedule always needs the pair).
 // ---------------------------------------------------------------------------------------------
-struct DmDeque
+// byte-wise unsigned minimum of two packed dwords (no carries between the bytes)
+__device__ __forceinline__ uint32_t min_u8x4(uint32_t a, uint32_t b)
 {
-	uint16_t *ring;        // [256][64] entries: (logical step & 255) << 8 | g
-	uint32_t  head, tail;  // monotonically increasing; slot = index & 255; count = tail - head <= 256
-	uint32_t  lane;
+	const uint32_t d  = (a | 0x80808080u) - (b & 0x7f7f7f7fu);                        // bit 7 of a byte: low 7 bits of a >= those of b
+	const uint32_t ge = ((a & ~b) | (~(a ^ b) & d)) & 0x80808080u;                    // bit 7: a >= b
+	const uint32_t m  = (ge - (ge >> 7)) | ge;                                        // 0xff where a >= b
+	return (b & m) | (a & ~m);
+}
 
-	__device__ __forceinline__ uint32_t at(uint32_t idx) const { return ring[(idx & 255u) * 64u + lane]; }
-	__device__ __forceinline__ static uint32_t value(uint32_t entry, uint32_t s) { return max((s - (entry >> 8)) & 255u, entry & 255u); }
-
-	// one sweep step at logical step s with input gp; returns out(p)
-	__device__ __forceinline__ uint32_t step(uint32_t s, uint32_t gp)
+template <int MODE, int XT, int SEG, bool XAXIS>
+__global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst, uint8_t *dst2, uint32_t n_lines, int len,
+                                                size_t line_stride, size_t axis_stride, size_t other_stride, uint32_t chunks_x, uint32_t chunks_p, int ch)
+{
+	// A line is one run of the axis; the workgroup owns lines cx * XT .. + XT of group `other`:
+	//   y / z pass: lines = consecutive x (line_stride 1), LDS index p * XT + line (a dword = 4 lines of one cell row)
+	//   x pass (XAXIS): lines = consecutive rows (line_stride = width), LDS index line * (SEG + 4) + p (a dword = 4 cells of one line)
+	// Levels 0..8 of the sparse table, then one (MODE 2: two) level-sized result area for a coalesced write-out.
+	constexpr int kPitch = XAXIS ? SEG + 4 : XT;        // x pass: one dword of padding per line spreads the lines over the LDS banks
+	constexpr int kLevel = XAXIS ? XT * kPitch : SEG * XT, kOut = 9 * kLevel;
+	__shared__ __align__(16) uint8_t s_t[(MODE == 2 ? 11 : 10) * kLevel];
+	const uint32_t cx = blockIdx.x % chunks_x, cp = (blockIdx.x / chunks_x) % chunks_p, other = blockIdx.x / (chunks_x * chunks_p);
+	const int      out0 = (int) cp * ch, out1 = min(len, out0 + ch);
+	const int      seg0 = max(0, out0 - 255), n = min(len, out1 + 255) - seg0;        // staged cells [seg0, seg0 + n), n <= SEG
+	const int      t      = (int) threadIdx.x;
+	const size_t   base   = (size_t) other * other_stride + (size_t) cx * XT * line_stride + (size_t) seg0 * axis_stride;
+	auto           at     = [](int p, int line) { return XAXIS ? line * kPitch + p : p * XT + line; };
+	const int      n4     = (n + 3) & ~3;        // x pass: the tail of the last dword of a line is padded with 255
+	// staging / write-out: iteration q of a thread is cell (line, p); x pass: threads run along the row, rows one after the other;
+	// y / z pass: 256 / XT cell rows of XT lines at a time
+	const int per_line = (n4 + 255) / 256;
+	const int n_iter   = XAXIS ? XT * per_line : (n + 256 / XT - 1) / (256 / XT);
+	auto      cell     = [&](int q, int &line, int &p) {
+		if (XAXIS)
+			line = q / per_line, p = t + 256 * (q % per_line);
+		else
+			line = t % XT, p = t / XT + q * (256 / XT);
+	};
+	constexpr int kBatch = 8;        // loads in flight per thread
+	for (int q0 = 0; q0 < n_iter; q0 += kBatch)
 	{
-		while (tail != head && (at(tail - 1) & 255u) >= gp)        // (a) dominated by the new, nearer candidate
-			--tail;
-		ring[(tail & 255u) * 64u + lane] = (uint16_t) (((s & 255u) << 8) | gp);
-		++tail;
-		if (tail - head >= 2 && (((s - (at(head) >> 8)) & 255u) == 0u))        // far end is now 256 cells away
-			++head;
-		while (tail - head >= 2 && value(at(head), s) >= value(at(head + 1), s))        // (b)
-			++head;
-		return value(at(head), s);
-	}
-};
-
-template <int MODE>
-__global__ void __launch_bounds__(64) k_dm_sweep(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int mw, int len, size_t axis_stride,
-                                                 size_t other_stride, uint32_t chunks_x)
-{
-	__shared__ uint16_t s_ring[256 * 64];
-	const uint32_t cx = blockIdx.x % chunks_x, other = blockIdx.x / chunks_x;
-	const int      x  = (int) cx * 64 + (int) threadIdx.x;
-	if (x >= mw)
-		return;
-	const size_t base = (size_t) other * other_stride + (size_t) x;
-	DmDeque      dq{s_ring, 0u, 0u, threadIdx.x};
-	constexpr int kAhead = 8;        // rows fetched ahead of the serial deque work
-	if (MODE <= 0)
-	{        // candidates at lower index: ascending sweep
-		for (int s0 = 0; s0 < len; s0 += kAhead)
+		uint8_t v[kBatch];
+#pragma unroll
+		for (int j = 0; j < kBatch; ++j)
 		{
-			uint32_t g[kAhead];
+			int line, p;
+			cell(q0 + j, line, p);
+			const bool ok = q0 + j < n_iter && p < n && cx * XT + (uint32_t) line < n_lines;
+			v[j]          = ok ? src[base + (size_t) line * line_stride + (size_t) p * axis_stride] : (uint8_t) 255;
+		}
 #pragma unroll
-			for (int j = 0; j < kAhead; ++j)
-				g[j] = (s0 + j < len) ? src[base + (size_t) (s0 + j) * axis_stride] : 255u;
-#pragma unroll
-			for (int j = 0; j < kAhead; ++j)
-				if (s0 + j < len)
-					dst[base + (size_t) (s0 + j) * axis_stride] = (uint8_t) dq.step((uint32_t) (s0 + j), g[j]);
+		for (int j = 0; j < kBatch; ++j)
+		{
+			int line, p;
+			cell(q0 + j, line, p);
+			if (q0 + j < n_iter && p < (XAXIS ? n4 : n))
+				s_t[at(p, line)] = v[j];
 		}
 	}
-	if (MODE >= 0)
-	{        // candidates at higher index: descending sweep; MODE 0 combines with the first sweep's result
-		dq.head = dq.tail = 0u;
-		for (int s0 = 0; s0 < len; s0 += kAhead)
-		{
-			uint32_t g[kAhead], prev[kAhead];
-#pragma unroll
-			for (int j = 0; j < kAhead; ++j)
+	__syncthreads();
+	// ---- sparse table, four cells per operation ------------------------------------------------------------------
+	for (int k = 1; k <= 8 && (1 << (k - 1)) < n; ++k)
+	{
+		const int       h = 1 << (k - 1);
+		const uint32_t *a = reinterpret_cast<const uint32_t *>(s_t + (k - 1) * kLevel);
+		uint32_t *      b = reinterpret_cast<uint32_t *>(s_t + k * kLevel);
+		if (XAXIS)
+		{        // dword e of a line = cells 4e .. 4e+3; the partner cells 4e+h .. are a byte-shifted pair of dwords for h < 4
+			constexpr int kDw = SEG / 4, kRowDw = kPitch / 4;
+			const int     nd  = n4 / 4;
+			for (int idx = t; idx < XT * kDw; idx += 256)
 			{
-				const int p = len - 1 - (s0 + j);
-				g[j]        = (p >= 0) ? src[base + (size_t) p * axis_stride] : 255u;
-				prev[j]     = (MODE == 0 && p >= 0) ? dst[base + (size_t) p * axis_stride] : 255u;
-			}
-#pragma unroll
-			for (int j = 0; j < kAhead; ++j)
-			{
-				const int p = len - 1 - (s0 + j);
-				if (p >= 0)
-					dst[base + (size_t) p * axis_stride] = (uint8_t) min(dq.step((uint32_t) (s0 + j), g[j]), prev[j]);
+				const int line = idx / kDw, e = idx % kDw;
+				if (e >= nd)
+					continue;
+				const uint32_t *row = a + line * kRowDw;
+				uint32_t        o;
+				if (h >= 4)
+					o = (e + h / 4 < nd) ? row[e + h / 4] : 0xffffffffu;
+				else
+				{
+					const uint32_t nx = (e + 1 < nd) ? row[e + 1] : 0xffffffffu;
+					o                 = h == 1 ? __builtin_amdgcn_alignbyte(nx, row[e], 1) : __builtin_amdgcn_alignbyte(nx, row[e], 2);
+				}
+				b[line * kRowDw + e] = min_u8x4(row[e], o);
 			}
 		}
+		else
+		{        // dword = 4 lines of cell row p; the partner is the same dword h rows on
+			constexpr int kDw = XT / 4;
+			for (int e = t; e < n * kDw; e += 256)
+			{
+				const int      p = e / kDw;
+				const uint32_t o = (p + h < n) ? a[e + h * kDw] : 0xffffffffu;
+				b[e]             = min_u8x4(a[e], o);
+			}
+		}
+		__syncthreads();
+	}
+	// ---- results: each thread owns a run of consecutive cells of one line; the first by bisection, the rest by walking
+	// (the result of a neighbouring cell differs by at most one, so one or two window tests settle each further cell)
+	{
+		constexpr int kRuns = 256 / XT;
+		const int     line  = XAXIS ? t / kRuns : t % XT, run = XAXIS ? t % kRuns : t / XT;
+		const int     nout  = out1 - out0, rl = (nout + kRuns - 1) / kRuns;
+		const int     pa = out0 - seg0 + run * rl, pb = min(pa + rl, out1 - seg0);        // [pa, pb)
+		auto rmq = [&](int l, int r) -> uint32_t {
+			const int      k  = 31 - __builtin_clz((uint32_t) (r - l + 1));
+			const uint8_t *tk = s_t + k * kLevel;
+			return min((uint32_t) tk[at(l, line)], (uint32_t) tk[at(r - (1 << k) + 1, line)]);
+		};
+		auto bisect = [&](int p, int dir) -> uint32_t {
+			uint32_t lo = 0, hi = s_t[at(p, line)];
+#pragma unroll
+			for (int it = 0; it < 8; ++it)
+			{
+				const uint32_t mid = (lo + hi) >> 1;
+				const int      l = dir == 1 ? p : max(p - (int) mid, 0);
+				const int      r = dir == -1 ? p : min(p + (int) mid, n - 1);
+				const bool     ok = rmq(l, r) <= mid;
+				hi = ok ? mid : hi;
+				lo = ok ? lo : mid + 1;
+			}
+			return hi;
+		};
+		if (pa < pb)
+		{
+			if (MODE == 0)
+			{
+				uint32_t c               = bisect(pa, 0);
+				s_t[kOut + at(pa, line)] = (uint8_t) c;
+				for (int p = pa + 1; p < pb; ++p)
+				{        // out(p) is c - 1, c or c + 1
+					const int      c1 = max((int) c - 1, 0);
+					const uint32_t w1 = rmq(max(p - c1, 0), min(p + c1, n - 1));
+					const uint32_t w0 = rmq(max(p - (int) c, 0), min(p + (int) c, n - 1));
+					c                 = (c >= 1u && w1 <= c - 1u) ? c - 1u : (w0 <= c ? c : c + 1u);
+					s_t[kOut + at(p, line)] = (uint8_t) c;
+				}
+			}
+			if (MODE == 1 || MODE == 2)
+			{        // candidates at higher index: walk down; the candidates above p give c or c + 1, the cell itself g(p)
+				uint32_t c                   = bisect(pb - 1, 1);
+				s_t[kOut + at(pb - 1, line)] = (uint8_t) c;
+				for (int p = pb - 2; p >= pa; --p)
+				{
+					const uint32_t w = c >= 1u ? rmq(p + 1, min(p + (int) c, n - 1)) : 255u;
+					const uint32_t T = (c >= 1u && w <= c) ? c : c + 1u;
+					c                = min((uint32_t) s_t[at(p, line)], T);
+					s_t[kOut + at(p, line)] = (uint8_t) c;
+				}
+			}
+			if (MODE == -1 || MODE == 2)
+			{
+				constexpr int o2             = MODE == 2 ? kOut + kLevel : kOut;
+				uint32_t      c              = bisect(pa, -1);
+				s_t[o2 + at(pa, line)]       = (uint8_t) c;
+				for (int p = pa + 1; p < pb; ++p)
+				{
+					const uint32_t w = c >= 1u ? rmq(max(p - (int) c, 0), p - 1) : 255u;
+					const uint32_t T = (c >= 1u && w <= c) ? c : c + 1u;
+					c                = min((uint32_t) s_t[at(p, line)], T);
+					s_t[o2 + at(p, line)] = (uint8_t) c;
+				}
+			}
+		}
+	}
+	__syncthreads();
+	for (int q = 0; q < n_iter; ++q)
+	{
+		int line, p;
+		cell(q, line, p);
+		if (p < out0 - seg0 || p >= out1 - seg0 || cx * XT + (uint32_t) line >= n_lines)
+			continue;
+		const size_t o = base + (size_t) line * line_stride + (size_t) p * axis_stride;
+		dst[o]         = s_t[kOut + at(p, line)];
+		if (MODE == 2)
+			dst2[o] = s_t[kOut + kLevel + at(p, line)];
 	}
 }
 
@@ -845,8 +909,14 @@ static int row_stride_for(int mw)
 }
 
 template <int MODE>
+static int launch_dm_rmq(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *dst, uint8_t *dst2, VkvExtent3D me, hipStream_t s);
+
+template <int MODE>
 static int launch_dm_x(vkv_ctx *ctx, const uint8_t *src, uint8_t *dst, VkvExtent3D me, hipStream_t s)
 {
+	if (me.width <= 1024)
+		return launch_dm_rmq<MODE>(ctx, 0, src, dst, nullptr, me, s);
+	// longer rows: serial row scan out of LDS (in place, like the table kernel for short rows)
 	const uint32_t n_rows = me.height * me.depth;
 	const int      stride = row_stride_for((int) me.width);
 	const size_t   lds    = (size_t) stride * 64;
@@ -856,34 +926,56 @@ static int launch_dm_x(vkv_ctx *ctx, const uint8_t *src, uint8_t *dst, VkvExtent
 	return check_launch(ctx, "distance_map x pass");
 }
 
+// axis: 0 = x, 1 = y, 2 = z.  MODE 2 writes the +1 result to dst and the -1 result to dst2.  The x pass may run in place
+// (a workgroup stages whole rows before it writes); rows longer than 1024 cells go to k_dm_x.
+template <int MODE>
+static int launch_dm_rmq(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *dst, uint8_t *dst2, VkvExtent3D me, hipStream_t s)
+{
+	const size_t   sy = me.width, sz = (size_t) me.width * me.height;
+	const int      len     = axis == 0 ? (int) me.width : axis == 1 ? (int) me.height : (int) me.depth;
+	const uint32_t other   = axis == 0 ? 1u : axis == 1 ? me.depth : me.height;
+	const uint32_t n_lines = axis == 0 ? me.height * me.depth : me.width;
+	const size_t   ls = axis == 0 ? sy : 1, as = axis == 0 ? 1 : axis == 1 ? sy : sz, os = axis == 1 ? sz : sy;
+#define VKV_DM_RMQ(XT, SEG, XAXIS)                                                                                                                     \
+	do                                                                                                                                                  \
+	{                                                                                                                                                   \
+		const int      ch       = len <= (SEG) ? len : (SEG) -510;                                                                                     \
+		const uint32_t chunks_p = (uint32_t) ((len + ch - 1) / ch), chunks_x = (n_lines + (XT) -1) / (XT);                                              \
+		if ((uint64_t) chunks_x * chunks_p * other > 0x7fffffffull)                                                                                     \
+			return set_error(ctx, VKV_E_UNSUPPORTED, "distance_map: map too large for one launch");                                                     \
+		hipLaunchKernelGGL((k_dm_rmq<MODE, XT, SEG, XAXIS>), dim3(chunks_x * chunks_p * other), dim3(256), 0, s, src, dst, dst2, n_lines, len, ls, as,  \
+		                   os, chunks_x, chunks_p, ch);                                                                                                 \
+	} while (0)
+	if (axis == 0)
+	{
+		if (len <= 256)
+			VKV_DM_RMQ(16, 256, true);
+		else
+			VKV_DM_RMQ(4, 1024, true);
+	}
+	else if (len <= 128 && me.width > 16)
+		VKV_DM_RMQ(32, 128, false);
+	else if (len <= 256)
+		VKV_DM_RMQ(16, 256, false);
+	else
+		VKV_DM_RMQ(8, 768, false);
+#undef VKV_DM_RMQ
+	return check_launch(ctx, "distance_map axis pass");
+}
+
 // axis: 1 = y, 2 = z
 template <int MODE>
 static int launch_dm_axis(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *dst, VkvExtent3D me, hipStream_t s)
 {
-	const uint32_t chunks_x = (me.width + 63) / 64;
-	const size_t   sy = me.width, sz = (size_t) me.width * me.height;
-	const int      len   = axis == 1 ? (int) me.height : (int) me.depth;
-	const uint32_t other = axis == 1 ? me.depth : me.height;
-	static const bool brute = [] { const char *e = std::getenv("VKV_DM_BRUTE_FORCE"); return e && e[0] == '1'; }();
-	if (brute)
-	{        // first version (data-dependent search out of an LDS strip), kept for A/B and as a cross-check in the tests
-		if ((size_t) len * 64 > 64 * 1024)
-			(void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dm_axis<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, len * 64);
-		hipLaunchKernelGGL(k_dm_axis<MODE>, dim3(chunks_x * other), dim3(256), (size_t) len * 64, s, src, dst, (int) me.width, len, axis == 1 ? sy : sz,
-		                   axis == 1 ? sz : sy, chunks_x);
-	}
-	else
-		hipLaunchKernelGGL(k_dm_sweep<MODE>, dim3(chunks_x * other), dim3(64), 0, s, src, dst, (int) me.width, len, axis == 1 ? sy : sz, axis == 1 ? sz : sy,
-		                   chunks_x);
-	return check_launch(ctx, "distance_map axis pass");
+	return launch_dm_rmq<MODE>(ctx, axis, src, dst, nullptr, me, s);
 }
 
 static int dm_check_extent(vkv_ctx *ctx, VkvExtent3D me)
 {
 	if (me.width == 0 || me.height == 0 || me.depth == 0)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "distance_map: zero map extent");
-	if (me.width > 2048 || me.height > 2048 || me.depth > 2048)
-		return set_error(ctx, VKV_E_UNSUPPORTED, "distance_map: map axis longer than 2048 cells (LDS strip limit)");
+	if (me.width > 2048)
+		return set_error(ctx, VKV_E_UNSUPPORTED, "distance_map: map rows longer than 2048 cells (LDS strip limit of the x pass)");
 	return VKV_OK;
 }
 
@@ -903,6 +995,21 @@ int launch_distance_map_anisotropic(vkv_ctx *ctx, uint8_t *const m[8], uint8_t *
 	int rc = dm_check_extent(ctx, me);
 	if (rc) return rc;
 	const uint8_t *occ = m[7];
+	if (me.width <= 1024)
+	{
+		// Same results with 7 launches instead of 14: every pass answers its +1 and -1 queries from one table.  Buffers: the x
+		// pass leaves x+ in m[3] and x- in m[7] (in place on the occupancy); y of x+ puts y+ into swap and y- into m[1], whose z
+		// passes fill (m[2], m[3]) and then (m[0], m[1]); the x- half repeats this with m[4..7].
+		if ((rc = launch_dm_rmq<2>(ctx, 0, occ, m[3], m[7], me, s))) return rc;
+		for (int h = 0; h < 2; ++h)
+		{
+			uint8_t *const *q = m + 4 * h;
+			if ((rc = launch_dm_rmq<2>(ctx, 1, q[3], swap, q[1], me, s))) return rc;
+			if ((rc = launch_dm_rmq<2>(ctx, 2, q[1], q[2], q[3], me, s))) return rc;
+			if ((rc = launch_dm_rmq<2>(ctx, 2, swap, q[0], q[1], me, s))) return rc;
+		}
+		return VKV_OK;
+	}
 	if ((rc = launch_dm_x<1>(ctx, occ, m[3], me, s))) return rc;                  // stage1(3, +1)
 	if ((rc = launch_dm_axis<1>(ctx, 1, m[3], swap, me, s))) return rc;           // stage2(3, +1)
 	if ((rc = launch_dm_axis<1>(ctx, 2, swap, m[0], me, s))) return rc;           // stage3(0, +1)
