@@ -121,6 +121,59 @@ __global__ void __launch_bounds__(256) k_tf_bits(const uint8_t *__restrict__ tf_
 // Block = 256 threads = 256 consecutive voxels in x of one cell row (cy, cz); it walks the by*bz voxel rows of
 // that cell row, every load being a coalesced 64-byte segment per wave, ORs "occupied" into one LDS flag per cell.
 // GRAD: 0 = use_gradient false (gradient = 1.0), 1 = precomputed map, 2 = on-the-fly tetrahedron.
+// Same dword streaming for any block width: a workgroup owns `cpb` whole cells of a cell row (cpb a multiple of 4, so its first
+// voxel is dword aligned), a thread ORs the occupied bits of its 4 voxels over the by x bz rows and then flags their cells in LDS.
+template <int GRAD>
+__global__ void __launch_bounds__(256) k_occupancy_map_dword_any(const uint8_t *__restrict__ vol, const uint8_t *__restrict__ grad,
+                                                                 const uint32_t *__restrict__ tf_bits, uint8_t *__restrict__ map, int W, int H, int D,
+                                                                 int mw, int mh, int bx, int by, int bz, int cpb, uint32_t blocks_x)
+{
+	__shared__ uint32_t s_bits[2048];
+	__shared__ uint32_t s_cell[1024];
+	for (int i = threadIdx.x; i < 2048; i += 256)
+		s_bits[i] = tf_bits[i];
+	for (int i = threadIdx.x; i < cpb; i += 256)
+		s_cell[i] = 0;
+	__syncthreads();
+	const int c0 = (int) (blockIdx.x % blocks_x) * cpb, x0 = c0 * bx;        // first cell / voxel of the workgroup
+	const int cy = (int) (blockIdx.x / blocks_x), cz = (int) blockIdx.y;
+	const int y_end = min((cy + 1) * by, H), z_end = min((cz + 1) * bz, D);
+	const int nd    = (min(cpb * bx, W - x0) + 3) >> 2;        // dwords of the span (W % 4 == 0: never past the row)
+	for (int d = threadIdx.x; d < nd; d += 256)
+	{
+		const int xd  = (x0 >> 2) + d;
+		uint32_t  occ = 0;
+		for (int z = cz * bz; z < z_end; ++z)
+			for (int y = cy * by; y < y_end; ++y)
+			{
+				const size_t   row = ((size_t) z * H + y) * (size_t) W;
+				const uint32_t v4  = reinterpret_cast<const uint32_t *>(vol + row)[xd];
+				const uint32_t g4  = GRAD == 1 ? reinterpret_cast<const uint32_t *>(grad + row)[xd] : 0xffffffffu;
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+				{
+					const uint32_t bit = ((g4 >> (8 * i)) & 255u) * 256u + ((v4 >> (8 * i)) & 255u);
+					occ |= ((s_bits[bit >> 5] >> (bit & 31u)) & 1u) << i;
+				}
+			}
+		if (occ)
+		{
+			int cell = (4 * d) / bx, in = (4 * d) - cell * bx;
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+			{
+				if ((occ >> i) & 1u)
+					s_cell[cell] = 1;        // benign race: every writer stores 1
+				if (++in == bx)
+					in = 0, ++cell;
+			}
+		}
+	}
+	__syncthreads();
+	for (int c = threadIdx.x; c < cpb && c0 + c < mw; c += 256)
+		map[((size_t) cz * mh + cy) * (size_t) mw + (size_t) (c0 + c)] = s_cell[c] ? 0 : 255;        // OCCUPIED = 0, EMPTY = 255
+}
+
 template <int GRAD>
 __global__ void __launch_bounds__(256) k_occupancy_map(const uint8_t *__restrict__ vol, const uint8_t *__restrict__ grad,
                                                        const uint32_t *__restrict__ tf_bits, uint8_t *__restrict__ map, int W, int H, int D,
@@ -849,6 +902,17 @@ int launch_occupancy_map(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_gr
 			if (bx == 1) VKV_OCC_DWORD(0, 1); else if (bx == 2) VKV_OCC_DWORD(0, 2); else VKV_OCC_DWORD(0, 4);
 		}
 #undef VKV_OCC_DWORD
+		return check_launch(ctx, "occupancy_map");
+	}
+	if (bx <= 256 && (e.width & 3u) == 0 && (!tf->use_gradient || precomputed) && (((uintptr_t) d_vol | (uintptr_t) d_grad) & 3u) == 0)
+	{
+		const int      cpb     = ((1024 / bx) & ~3) > 0 ? ((1024 / bx) & ~3) : 4;        // cells per workgroup (<= 1024, 4 | cpb)
+		const uint32_t ablocks = (me.width + cpb - 1) / cpb;
+		const dim3     agrid(ablocks * me.height, me.depth);
+		if (precomputed)
+			hipLaunchKernelGGL(k_occupancy_map_dword_any<1>, agrid, dim3(256), 0, s, d_vol, d_grad, d_bits, d_map, W, H, D, mw, mh, bx, by, bz, cpb, ablocks);
+		else
+			hipLaunchKernelGGL(k_occupancy_map_dword_any<0>, agrid, dim3(256), 0, s, d_vol, d_grad, d_bits, d_map, W, H, D, mw, mh, bx, by, bz, cpb, ablocks);
 		return check_launch(ctx, "occupancy_map");
 	}
 	if (!tf->use_gradient)
