@@ -604,11 +604,12 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 				uint32_t c               = bisect(pa, 0);
 				s_t[kOut + at(pa, line)] = (uint8_t) c;
 				for (int p = pa + 1; p < pb; ++p)
-				{        // out(p) is c - 1, c or c + 1
-					const int      c1 = max((int) c - 1, 0);
-					const uint32_t w1 = rmq(max(p - c1, 0), min(p + c1, n - 1));
-					const uint32_t w0 = rmq(max(p - (int) c, 0), min(p + (int) c, n - 1));
-					c                 = (c >= 1u && w1 <= c - 1u) ? c - 1u : (w0 <= c ? c : c + 1u);
+				{        // out(p) is c - 1, c or c + 1.  Radius c - 1 failed at p - 1, and the window of radius c - 1 at p is that window
+					 // minus its first cell plus cell p + c - 1: it can only succeed through the new cell - one byte, no query.
+					const int      e    = p + (int) c - 1;
+					const bool     down = c >= 1u && e < n && (uint32_t) s_t[at(min(e, n - 1), line)] <= c - 1u;
+					const uint32_t w0   = rmq(max(p - (int) c, 0), min(p + (int) c, n - 1));
+					c                   = down ? c - 1u : (w0 <= c ? c : c + 1u);
 					s_t[kOut + at(p, line)] = (uint8_t) c;
 				}
 			}
