@@ -493,7 +493,9 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 	constexpr int kPitch = XAXIS ? SEG + 4 : XT;        // x pass: one dword of padding per line spreads the lines over the LDS banks
 	constexpr int kLevel = XAXIS ? XT * kPitch : SEG * XT, kOut = 9 * kLevel;
 	__shared__ __align__(16) uint8_t s_t[(MODE == 2 ? 11 : 10) * kLevel];
-	const uint32_t cx = blockIdx.x % chunks_x, cp = (blockIdx.x / chunks_x) % chunks_p, other = blockIdx.x / (chunks_x * chunks_p);
+	// neighbouring line groups read and write parts of the same 128-byte lines: give each XCD (own L2) a contiguous range of them
+	const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+	const uint32_t cx = bid % chunks_x, cp = (bid / chunks_x) % chunks_p, other = bid / (chunks_x * chunks_p);
 	const int      out0 = (int) cp * ch, out1 = min(len, out0 + ch);
 	const int      seg0 = max(0, out0 - 255), n = min(len, out1 + 255) - seg0;        // staged cells [seg0, seg0 + n), n <= SEG
 	const int      t      = (int) threadIdx.x;
