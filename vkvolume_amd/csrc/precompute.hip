@@ -663,7 +663,9 @@ __global__ void __launch_bounds__(256) k_pack_volume_tiled(const uint8_t *__rest
 {
 	constexpr int kTX = 36, kRows = 81;        // tile: [9][9][36] texels of (v | g << 8); 33 used in x
 	__shared__ uint16_t s_tile[kRows * kTX];
-	const int bx0 = (int) (blockIdx.x % groups_x) * 8, by0 = (int) (blockIdx.x / groups_x) * 2, bz0 = (int) blockIdx.y * 2;
+	// x-neighbouring workgroups stage parts of the same 128-byte lines: consecutive groups go to one XCD (own L2)
+	const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+	const int      bx0 = (int) (bid % groups_x) * 8, by0 = (int) (bid / groups_x) * 2, bz0 = (int) blockIdx.y * 2;
 	const int wd  = W >> 2;
 	// ---- stage: row = (jz, jy) of the padded tile, 9 dwords per row starting one dword left of the tile
 	for (int it = threadIdx.x; it < kRows * 9; it += 256)
