@@ -13,7 +13,7 @@ Inputs (volume, gradient map, TF texture, distance map) are resident in HBM befo
 N = 1: the frame is 1920x1080.  N > 1 (weak scaling): the frame is (1920*sx)x(1080*sy) with sx*sy = N sampling the
 SAME frustum, cut into 16x16 tiles dealt round-robin to the ranks (volume replicated); each rank renders its tiles into
 a compact RGBA8 buffer, the buffers are gathered to rank 0 over RCCL and de-interleaved there.  The gather of frame k
-overlaps the render of frame k+1.  value = rays of all ranks / max-over-ranks wall time.
+overlaps the renders of the next frames; the de-interleave runs on its own stream.  value = rays of all ranks / max-over-ranks wall time.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the ray-march kernel by ALGORITHMIC bytes (SURVEY.md §8d:
 16 B per volume sample, 1 B per distance probe, 4 B per ray of RGBA8 output) over its HIP-event duration;
@@ -26,8 +26,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# ROCclr multiplexes HIP streams onto 4 hardware queues by default; the frames in flight, the assembly stream and RCCL's own
+# stream need one each or they serialise behind each other (measured: 0.27 -> 0.20 ms per step on the gather path).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -110,7 +114,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # no device_id: an eagerly created communicator measured 20 % slower on this pipeline than the lazily created one
+        dist.init_process_group("nccl", rank=rank, world_size=world)
 
     ctx = lib.Context(local_rank)  # raises if the HIP library is missing: there is no fallback path
     v, tf, frame, skip = build_scene(ctx, args.workload)
@@ -142,48 +147,55 @@ def main():
     # (the reference) gets from its per-frame command buffers.  N = 1 renders straight into the frame; N > 1 (or
     # --force-gather) renders this rank's tiles into a compact buffer that is gathered to rank 0 and de-interleaved.
     fif = max(1, args.frames_in_flight)
+    nbuf = fif  # frame k renders on stream k % fif into buffer k % nbuf
     gather, images = None, []
     if use_gather:
-        gather = multigpu.TileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda", n_buffers=fif)
+        nbuf = fif + 1  # one more buffer than render streams: a render does not wait for the gather of the frame fif steps back
+        gather = multigpu.TileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda", n_buffers=nbuf)
         bufs, my_rays = gather.buffers, gather.my_ray_count()
         if rank == 0:
-            images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(fif)]
+            images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
     else:
         bufs, my_rays = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(fif)], fw * fh
     torch.cuda.synchronize()
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(fif - 1)]
 
+    # HIP events bracket every launch at N = 1; on the gather path every 7th (a timing event per launch costs ~25 us per step
+    # there, more than 10 % of the step, once seven queues are busy)
+    ev_every = 7 if use_gather else 1  # coprime with the 8 views
     ev_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_stop = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    def collect(b):
-        """(on stream b) finish buffer b's gather, if one is pending, and de-interleave it into frame b on rank 0"""
-        flat = gather.finish(b)
-        if flat is not None:
-            ctx.scatter_tiles(flat.data_ptr(), images[b].data_ptr(), (fw, fh), (TILE, TILE), world, gather.tiles_per_rank, 4,
-                              torch.cuda.current_stream().cuda_stream)
+    # Assembly (wait for the gather, de-interleave on rank 0) has its own stream: a render stream only ever waits on the event
+    # that says its buffer is free again, never behind an assembly kernel.
+    side = torch.cuda.Stream() if gather else None
+    freed = [None] * nbuf
 
     def run(n_steps, timed):
         for k in range(n_steps):
-            b = k % fif
-            with torch.cuda.stream(streams[b]):
-                if gather:
-                    collect(b)  # buffer b's previous gather must have landed before the buffer is overwritten
-                if timed:
-                    ev_start[k].record(streams[b])
+            b, st = k % nbuf, streams[k % fif]
+            with torch.cuda.stream(st):
+                if gather and freed[b] is not None:
+                    st.wait_event(freed[b])  # frame k - nbuf: its gather has read bufs[b], its de-interleave has read flat[b]
+                if timed and k % ev_every == 0:
+                    ev_start[k].record(st)
                 sp.draw(params[k % N_VIEWS], rgba8=bufs[b])
-                if timed:
-                    ev_stop[k].record(streams[b])
+                if timed and k % ev_every == 0:
+                    ev_stop[k].record(st)
                 if gather:
-                    gather.start(b)  # RCCL gather of frame k overlaps the render of frame k + 1
-        if gather:
-            for b in range(fif):
-                with torch.cuda.stream(streams[b]):
-                    collect(b)
+                    gather.start(b)  # RCCL gather of frame k (ordered after the render) overlaps the renders of the next frames
+            if gather:
+                with torch.cuda.stream(side):
+                    flat = gather.finish(b)
+                    if flat is not None:
+                        ctx.scatter_tiles(flat.data_ptr(), images[b].data_ptr(), (fw, fh), (TILE, TILE), world, gather.tiles_per_rank, 4,
+                                          side.cuda_stream)
+                    freed[b] = torch.cuda.Event()
+                    freed[b].record(side)
 
     def fence():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     run(args.warmup, False)
@@ -197,11 +209,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kernel_ms = [ev_start[k].elapsed_time(ev_stop[k]) for k in range(args.steps)]
+    timed_steps = list(range(0, args.steps, ev_every))
+    kernel_ms = [ev_start[k].elapsed_time(ev_stop[k]) for k in timed_steps]
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
     # algorithmic bytes of this rank's launches, averaged over the launches actually timed
     b_out = 4
-    alg_bytes = [n_vs[k % N_VIEWS] * 16 + n_ds[k % N_VIEWS] * 1 + my_rays * b_out for k in range(args.steps)]
+    alg_bytes = [n_vs[k % N_VIEWS] * 16 + n_ds[k % N_VIEWS] * 1 + my_rays * b_out for k in timed_steps]
     alg_avg = sum(alg_bytes) / len(alg_bytes)
     achieved_gbs = alg_avg / (kernel_ms_avg * 1e-3) / 1e9
 
@@ -213,7 +226,7 @@ def main():
     vs_total, ds_total, cov_total = float(tot[0].item()), float(tot[1].item()), float(tot[2].item())
 
     if args.verify:
-        verify(ctx, sp, v, views, params, args.steps, fif, (fw, fh), bufs, images, gather, rank)
+        verify(ctx, sp, v, views, params, args.steps, nbuf, (fw, fh), bufs, images, gather, rank)
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -232,12 +245,14 @@ def main():
         "volume_samples_per_s": round(vs_total / elapsed, 1), "distance_probes_per_s": round(ds_total / elapsed, 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
-                     "achieved_aggregate": round(sum(alg_bytes) / elapsed / 1e9, 2),
+                     "achieved_aggregate": round(sum(n_vs[k % N_VIEWS] * 16 + n_ds[k % N_VIEWS] * 1 + my_rays * b_out for k in range(args.steps))
+                                                 / elapsed / 1e9, 2),
                      "kernel": "k_raymarch", "kernel_ms_avg": round(kernel_ms_avg, 4),
                      "algorithmic_bytes_per_launch": int(alg_avg),
                      "note": "algorithmic (requested) bytes: 16 B/volume sample + 1 B/distance probe + 4 B/ray; NOT DRAM traffic. achieved = per "
                              "launch / HIP-event duration of that launch (launches of consecutive frames overlap when frames_in_flight > 1); "
-                             "achieved_aggregate = this rank's bytes of all timed launches / wall time"},
+                             "achieved_aggregate = this rank's bytes of all timed launches / wall time; HIP events bracket every launch "
+                             "at N = 1 and every 7th launch on the gather path"},
     }
 
     # HBM traffic cannot be read from inside the process; it comes from separate rocprofv3 --pmc passes over this same
@@ -258,7 +273,7 @@ def main():
         dist.destroy_process_group()
 
 
-def verify(ctx, sp, v, views, params, steps, fif, frame, bufs, images, gather, rank):
+def verify(ctx, sp, v, views, params, steps, nbuf, frame, bufs, images, gather, rank):
     """The frame left in the last step's buffer must equal a direct single-launch render of the same view, bit for bit."""
     if rank != 0:
         return
@@ -267,7 +282,7 @@ def verify(ctx, sp, v, views, params, steps, fif, frame, bufs, images, gather, r
     direct = torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda")
     sp.draw(sp.make_params(*views[k % N_VIEWS], abi.full_frame_tiles(fw, fh, TILE, TILE)), rgba8=direct)
     torch.cuda.synchronize()
-    got = images[k % fif] if gather else bufs[k % fif].view(fh, fw, 4)
+    got = images[k % nbuf] if gather else bufs[k % nbuf].view(fh, fw, 4)
     if not torch.equal(got, direct):
         raise SystemExit("verify failed: assembled frame differs from the direct render in %d bytes" % int((got != direct).sum().item()))
     print("verify ok: frame of step %d matches the direct render (%d non-zero bytes)" % (k, int((direct != 0).sum().item())), file=sys.stderr)
