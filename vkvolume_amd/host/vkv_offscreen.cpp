@@ -8,6 +8,7 @@
 //                 [--azimuth=DEG --elevation=DEG] [--dump-rgba8=file] [--dump-counts=file] [--dump-params=file]
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -33,6 +34,7 @@ struct Args
 	uint32_t    blocksize = 4, skipmode = 2;                             // :71-80
 	bool        gradient_test = false;
 	int         benchmark     = 0;
+	int         frames_in_flight = 3;        // benchmark mode: frames rendered concurrently, like the reference's swap-chain images
 	std::string dataset;
 	std::string synthetic;
 	float       azimuth = 30.0f, elevation = 20.0f;
@@ -74,6 +76,7 @@ Args parse(int argc, char **argv)
 		else if (flag(s, "--skipmode", v)) { const uint32_t m = (uint32_t) std::stoul(v); if (m <= 3) a.skipmode = m; }
 		else if (flag(s, "--gradient_test", v)) a.gradient_test = true;
 		else if (flag(s, "--benchmark", v)) a.benchmark = std::stoi(v);
+		else if (flag(s, "--frames-in-flight", v)) a.frames_in_flight = std::max(1, std::stoi(v));
 		else if (flag(s, "--synthetic", v)) a.synthetic = v;
 		else if (flag(s, "--azimuth", v)) a.azimuth = std::stof(v);
 		else if (flag(s, "--elevation", v)) a.elevation = std::stof(v);
@@ -231,14 +234,41 @@ int main(int argc, char **argv)
 		target.counts         = device_alloc<uint32_t>(n_pixels * 3);
 
 		const int frames = benchmark ? args.benchmark : 1;
-		subpass.draw(target);        // warm-up
+		subpass.draw(target);        // warm-up (and the frame the dumps below read)
 		(void) hipStreamSynchronize(stream);
-		const auto t0 = std::chrono::steady_clock::now();
-		for (int f = 0; f < frames; ++f)
-			subpass.draw(target);
-		(void) hipStreamSynchronize(stream);
-		const double ms = ms_since(t0);
-		std::printf("ran %d frames, averaged %g fps\n", frames, 1000.0 * frames / ms);
+		{
+			// Benchmark frames go round-robin over a few HIP streams, each with its own colour target - what the reference gets from
+			// its per-swap-chain-image command buffers: the long tail of one frame overlaps the start of the next.
+			const int                fif = benchmark ? args.frames_in_flight : 1;
+			std::vector<hipStream_t> streams(fif, stream);
+			std::vector<RenderTarget> targets(fif, target);
+			for (int i = 0; i < fif; ++i)
+			{
+				targets[i].counts = nullptr;        // the frag's counters are test-mode outputs, not part of a frame
+				if (i > 0)
+				{
+					if (hipStreamCreate(&streams[i]) != hipSuccess)
+						throw std::runtime_error("hipStreamCreate failed");
+					targets[i].rgba8 = device_alloc<uint8_t>(n_pixels * 4);
+				}
+			}
+			const auto t0 = std::chrono::steady_clock::now();
+			for (int f = 0; f < frames; ++f)
+			{
+				dc.stream = streams[f % fif];
+				subpass.draw(benchmark ? targets[f % fif] : target);
+			}
+			for (int i = 0; i < fif; ++i)
+				(void) hipStreamSynchronize(streams[i]);
+			const double ms = ms_since(t0);
+			dc.stream       = stream;
+			std::printf("ran %d frames, averaged %g fps\n", frames, 1000.0 * frames / ms);
+			for (int i = 1; i < fif; ++i)
+			{
+				(void) hipFree(targets[i].rgba8);
+				(void) hipStreamDestroy(streams[i]);
+			}
+		}
 
 		if (!args.dump_params.empty())
 		{        // the exact parameter block draw() handed to vkv_render (device pointers included), for the parity tests
