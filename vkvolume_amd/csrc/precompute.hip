@@ -504,11 +504,11 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 	const int      n4     = (n + 3) & ~3;        // x pass: the tail of the last dword of a line is padded with 255
 	// staging / write-out: iteration q of a thread is cell (line, p); x pass: threads run along the row, rows one after the other;
 	// y / z pass: 256 / XT cell rows of XT lines at a time
-	const int per_line = (n4 + 255) / 256;
-	const int n_iter   = XAXIS ? XT * per_line : (n + 256 / XT - 1) / (256 / XT);
-	auto      cell     = [&](int q, int &line, int &p) {
+	constexpr int kPerLine = SEG / 256 > 0 ? SEG / 256 : 1;        // x pass: 256-cell pieces per line (compile-time: no division in the loops)
+	const int     n_iter   = XAXIS ? XT * kPerLine : (n + 256 / XT - 1) / (256 / XT);
+	auto          cell     = [&](int q, int &line, int &p) {
 		if (XAXIS)
-			line = q / per_line, p = t + 256 * (q % per_line);
+			line = q / kPerLine, p = t + 256 * (q % kPerLine);        // pieces past the end of the line fail the p < n tests below
 		else
 			line = t % XT, p = t / XT + q * (256 / XT);
 	};
