@@ -57,12 +57,22 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
 	const int      wd = W >> 2;        // dwords per row
 	// ---- stage: 100 rows x 18 dwords; rows clamp in y and z, dword columns clamp in x (the two x-border bytes are patched below)
 	constexpr int kRows = (kGradTileZ + 2) * (kGradTileY + 2), kCols = kGradPitch / 4;
-	for (int d = threadIdx.x; d < kRows * kCols; d += 256)
 	{
-		const int row = d / kCols, col = d - row * kCols;
-		const int gy = min(max(y0 - 1 + row % (kGradTileY + 2), 0), H - 1), gz = min(max(z0 - 1 + row / (kGradTileY + 2), 0), D - 1);
-		const int gc = min(max((x0 >> 2) - 1 + col, 0), wd - 1);
-		reinterpret_cast<uint32_t *>(s_tile)[d] = reinterpret_cast<const uint32_t *>(vol + ((size_t) gz * H + gy) * (size_t) W)[gc];
+		constexpr int kIter = (kRows * kCols + 255) / 256;        // 8 dwords per thread, all in flight before the first LDS store
+		uint32_t      v[kIter];
+#pragma unroll
+		for (int j = 0; j < kIter; ++j)
+		{
+			const int d   = min((int) threadIdx.x + 256 * j, kRows * kCols - 1);
+			const int row = d / kCols, col = d - row * kCols;
+			const int gy = min(max(y0 - 1 + row % (kGradTileY + 2), 0), H - 1), gz = min(max(z0 - 1 + row / (kGradTileY + 2), 0), D - 1);
+			const int gc = min(max((x0 >> 2) - 1 + col, 0), wd - 1);
+			v[j]         = reinterpret_cast<const uint32_t *>(vol + ((size_t) gz * H + gy) * (size_t) W)[gc];
+		}
+#pragma unroll
+		for (int j = 0; j < kIter; ++j)
+			if ((int) threadIdx.x + 256 * j < kRows * kCols)
+				reinterpret_cast<uint32_t *>(s_tile)[threadIdx.x + 256 * j] = v[j];
 	}
 	__syncthreads();
 	// clamp-to-edge in x: byte x = -1 must equal voxel 0, byte x = W must equal voxel W-1
@@ -141,21 +151,30 @@ __global__ void __launch_bounds__(256) k_occupancy_map_dword_any(const uint8_t *
 	const int nd    = (min(cpb * bx, W - x0) + 3) >> 2;        // dwords of the span (W % 4 == 0: never past the row)
 	for (int d = threadIdx.x; d < nd; d += 256)
 	{
-		const int xd  = (x0 >> 2) + d;
-		uint32_t  occ = 0;
-		for (int z = cz * bz; z < z_end; ++z)
-			for (int y = cy * by; y < y_end; ++y)
+		const int     xd     = (x0 >> 2) + d;
+		uint32_t      occ    = 0;
+		constexpr int kBatch = 8;        // rows fetched together (see k_occupancy_map_dword)
+		const int     ny = y_end - cy * by, n_rows = ny * (z_end - cz * bz);
+		for (int r0 = 0; r0 < n_rows; r0 += kBatch)
+		{
+			uint32_t v4[kBatch], g4[kBatch];
+#pragma unroll
+			for (int j = 0; j < kBatch; ++j)
 			{
-				const size_t   row = ((size_t) z * H + y) * (size_t) W;
-				const uint32_t v4  = reinterpret_cast<const uint32_t *>(vol + row)[xd];
-				const uint32_t g4  = GRAD == 1 ? reinterpret_cast<const uint32_t *>(grad + row)[xd] : 0xffffffffu;
+				const int    r   = min(r0 + j, n_rows - 1);
+				const size_t row = ((size_t) (cz * bz + r / ny) * H + (size_t) (cy * by + r % ny)) * (size_t) W;
+				v4[j]            = reinterpret_cast<const uint32_t *>(vol + row)[xd];
+				g4[j]            = GRAD == 1 ? reinterpret_cast<const uint32_t *>(grad + row)[xd] : 0xffffffffu;
+			}
+#pragma unroll
+			for (int j = 0; j < kBatch; ++j)
 #pragma unroll
 				for (int i = 0; i < 4; ++i)
 				{
-					const uint32_t bit = ((g4 >> (8 * i)) & 255u) * 256u + ((v4 >> (8 * i)) & 255u);
+					const uint32_t bit = ((g4[j] >> (8 * i)) & 255u) * 256u + ((v4[j] >> (8 * i)) & 255u);
 					occ |= ((s_bits[bit >> 5] >> (bit & 31u)) & 1u) << i;
 				}
-			}
+		}
 		if (occ)
 		{
 			int cell = (4 * d) / bx, in = (4 * d) - cell * bx;
@@ -245,19 +264,31 @@ __global__ void __launch_bounds__(256) k_occupancy_map_dword(const uint8_t *__re
 		return;
 	const int y_end = min((cy + 1) * by, H), z_end = min((cz + 1) * bz, D);
 	uint32_t  occ   = 0;        // bit i: voxel 4*xd + i of some row is occupied
-	for (int z = cz * bz; z < z_end; ++z)
-		for (int y = cy * by; y < y_end; ++y)
+	// the by x bz rows of the cell are fetched eight at a time (16 loads in flight per lane: the kernel is a pure stream and
+	// bandwidth = bytes in flight / latency)
+	constexpr int kBatch = 8;
+	const int     ny = y_end - cy * by, n_rows = ny * (z_end - cz * bz);
+	for (int r0 = 0; r0 < n_rows; r0 += kBatch)
+	{
+		uint32_t v4[kBatch], g4[kBatch];
+#pragma unroll
+		for (int j = 0; j < kBatch; ++j)
 		{
-			const size_t   row = ((size_t) z * H + y) * (size_t) W;
-			const uint32_t v4  = reinterpret_cast<const uint32_t *>(vol + row)[xd];
-			const uint32_t g4  = GRAD == 1 ? reinterpret_cast<const uint32_t *>(grad + row)[xd] : 0xffffffffu;        // gradient 1.0 -> texel 255
+			const int    r   = min(r0 + j, n_rows - 1);        // the tail repeats the last row (idempotent OR)
+			const int    z   = cz * bz + r / ny, y = cy * by + r % ny;
+			const size_t row = ((size_t) z * H + y) * (size_t) W;
+			v4[j]            = reinterpret_cast<const uint32_t *>(vol + row)[xd];
+			g4[j]            = GRAD == 1 ? reinterpret_cast<const uint32_t *>(grad + row)[xd] : 0xffffffffu;        // gradient 1.0 -> texel 255
+		}
+#pragma unroll
+		for (int j = 0; j < kBatch; ++j)
 #pragma unroll
 			for (int i = 0; i < 4; ++i)
 			{
-				const uint32_t bit = ((g4 >> (8 * i)) & 255u) * 256u + ((v4 >> (8 * i)) & 255u);
+				const uint32_t bit = ((g4[j] >> (8 * i)) & 255u) * 256u + ((v4[j] >> (8 * i)) & 255u);
 				occ |= ((s_bits[bit >> 5] >> (bit & 31u)) & 1u) << i;
 			}
-		}
+	}
 	constexpr int      kCells = 4 / BX;
 	constexpr uint32_t kMask  = (1u << BX) - 1u;
 	uint8_t *          out    = map + ((size_t) cz * mh + cy) * (size_t) mw + (size_t) xd * kCells;
@@ -310,25 +341,34 @@ __global__ void __launch_bounds__(256) k_occupied_voxel_count(const uint8_t *__r
 	uint32_t       n    = 0;
 	if (GRAD != 2 && DWORDS)
 	{        // dword-aligned rows: one lane tests 4 voxels per load (256 contiguous bytes per wave-load)
-		const int xd = (int) (bx * 64 + (threadIdx.x & 63));        // dword column
-		for (uint32_t rg = blockIdx.x / blocks_x; rg < n_row_groups; rg += gridDim.x / blocks_x)
-		{
-			const uint32_t row = rg * 4 + (threadIdx.x >> 6);
-			uint32_t       c   = 0;
-			if (xd * 4 < W && row < rows)
+		const int      xd     = (int) (bx * 64 + (threadIdx.x & 63));        // dword column
+		const uint32_t stride = gridDim.x / blocks_x;
+		constexpr int  kBatch = 8;        // row groups fetched together: 16 loads in flight per lane
+		if (xd * 4 < W)
+			for (uint32_t rg0 = blockIdx.x / blocks_x; rg0 < n_row_groups; rg0 += stride * kBatch)
 			{
-				const size_t   o  = (size_t) row * (size_t) W;
-				const uint32_t v4 = reinterpret_cast<const uint32_t *>(vol + o)[xd];
-				const uint32_t g4 = GRAD == 1 ? reinterpret_cast<const uint32_t *>(grad + o)[xd] : 0xffffffffu;
+				uint32_t v4[kBatch], g4[kBatch];
 #pragma unroll
-				for (int i = 0; i < 4; ++i)
+				for (int j = 0; j < kBatch; ++j)
 				{
-					const uint32_t bit = ((g4 >> (8 * i)) & 255u) * 256u + ((v4 >> (8 * i)) & 255u);
-					c += (s_bits[bit >> 5] >> (bit & 31u)) & 1u;
+					const uint32_t row = (rg0 + (uint32_t) j * stride) * 4 + (threadIdx.x >> 6);
+					const bool     ok  = rg0 + (uint32_t) j * stride < n_row_groups && row < rows;
+					const size_t   o   = (size_t) (ok ? row : 0u) * (size_t) W;
+					v4[j]              = ok ? reinterpret_cast<const uint32_t *>(vol + o)[xd] : 0u;
+					g4[j]              = (ok && GRAD == 1) ? reinterpret_cast<const uint32_t *>(grad + o)[xd] : (ok ? 0xffffffffu : 0u);
+				}
+#pragma unroll
+				for (int j = 0; j < kBatch; ++j)
+				{
+					const bool ok = rg0 + (uint32_t) j * stride < n_row_groups && (rg0 + (uint32_t) j * stride) * 4 + (threadIdx.x >> 6) < rows;
+#pragma unroll
+					for (int i = 0; i < 4; ++i)
+					{
+						const uint32_t bit = ((g4[j] >> (8 * i)) & 255u) * 256u + ((v4[j] >> (8 * i)) & 255u);
+						n += ok ? (s_bits[bit >> 5] >> (bit & 31u)) & 1u : 0u;        // per-lane partial sums, reduced below
+					}
 				}
 			}
-			n += c;        // per-lane partial sums, reduced below
-		}
 		for (int o2 = 32; o2 > 0; o2 >>= 1)
 			n += (uint32_t) __shfl_xor((int) n, o2);
 	}
