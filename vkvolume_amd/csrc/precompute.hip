@@ -708,20 +708,34 @@ __global__ void __launch_bounds__(256) k_pack_volume_tiled(const uint8_t *__rest
 	const int      bx0 = (int) (bid % groups_x) * 8, by0 = (int) (bid / groups_x) * 2, bz0 = (int) blockIdx.y * 2;
 	const int wd  = W >> 2;
 	// ---- stage: row = (jz, jy) of the padded tile, 9 dwords per row starting one dword left of the tile
-	for (int it = threadIdx.x; it < kRows * 9; it += 256)
 	{
-		const int row = it / 9, c = it - row * 9;
-		const int y = min(max(by0 * 4 + row % 9 - 1, 0), H - 1), z = min(max(bz0 * 4 + row / 9 - 1, 0), D - 1);
-		const int dc = min(max(bx0 - 1 + c, 0), wd - 1);
-		const size_t   o  = ((size_t) z * H + y) * (size_t) W;
-		const uint32_t v4 = reinterpret_cast<const uint32_t *>(vol + o)[dc];
-		const uint32_t g4 = grad ? reinterpret_cast<const uint32_t *>(grad + o)[dc] : 0u;
+		constexpr int kIter = (kRows * 9 + 255) / 256;        // 3 x 2 dwords per thread, all in flight before the first LDS store
+		uint32_t      v4[kIter], g4[kIter];
 #pragma unroll
-		for (int k = 0; k < 4; ++k)
+		for (int j = 0; j < kIter; ++j)
 		{
-			const int jx = 4 * c - 3 + k;        // padded tile column of voxel x = 4 * (bx0 - 1 + c) + k
-			if (jx >= 0 && jx <= 32)
-				s_tile[row * kTX + jx] = (uint16_t) (((v4 >> (8 * k)) & 255u) | (((g4 >> (8 * k)) & 255u) << 8));
+			const int it  = min((int) threadIdx.x + 256 * j, kRows * 9 - 1);
+			const int row = it / 9, c = it - row * 9;
+			const int y = min(max(by0 * 4 + row % 9 - 1, 0), H - 1), z = min(max(bz0 * 4 + row / 9 - 1, 0), D - 1);
+			const int dc = min(max(bx0 - 1 + c, 0), wd - 1);
+			const size_t o = ((size_t) z * H + y) * (size_t) W;
+			v4[j]          = reinterpret_cast<const uint32_t *>(vol + o)[dc];
+			g4[j]          = grad ? reinterpret_cast<const uint32_t *>(grad + o)[dc] : 0u;
+		}
+#pragma unroll
+		for (int j = 0; j < kIter; ++j)
+		{
+			const int it = (int) threadIdx.x + 256 * j;
+			if (it >= kRows * 9)
+				break;
+			const int row = it / 9, c = it - row * 9;
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+			{
+				const int jx = 4 * c - 3 + k;        // padded tile column of voxel x = 4 * (bx0 - 1 + c) + k
+				if (jx >= 0 && jx <= 32)
+					s_tile[row * kTX + jx] = (uint16_t) (((v4[j] >> (8 * k)) & 255u) | (((g4[j] >> (8 * k)) & 255u) << 8));
+			}
 		}
 	}
 	__syncthreads();
@@ -739,25 +753,25 @@ __global__ void __launch_bounds__(256) k_pack_volume_tiled(const uint8_t *__rest
 		}
 		__syncthreads();
 	}
-	// ---- write: 32 bricks x 64 dwords
-	for (int it = threadIdx.x; it < 32 * 64; it += 256)
+	// ---- write: 32 bricks x 16 pieces of 16 bytes (a store instruction costs the same per lane whatever its width)
+	for (int it = threadIdx.x; it < 32 * 16; it += 256)
 	{
-		const int b = it >> 6, d = it & 63;
+		const int b = it >> 4, q = it & 15;
 		const int bx = bx0 + (b & 7), by = by0 + ((b >> 3) & 1), bz = bz0 + (b >> 4);
 		if (bx >= pd.bx || by >= pd.by || bz >= pd.bz)
 			continue;
-		uint32_t word = 0;
+		uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
-		for (int h = 0; h < 2; ++h)
+		for (int k = 0; k < 8; ++k)
 		{
-			const int t = 2 * d + h;
+			const int t = 8 * q + k;        // texel of the 5^3 brick, x fastest; 125..127 are padding
 			if (t < 125)
 			{
 				const int lx = t % 5, ly = (t / 5) % 5, lz = t / 25;
-				word |= (uint32_t) s_tile[(((b >> 4) * 4 + lz) * 9 + ((b >> 3) & 1) * 4 + ly) * kTX + (b & 7) * 4 + lx] << (16 * h);
+				w[k >> 1] |= (uint32_t) s_tile[(((b >> 4) * 4 + lz) * 9 + ((b >> 3) & 1) * 4 + ly) * kTX + (b & 7) * 4 + lx] << (16 * (k & 1));
 			}
 		}
-		reinterpret_cast<uint32_t *>(packed + packed_brick_offset(bx, by, bz, pd.mx, pd.my))[d] = word;
+		reinterpret_cast<uint4 *>(packed + packed_brick_offset(bx, by, bz, pd.mx, pd.my))[q] = make_uint4(w[0], w[1], w[2], w[3]);
 	}
 }
 
