@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(256) k_pack_volume(const uint8_t *__restrict__
 // workgroup builds in LDS four cells per operation.  Results of neighbouring cells differ by at most one (two-sided) or follow
 // from the neighbour with one window test (one-sided), so a thread bisects only the first cell of its run and walks the rest.
 // History: a data-dependent search out of an LDS strip (1.4 ms for the three C3 passes), then an O(N) monotone-deque sweep per
-// column (0.66 ms: 51 K serial sweeps whose LDS round trips sit on one dependency chain), now 0.17 ms.
+// column (0.66 ms: 51 K serial sweeps whose LDS round trips sit on one dependency chain), now 0.13 ms.
 // A workgroup takes XT lines and a run of the axis: the whole line when it fits SEG cells, else `ch` outputs plus 255 cells of
 // halo on both sides (a candidate further away can never win: the result never exceeds g(p) <= 255).
 // MODE 0: two-sided, +1 / -1: candidates at higher / lower index, 2: both one-sided results from one table (dst = +1,
@@ -524,7 +524,7 @@ __device__ __forceinline__ uint32_t min_u8x4(uint32_t a, uint32_t b)
 
 template <int MODE, int XT, int SEG, bool XAXIS>
 __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst, uint8_t *dst2, uint32_t n_lines, int len,
-                                                size_t line_stride, size_t axis_stride, size_t other_stride, uint32_t chunks_x, uint32_t chunks_p, int ch)
+                                                size_t line_stride, size_t axis_stride, size_t other_stride, uint32_t chunks_x, uint32_t chunks_p, int ch, int vec)
 {
 	// A line is one run of the axis; the workgroup owns lines cx * XT .. + XT of group `other`:
 	//   y / z pass: lines = consecutive x (line_stride 1), LDS index p * XT + line (a dword = 4 lines of one cell row)
@@ -552,6 +552,34 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 		else
 			line = t % XT, p = t / XT + q * (256 / XT);
 	};
+	// `vec`: every group of XT lines (y / z pass, XT = 16: one 16-byte row segment) or every 4 cells of a line (x pass) is an aligned
+	// vector in memory and in the LDS layout - one load / store instruction moves what 16 / 4 byte-wide ones would
+	if (vec && !XAXIS)
+	{
+		for (int p = t; p < n; p += 256)
+			*reinterpret_cast<uint4 *>(s_t + p * XT) = *reinterpret_cast<const uint4 *>(src + base + (size_t) p * axis_stride);
+	}
+	else if (vec)
+	{
+		constexpr int kDw = SEG / 4, kIter = XT * kDw / 256;
+		uint32_t      v[kIter];
+#pragma unroll
+		for (int j = 0; j < kIter; ++j)
+		{
+			const int  idx = t + 256 * j, line = idx / kDw, e = idx % kDw;
+			const bool ok  = 4 * e < n && cx * XT + (uint32_t) line < n_lines;
+			v[j]           = ok ? *reinterpret_cast<const uint32_t *>(src + base + (size_t) line * line_stride + (size_t) (4 * e)) : 0xffffffffu;
+		}
+#pragma unroll
+		for (int j = 0; j < kIter; ++j)
+		{
+			const int idx = t + 256 * j, line = idx / kDw, e = idx % kDw;
+			if (4 * e < n4)
+				*reinterpret_cast<uint32_t *>(s_t + line * kPitch + 4 * e) = v[j];
+		}
+	}
+	else
+	{
 	constexpr int kBatch = 8;        // loads in flight per thread
 	for (int q0 = 0; q0 < n_iter; q0 += kBatch)
 	{
@@ -572,6 +600,7 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 			if (q0 + j < n_iter && p < (XAXIS ? n4 : n))
 				s_t[at(p, line)] = v[j];
 		}
+	}
 	}
 	__syncthreads();
 	// ---- sparse table, four cells per operation ------------------------------------------------------------------
@@ -683,6 +712,33 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 		}
 	}
 	__syncthreads();
+	if (vec && !XAXIS)
+	{
+		for (int p = out0 - seg0 + t; p < out1 - seg0; p += 256)
+		{
+			const size_t o = base + (size_t) p * axis_stride;
+			*reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(s_t + kOut + p * XT);
+			if (MODE == 2)
+				*reinterpret_cast<uint4 *>(dst2 + o) = *reinterpret_cast<const uint4 *>(s_t + kOut + kLevel + p * XT);
+		}
+		return;
+	}
+	if (vec)
+	{        // x pass, whole lines (out0 = seg0 = 0, n = len, 4 | n)
+		constexpr int kDw = SEG / 4, kIter = XT * kDw / 256;
+#pragma unroll
+		for (int j = 0; j < kIter; ++j)
+		{
+			const int idx = t + 256 * j, line = idx / kDw, e = idx % kDw;
+			if (4 * e >= n || cx * XT + (uint32_t) line >= n_lines)
+				continue;
+			const size_t o = base + (size_t) line * line_stride + (size_t) (4 * e);
+			*reinterpret_cast<uint32_t *>(dst + o) = *reinterpret_cast<const uint32_t *>(s_t + kOut + line * kPitch + 4 * e);
+			if (MODE == 2)
+				*reinterpret_cast<uint32_t *>(dst2 + o) = *reinterpret_cast<const uint32_t *>(s_t + kOut + kLevel + line * kPitch + 4 * e);
+		}
+		return;
+	}
 	for (int q = 0; q < n_iter; ++q)
 	{
 		int line, p;
@@ -1066,8 +1122,11 @@ static int launch_dm_rmq(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *ds
 		const uint32_t chunks_p = (uint32_t) ((len + ch - 1) / ch), chunks_x = (n_lines + (XT) -1) / (XT);                                              \
 		if ((uint64_t) chunks_x * chunks_p * other > 0x7fffffffull)                                                                                     \
 			return set_error(ctx, VKV_E_UNSUPPORTED, "distance_map: map too large for one launch");                                                     \
+		const uintptr_t al = (uintptr_t) src | (uintptr_t) dst | (uintptr_t) dst2;                                                                      \
+		const int vec = (XAXIS) ? (chunks_p == 1 && (me.width & 3u) == 0 && (al & 3u) == 0)                                                             \
+		                        : ((XT) == 16 && (me.width & 15u) == 0 && (al & 15u) == 0);                                                              \
 		hipLaunchKernelGGL((k_dm_rmq<MODE, XT, SEG, XAXIS>), dim3(chunks_x * chunks_p * other), dim3(256), 0, s, src, dst, dst2, n_lines, len, ls, as,  \
-		                   os, chunks_x, chunks_p, ch);                                                                                                 \
+		                   os, chunks_x, chunks_p, ch, vec);                                                                                            \
 	} while (0)
 	if (axis == 0)
 	{
