@@ -1317,7 +1317,13 @@ int launch_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, ui
                          uint32_t tiles_per_rank, uint32_t bpp, hipStream_t s)
 {
 	const dim3 grid((iw + 63) / 64, (ih + 3) / 4);
-	if (bpp == 4)
+	if (bpp == 4 && (iw & 3u) == 0 && (tw & 3u) == 0 && ((((uintptr_t) d_gathered) | ((uintptr_t) d_image)) & 15u) == 0)
+	{        // four RGBA8 pixels per lane: rows of both layouts are whole multiples of 16 bytes, so it is the 16-byte kernel on iw/4 x tw/4
+		const dim3 grid4((iw / 4 + 63) / 64, (ih + 3) / 4);
+		hipLaunchKernelGGL(k_scatter_tiles<uint4>, grid4, dim3(256), 0, s, (const uint4 *) d_gathered, (uint4 *) d_image, iw / 4, ih, tw / 4, th, n_ranks,
+		                   tiles_per_rank);
+	}
+	else if (bpp == 4)
 		hipLaunchKernelGGL(k_scatter_tiles<uint32_t>, grid, dim3(256), 0, s, (const uint32_t *) d_gathered, (uint32_t *) d_image, iw, ih, tw, th, n_ranks,
 		                   tiles_per_rank);
 	else if (bpp == 16)
