@@ -402,3 +402,47 @@ def test_render_depth_attachment_and_blending(ctx, shell_scene, skipping_type, b
     assert np.abs(got_depth[frag] - ref.depth[frag]).max() <= DEPTH_TOL
     if not blend:
         assert frag.all() and np.array_equal(got_depth[:, 2 * third:], in_depth[:, 2 * third:])  # pass-through where discarded
+
+
+# ------------------------------------------------------------------------------------------------------
+# randomised configurations: every knob of the path drawn at random, HIP vs oracle
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(24))
+def test_render_fuzz(ctx, seed):
+    """Random volume shape / content, voxel size and rotation, TF window, sampling and alpha factors, block size, skipping mode, ERT,
+    gradient variant, clip distance, camera (sometimes inside the box) and frame size: counters bit-exact, colour and depth within the
+    stated tolerance (observed 0), and all four {sampling layout} x {scheduler} variants identical (gpu_render)."""
+    rng = np.random.default_rng(1000 + seed)
+    shape = tuple(int(x) for x in rng.integers(5, 46, size=3))  # w, h, d
+    kind = int(rng.integers(0, 3))
+    if kind == 2:
+        vol = T.random_volume(shape, seed=seed, sparsity=float(rng.uniform(0.6, 0.995)))
+    else:
+        vol = O.synth_volume(shape, kind, int(rng.integers(1, 1 << 30)))
+    grad_variant = ("precomputed", "on_the_fly", "no_gradient")[int(rng.integers(0, 3))]
+    imin = float(rng.uniform(0.0, 0.4))
+    tfo = dict(intensity_min=imin, intensity_max=float(rng.uniform(imin + 0.05, 1.0)), sampling_factor=float(rng.choice([0.5, 1.0, 1.0, 1.7, 3.0])),
+               voxel_alpha_factor=float(rng.choice([0.3, 1.0, 1.0, 2.5])))
+    if grad_variant == "no_gradient":
+        opt = abi.VolumeOptions(gradient_min=0.0, gradient_max=0.0, **tfo)
+    else:
+        gmin = float(rng.uniform(0.0, 0.1))
+        opt = abi.VolumeOptions(gradient_min=gmin, gradient_max=float(rng.uniform(gmin + 0.05, 0.6)), use_precomputed_gradient=(grad_variant == "precomputed"), **tfo)
+    block = int(rng.integers(1, 8))
+    voxel = tuple(float(x) for x in rng.uniform(0.2, 2.0, size=3))
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    scene = T.OracleScene(vol, opt, block, voxel_size=voxel, axis_angle=(float(axis[0]), float(axis[1]), float(axis[2]), float(rng.uniform(0, 360))))
+    v, tf = make_gpu_volume(ctx, scene)
+    st = int(rng.integers(0, 4))
+    V.ComputeDistanceMap(ctx).compute(v, tf, st)
+    size = (int(rng.integers(3, 9)) * 16 - int(rng.integers(0, 16)), int(rng.integers(2, 6)) * 16 - int(rng.integers(0, 16)))
+    radius = float(rng.choice([30.0, 60.0, 110.0, 150.0, 260.0]))  # the node is scaled to 100 units: 30 / 60 put the camera inside or at the box
+    view, proj = T.orbit(float(rng.uniform(0, 360)), elevation=float(rng.uniform(-80, 80)), radius=radius, fov=float(rng.uniform(25, 100)), image_size=size)
+    opts = abi.RenderOptions(skipping_type=st, clip_distance=float(rng.choice([0.1, 1.0, 1.0, 20.0, 70.0])), early_ray_termination=bool(rng.integers(0, 2)))
+    params = scene.params(view, proj, size, opts)
+    ref = scene.render(params)
+    compare_render(gpu_render(ctx, v, params), ref, "fuzz %d: shape %s block %d mode %d %s" % (seed, shape, block, st, grad_variant))
+    print("fuzz %d: shape %s block %d mode %d %s ert %d: %d samples, %d probes, %d pixels with colour" % (
+        seed, shape, block, st, grad_variant, opts.early_ray_termination, int(ref.counts[..., 0].sum()), int(ref.counts[..., 1].sum()),
+        int((ref.color[..., 3] > 0).sum())))
