@@ -107,7 +107,9 @@ def sparse_occupancy(shape_dhw, seed, p):
                                          ((300, 290, 70), 0.00001), ((64, 64, 64), 0.3),
                                          # rows > 1024 cells (serial x scan), axes of several chunks, widths around the kernel's line groups
                                          ((2, 3, 1100), 0.002), ((2, 1500, 3), 0.001), ((1300, 2, 17), 0.0004), ((30, 130, 33), 0.001),
-                                         ((3, 5, 1024), 0.0008), ((2, 2, 257), 0.004)])
+                                         ((3, 5, 1024), 0.0008), ((2, 2, 257), 0.004),
+                                         # 16 | width and 128 < axis <= 256: the 16-byte vector staging of the y / z passes
+                                         ((200, 130, 32), 0.0002), ((3, 140, 48), 0.002), ((131, 2, 16), 0.004)])
 def test_distance_map_parity(ctx, shape_dhw, p):
     occ = sparse_occupancy(shape_dhw, 3, p)
     d, h, w = shape_dhw
@@ -122,7 +124,8 @@ def test_distance_map_parity(ctx, shape_dhw, p):
 @pytest.mark.parametrize("shape_dhw,p", [((16, 16, 16), 0.02), ((9, 10, 13), 0.01), ((5, 70, 3), 0.01), ((40, 33, 130), 0.0005),
                                          ((1, 1, 1), 1.0), ((6, 6, 6), 0.0), ((600, 2, 3), 0.0006), ((2, 700, 1), 0.0015), ((90, 280, 70), 0.00002),
                                          ((2, 3, 1100), 0.002), ((2, 1500, 3), 0.001), ((1300, 2, 17), 0.0004), ((30, 130, 33), 0.001),
-                                         ((3, 5, 1024), 0.0008), ((2, 2, 257), 0.004)])
+                                         ((3, 5, 1024), 0.0008), ((2, 2, 257), 0.004),
+                                         ((200, 130, 32), 0.0002), ((3, 140, 48), 0.002), ((131, 2, 16), 0.004)])
 def test_distance_map_anisotropic_parity(ctx, shape_dhw, p):
     occ = sparse_occupancy(shape_dhw, 4, p)
     d, h, w = shape_dhw
