@@ -109,7 +109,9 @@ def sparse_occupancy(shape_dhw, seed, p):
                                          ((2, 3, 1100), 0.002), ((2, 1500, 3), 0.001), ((1300, 2, 17), 0.0004), ((30, 130, 33), 0.001),
                                          ((3, 5, 1024), 0.0008), ((2, 2, 257), 0.004),
                                          # 16 | width and 128 < axis <= 256: the 16-byte vector staging of the y / z passes
-                                         ((200, 130, 32), 0.0002), ((3, 140, 48), 0.002), ((131, 2, 16), 0.004)])
+                                         ((200, 130, 32), 0.0002), ((3, 140, 48), 0.002), ((131, 2, 16), 0.004),
+                                         # 8 | width and 256 < axis <= 512: whole-line table with 8-byte vectors
+                                         ((2, 300, 24), 0.001), ((400, 3, 8), 0.001)])
 def test_distance_map_parity(ctx, shape_dhw, p):
     occ = sparse_occupancy(shape_dhw, 3, p)
     d, h, w = shape_dhw
@@ -125,7 +127,7 @@ def test_distance_map_parity(ctx, shape_dhw, p):
                                          ((1, 1, 1), 1.0), ((6, 6, 6), 0.0), ((600, 2, 3), 0.0006), ((2, 700, 1), 0.0015), ((90, 280, 70), 0.00002),
                                          ((2, 3, 1100), 0.002), ((2, 1500, 3), 0.001), ((1300, 2, 17), 0.0004), ((30, 130, 33), 0.001),
                                          ((3, 5, 1024), 0.0008), ((2, 2, 257), 0.004),
-                                         ((200, 130, 32), 0.0002), ((3, 140, 48), 0.002), ((131, 2, 16), 0.004)])
+                                         ((200, 130, 32), 0.0002), ((3, 140, 48), 0.002), ((131, 2, 16), 0.004), ((2, 300, 24), 0.001), ((400, 3, 8), 0.001)])
 def test_distance_map_anisotropic_parity(ctx, shape_dhw, p):
     occ = sparse_occupancy(shape_dhw, 4, p)
     d, h, w = shape_dhw

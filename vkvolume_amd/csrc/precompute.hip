@@ -4,6 +4,7 @@
 // and their shaders (gradient_map.comp, occupancy_map.comp, distance_map.comp, distance_map_anisotropic.comp).
 // All kernels are integer/byte streaming work bound by HBM / LDS bandwidth; no MFMA.
 #include <cstdlib>
+#include <type_traits>
 
 #include "vkv_device.hpp"
 
@@ -556,8 +557,9 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 	// vector in memory and in the LDS layout - one load / store instruction moves what 16 / 4 byte-wide ones would
 	if (vec && !XAXIS)
 	{
+		using vec_t = typename std::conditional<XT == 16, uint4, uint2>::type;        // the XT lines of one cell row
 		for (int p = t; p < n; p += 256)
-			*reinterpret_cast<uint4 *>(s_t + p * XT) = *reinterpret_cast<const uint4 *>(src + base + (size_t) p * axis_stride);
+			*reinterpret_cast<vec_t *>(s_t + p * XT) = *reinterpret_cast<const vec_t *>(src + base + (size_t) p * axis_stride);
 	}
 	else if (vec)
 	{
@@ -714,12 +716,13 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 	__syncthreads();
 	if (vec && !XAXIS)
 	{
+		using vec_t = typename std::conditional<XT == 16, uint4, uint2>::type;
 		for (int p = out0 - seg0 + t; p < out1 - seg0; p += 256)
 		{
 			const size_t o = base + (size_t) p * axis_stride;
-			*reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(s_t + kOut + p * XT);
+			*reinterpret_cast<vec_t *>(dst + o) = *reinterpret_cast<const vec_t *>(s_t + kOut + p * XT);
 			if (MODE == 2)
-				*reinterpret_cast<uint4 *>(dst2 + o) = *reinterpret_cast<const uint4 *>(s_t + kOut + kLevel + p * XT);
+				*reinterpret_cast<vec_t *>(dst2 + o) = *reinterpret_cast<const vec_t *>(s_t + kOut + kLevel + p * XT);
 		}
 		return;
 	}
@@ -1124,7 +1127,7 @@ static int launch_dm_rmq(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *ds
 			return set_error(ctx, VKV_E_UNSUPPORTED, "distance_map: map too large for one launch");                                                     \
 		const uintptr_t al = (uintptr_t) src | (uintptr_t) dst | (uintptr_t) dst2;                                                                      \
 		const int vec = (XAXIS) ? (chunks_p == 1 && (me.width & 3u) == 0 && (al & 3u) == 0)                                                             \
-		                        : ((XT) == 16 && (me.width & 15u) == 0 && (al & 15u) == 0);                                                              \
+		                        : (((XT) == 16 || (XT) == 8) && (me.width & ((XT) -1)) == 0 && (al & ((XT) -1)) == 0);                                   \
 		hipLaunchKernelGGL((k_dm_rmq<MODE, XT, SEG, XAXIS>), dim3(chunks_x * chunks_p * other), dim3(256), 0, s, src, dst, dst2, n_lines, len, ls, as,  \
 		                   os, chunks_x, chunks_p, ch, vec);                                                                                            \
 	} while (0)
@@ -1139,6 +1142,8 @@ static int launch_dm_rmq(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *ds
 		VKV_DM_RMQ(32, 128, false);
 	else if (len <= 256)
 		VKV_DM_RMQ(16, 256, false);
+	else if (len <= 512)
+		VKV_DM_RMQ(8, 512, false);        // whole line, no halo
 	else
 		VKV_DM_RMQ(8, 768, false);
 #undef VKV_DM_RMQ
