@@ -12,7 +12,8 @@ Inputs (volume, gradient map, TF texture, distance map) are resident in HBM befo
 
 N = 1: the frame is 1920x1080.  N > 1 (weak scaling): the frame is (1920*sx)x(1080*sy) with sx*sy = N sampling the
 SAME frustum, cut into 16x16 tiles dealt round-robin to the ranks (volume replicated); each rank renders its tiles into
-a compact RGBA8 buffer, the buffers are gathered to rank 0 over RCCL and de-interleaved there.  The gather of frame k
+a compact RGBA8 buffer, the buffers are gathered over RCCL to the frame's owner (rank k mod N for frame k, so that consecutive
+frames use disjoint xGMI links; --frame-owner rank0 pins it) and de-interleaved there.  The gather of frame k
 overlaps the renders of the next frames; the de-interleave runs on its own stream.  value = rays of all ranks / max-over-ranks wall time.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the ray-march kernel by ALGORITHMIC bytes (SURVEY.md §8d:
@@ -92,6 +93,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-in-flight", type=int, default=3, help="render consecutive frames on this many HIP streams (each with its "
                     "own framebuffer) so the tail of one frame overlaps the start of the next; 1 = strictly one frame at a time")
+    ap.add_argument("--frame-owner", default="rotate", choices=["rotate", "rank0"], help="N > 1: rank that assembles frame k: k mod N "
+                    "(default; the inbound xGMI links and the de-interleave of consecutive frames are then disjoint) or always rank 0")
     ap.add_argument("--force-gather", action="store_true", help="exercise the tile gather / de-interleave path with a 1-rank process group")
     ap.add_argument("--verify", action="store_true", help="after timing, check the assembled frame of the last step against a direct render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,12 +151,13 @@ def main():
     # --force-gather) renders this rank's tiles into a compact buffer that is gathered to rank 0 and de-interleaved.
     fif = max(1, args.frames_in_flight)
     nbuf = fif  # frame k renders on stream k % fif into buffer k % nbuf
-    gather, images = None, []
+    gather, images, rotate = None, [], False
     if use_gather:
         nbuf = fif + 1  # one more buffer than render streams: a render does not wait for the gather of the frame fif steps back
-        gather = multigpu.TileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda", n_buffers=nbuf)
+        rotate = args.frame_owner == "rotate" and world > 1
+        gather = multigpu.TileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda", n_buffers=nbuf, any_root=rotate)
         bufs, my_rays = gather.buffers, gather.my_ray_count()
-        if rank == 0:
+        if rank == 0 or rotate:
             images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
     else:
         bufs, my_rays = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(fif)], fw * fh
@@ -183,7 +187,8 @@ def main():
                 if timed and k % ev_every == 0:
                     ev_stop[k].record(st)
                 if gather:
-                    gather.start(b)  # RCCL gather of frame k (ordered after the render) overlaps the renders of the next frames
+                    # RCCL gather of frame k (ordered after the render) overlaps the renders of the next frames
+                    gather.start(b, k % world if rotate else 0)
             if gather:
                 with torch.cuda.stream(side):
                     flat = gather.finish(b)
@@ -226,7 +231,7 @@ def main():
     vs_total, ds_total, cov_total = float(tot[0].item()), float(tot[1].item()), float(tot[2].item())
 
     if args.verify:
-        verify(ctx, sp, v, views, params, args.steps, nbuf, (fw, fh), bufs, images, gather, rank)
+        verify(ctx, sp, v, views, params, args.steps, nbuf, (fw, fh), bufs, images, gather, rank, (args.steps - 1) % world if rotate else 0)
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -239,7 +244,8 @@ def main():
         "config": {"workload": "%s: %dx%dx%d uint8 synthetic shells, %dx%d frame, %s ESS + ERT, block 4, TF imin 0.1 imax 1 gmin 0 gmax 0.2, "
                                "8 orbit views" % (args.workload, *WORKLOADS[args.workload][0], fw, fh,
                                                   {1: "block", 2: "Chebyshev distance-map", 3: "anisotropic"}[skip]),
-                   "parallelism": "screen tiles 16x16 round-robin over %d GPU(s), RCCL gather to rank 0" % world if world > 1 else "1 GPU",
+                   "parallelism": "screen tiles 16x16 round-robin over %d GPU(s), RCCL gather to %s" % (
+                       world, "rank k mod N for frame k" if rotate else "rank 0") if world > 1 else "1 GPU",
                    "output": "RGBA8", "frames_in_flight": fif, "occupied_voxel_percent": round(occupied_voxel_percent(ctx, v, tf), 4)},
         "covered_Mray_per_s": round(cov_total / elapsed / 1e6, 3), "covered_fraction": round(cov_total / (rays_per_frame_all * args.steps), 4),
         "volume_samples_per_s": round(vs_total / elapsed, 1), "distance_probes_per_s": round(ds_total / elapsed, 1),
@@ -273,9 +279,10 @@ def main():
         dist.destroy_process_group()
 
 
-def verify(ctx, sp, v, views, params, steps, nbuf, frame, bufs, images, gather, rank):
-    """The frame left in the last step's buffer must equal a direct single-launch render of the same view, bit for bit."""
-    if rank != 0:
+def verify(ctx, sp, v, views, params, steps, nbuf, frame, bufs, images, gather, rank, owner):
+    """The frame left in the last step's buffer (on the rank that owns it) must equal a direct single-launch render of the same
+    view, bit for bit."""
+    if rank != owner:
         return
     k = steps - 1
     fw, fh = frame
@@ -285,7 +292,8 @@ def verify(ctx, sp, v, views, params, steps, nbuf, frame, bufs, images, gather, 
     got = images[k % nbuf] if gather else bufs[k % nbuf].view(fh, fw, 4)
     if not torch.equal(got, direct):
         raise SystemExit("verify failed: assembled frame differs from the direct render in %d bytes" % int((got != direct).sum().item()))
-    print("verify ok: frame of step %d matches the direct render (%d non-zero bytes)" % (k, int((direct != 0).sum().item())), file=sys.stderr)
+    print("verify ok (rank %d): frame of step %d matches the direct render (%d non-zero bytes)" % (rank, k, int((direct != 0).sum().item())),
+          file=sys.stderr)
 
 
 def cpu_baseline(v, params, frame, target_seconds):

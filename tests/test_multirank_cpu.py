@@ -25,12 +25,12 @@ def _scene():
     return scene, view, proj, uniforms
 
 
-def _worker(rank, port, out_path):
+def _worker(rank, port, out_path, rotate):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:
         scene, view, proj, uniforms = _scene()
-        g = multigpu.TileGather(dist, rank, WORLD, FRAME, 16, 4, device="cpu")
+        g = multigpu.TileGather(dist, rank, WORLD, FRAME, 16, 4, device="cpu", any_root=rotate)
         opts = abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0)
         frames = []
         for k in range(3):  # three frames through the two buffers: exercises buffer reuse + ordering
@@ -41,26 +41,27 @@ def _worker(rank, port, out_path):
             p = scene.params(view, proj, FRAME, opts, tiles=g.schedule, uniforms=uniforms)
             r = scene.render(p, n_threads=2, want_rgba8=True)
             g.buffers[b][:r.rgba8.shape[0]].copy_(torch.from_numpy(r.rgba8))
-            g.start(b)
+            g.start(b, k % WORLD if rotate else 0)  # rotate: frame k is assembled on rank k mod WORLD
         for b in (1, 0):
             flat = g.finish(b)
             if flat is not None:
                 frames.append(multigpu.deinterleave_reference(flat.numpy(), FRAME, 16, WORLD))
-        if rank == 0:
-            np.save(out_path, np.stack(frames))
+        np.save("%s.%d.npy" % (out_path, rank), np.stack(frames) if frames else np.zeros((0, FRAME[1], FRAME[0], 4), np.uint8))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_tile_gather_reassembles_the_frame(tmp_path):
+@pytest.mark.parametrize("rotate", [False, True])
+def test_two_rank_tile_gather_reassembles_the_frame(tmp_path, rotate):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    out = str(tmp_path / "frames.npy")
-    mp.spawn(_worker, args=(port, out), nprocs=WORLD, join=True)
-    frames = np.load(out)
-    assert frames.shape[0] == 3
+    out = str(tmp_path / "frames")
+    mp.spawn(_worker, args=(port, out, rotate), nprocs=WORLD, join=True)
+    per_rank = [np.load("%s.%d.npy" % (out, r)) for r in range(WORLD)]
+    assert [f.shape[0] for f in per_rank] == ([2, 1] if rotate else [3, 0])  # frames 0 and 2 on rank 0, frame 1 on rank 1
+    frames = np.concatenate(per_rank)
     scene, view, proj, uniforms = _scene()
     full = scene.params(view, proj, FRAME, abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0),
                         tiles=abi.full_frame_tiles(FRAME[0], FRAME[1]), uniforms=uniforms)

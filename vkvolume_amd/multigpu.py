@@ -1,8 +1,9 @@
 """Screen-tile sharding of one frame over the ranks of a node.
 
 Rays are independent, so the path shards by screen tiles with the volume replicated per GPU and exactly one exchange
-step: every rank's compact tile buffer is gathered to rank 0 (RCCL gather over xGMI = 7 concurrent point-to-point
-transfers, one per link into the root), where ``vkv_scatter_tiles`` de-interleaves them into the frame.
+step: every rank's compact tile buffer is gathered to the frame's owner (RCCL gather over xGMI = 7 concurrent point-to-point
+transfers, one per link into the root), where ``vkv_scatter_tiles`` de-interleaves them into the frame.  The owner can rotate
+over the ranks frame by frame (``any_root``), which spreads the inbound traffic and the de-interleave over all GPUs.
 
 Tiles are dealt round-robin (tile t -> rank t mod world) because empty-space skipping makes per-pixel cost vary by
 more than 10x; contiguous strips would not balance.
@@ -16,7 +17,7 @@ class TileGather:
     """Double-buffered gather of per-rank compact tile buffers to rank 0, overlapping the collective of frame k with the
     render of frame k+1.  Works with any torch.distributed backend (nccl == RCCL on ROCm; gloo in the CPU tests)."""
 
-    def __init__(self, dist, rank, world, frame_size, tile=16, bytes_per_pixel=4, device="cuda", n_buffers=2):
+    def __init__(self, dist, rank, world, frame_size, tile=16, bytes_per_pixel=4, device="cuda", n_buffers=2, any_root=False):
         import torch
         self.dist, self.rank, self.world = dist, rank, world
         self.frame_size, self.tile, self.bpp = frame_size, tile, bytes_per_pixel
@@ -27,10 +28,14 @@ class TileGather:
         self.schedule = abi.full_frame_tiles(fw, fh, tile, tile, rank, world, compact=True)
         n = self.tiles_per_rank * tile * tile
         self.buffers = [torch.zeros((n, bytes_per_pixel), dtype=torch.uint8, device=device) for _ in range(n_buffers)]
+        # receive buffers live on every rank that can own a frame: rank 0 only, or all ranks (any_root) when the owner rotates -
+        # xGMI is point-to-point, so frames gathered to different roots travel over disjoint links and pipeline
         self.flat = None
-        if rank == 0:
+        if rank == 0 or any_root:
             self.flat = [torch.zeros((world, n, bytes_per_pixel), dtype=torch.uint8, device=device) for _ in range(n_buffers)]
+        self.any_root = any_root
         self.works = [None] * n_buffers
+        self.roots = [0] * n_buffers
 
     def my_ray_count(self):
         """in-image pixels of this rank's tiles (edge tiles are partial)"""
@@ -42,18 +47,21 @@ class TileGather:
             n += min(self.tile, fw - x0) * min(self.tile, fh - y0)
         return n
 
-    def start(self, b):
-        """launch the gather of buffer b (asynchronous)"""
-        gl = [self.flat[b][r] for r in range(self.world)] if self.rank == 0 else None
-        self.works[b] = self.dist.gather(self.buffers[b], gl, dst=0, async_op=True)
+    def start(self, b, root=0):
+        """launch the gather of buffer b to `root` (asynchronous); every rank must pass the same root"""
+        if root != 0 and not self.any_root:
+            raise ValueError("TileGather was created for rank 0 as the only frame owner")
+        gl = [self.flat[b][r] for r in range(self.world)] if self.rank == root else None
+        self.roots[b] = root
+        self.works[b] = self.dist.gather(self.buffers[b], gl, dst=root, async_op=True)
 
     def finish(self, b):
-        """wait for buffer b's gather; returns rank 0's [world, n, bpp] tensor (None elsewhere / if nothing pending)"""
+        """wait for buffer b's gather; returns the root's [world, n, bpp] tensor (None on the other ranks / if nothing pending)"""
         if self.works[b] is None:
             return None
         self.works[b].wait()
         self.works[b] = None
-        return self.flat[b] if self.rank == 0 else None
+        return self.flat[b] if self.rank == self.roots[b] else None
 
 
 def deinterleave_reference(flat, frame_size, tile, world):
