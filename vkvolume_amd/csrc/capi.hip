@@ -25,6 +25,7 @@ int launch_synth_volume(vkv_ctx *, uint8_t *, VkvExtent3D, uint32_t, uint32_t, h
 int launch_scatter_tiles(vkv_ctx *, const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 int launch_render(vkv_ctx *, const VkvRenderParams *, const float *, hipStream_t);
 int launch_pack_volume(vkv_ctx *, const uint8_t *, const uint8_t *, VkvExtent3D, void *, hipStream_t);
+int launch_check_numerics(vkv_ctx *, int, uint32_t, uint64_t, unsigned long long *, hipStream_t);
 int launch_tf_bits(vkv_ctx *, const uint8_t *, uint32_t *, hipStream_t);
 int launch_convert_volume(vkv_ctx *, const void *, int, bool, float, float, uint64_t, uint8_t *, hipStream_t);
 int launch_occupied_voxel_count(vkv_ctx *, const uint8_t *, const uint8_t *, const VkvTransferFunctionUniform *, VkvExtent3D, uint64_t *, hipStream_t);
@@ -112,6 +113,18 @@ int vkv_debug_trace(vkv_ctx *ctx, void *d_buffer)
 		return VKV_E_INVALID_ARGUMENT;
 	ctx->d_trace = d_buffer;
 	return VKV_OK;
+}
+
+// Diagnostic hook (not part of the public header): counts the floats with bit patterns [first_bits, first_bits + count) for which a
+// short-cut of the gradient kernel differs from the plain form (what = 0: the short correctly rounded sqrt vs __builtin_sqrtf,
+// what = 1: the one-instruction clamped R8_UNORM store); *d_mismatches (device, zeroed by the caller) += that.
+int vkv_debug_check(vkv_ctx *ctx, int32_t what, uint32_t first_bits, uint64_t count, uint64_t *d_mismatches, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (!d_mismatches)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "check: null pointer");
+	return launch_check_numerics(ctx, what, first_bits, count, reinterpret_cast<unsigned long long *>(d_mismatches), (hipStream_t) stream);
 }
 
 const char *vkv_last_error(const vkv_ctx *ctx) { return ctx ? ctx->error : "null context"; }

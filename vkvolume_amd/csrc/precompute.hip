@@ -35,14 +35,41 @@ __global__ void __launch_bounds__(256) k_gradient_map(const uint8_t *__restrict_
 
 // LDS-tiled version (the one the launcher uses when the rows are dword-aligned, W % 4 == 0): a workgroup computes a
 // 64 x 8 x 8 block of voxels from a (64+8) x 10 x 10 halo tile staged in LDS with coalesced dword loads, so every volume byte
-// is fetched ~1.6x instead of 4x with byte gathers.  R8_UNORM -> float uses the 3-instruction exact form of b / 255.
-__device__ __forceinline__ float unorm8_exact3(float b)
+// is fetched ~1.6x instead of 4x with byte gathers.
+// Correctly rounded sqrt for x == 0 or x normal with a normal root: v_sqrt_f32 (1 ulp) moved by at most one ulp after looking at
+// the signs of the two residuals - the sequence the compiler emits for __builtin_sqrtf under
+// -fhip-fp32-correctly-rounded-divide-sqrt, without the rescaling of tiny inputs and the inf / nan pass-through around it (7 of its
+// 16 instructions).  The gradient's sum of squares is 0 or >= ~1e-17 (squares of rounding residues of byte / 255 values), far above
+// 2^-96 where the rescaling starts.  vkv_debug_check (what = 0) compares it with __builtin_sqrtf for every float of a range; the GPU
+// tests run it over 0 and all of [2^-90, 4).
+__device__ __forceinline__ float sqrt_rn_normal(float x)
 {
-	// q = b * (1/255) refined by one residual step: equals the correctly rounded b / 255 for every byte value
-	// (checked exhaustively; the parity tests compare it with the IEEE division of the oracle)
-	const float q = b * kInv255;
-	const float r = __builtin_fmaf(-q, 255.0f, b);
-	return __builtin_fmaf(r, kInv255, q);
+	const float r  = __builtin_amdgcn_sqrtf(x);
+	const float rm = __int_as_float(__float_as_int(r) - 1), rp = __int_as_float(__float_as_int(r) + 1);
+	const float em = __builtin_fmaf(-rm, r, x), ep = __builtin_fmaf(-rp, r, x);
+	float       q  = (em <= 0.0f) ? rm : r;
+	q              = (ep > 0.0f) ? rp : q;
+	return q;
+}
+
+// R8_UNORM store of clamp(g, 0, 1) in one instruction: v_cvt_pk_u8_f32 rounds to nearest even and saturates to [0, 255], so fed
+// g * 255 it equals store_unorm8(g_clamp(g, 0, 1)) for every non-NaN float (vkv_debug_check what = 1 runs over all of them).
+__device__ __forceinline__ uint8_t store_unorm8_clamped(float g) { return (uint8_t) __builtin_amdgcn_cvt_pk_u8_f32(g * 255.0f, 0u, 0u); }
+
+// what = 0: sqrt_rn_normal vs __builtin_sqrtf; what = 1: store_unorm8_clamped vs store_unorm8(g_clamp(., 0, 1))
+__global__ void __launch_bounds__(256) k_check_numerics(int what, uint32_t first_bits, uint64_t count, unsigned long long *mismatches)
+{
+	const uint64_t i = (uint64_t) blockIdx.x * 256u + threadIdx.x;
+	if (i >= count)
+		return;
+	const float x = __uint_as_float(first_bits + (uint32_t) i);
+	bool        bad;
+	if (what == 0)
+		bad = __float_as_uint(sqrt_rn_normal(x)) != __float_as_uint(__builtin_sqrtf(x));
+	else
+		bad = store_unorm8_clamped(x) != store_unorm8(g_clamp(x, 0.0f, 1.0f));
+	if (bad)
+		atomicAdd(mismatches, 1ull);
 }
 
 constexpr int kGradTileX = 64, kGradTileY = 8, kGradTileZ = 8, kGradPitch = 72;        // pitch = 64 + 4 bytes of halo on each side
@@ -51,6 +78,8 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
                                                             float modifier, uint32_t tiles_x, uint32_t tiles_y, uint32_t n_tiles)
 {
 	__shared__ __align__(16) uint8_t s_tile[(kGradTileZ + 2) * (kGradTileY + 2) * kGradPitch];
+	__shared__ float                 s_unorm[256];        // b / 255 (IEEE division, once per workgroup): a tap costs one LDS read, not four VALU
+	s_unorm[threadIdx.x] = unorm8(threadIdx.x);
 	const uint32_t t  = xcd_remap(blockIdx.x, n_tiles);
 	const int      x0 = (int) (t % tiles_x) * kGradTileX;
 	const int      y0 = (int) ((t / tiles_x) % tiles_y) * kGradTileY;
@@ -104,11 +133,16 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
 			// tile coordinates of (x, y, z) are (lx + 4, ly + 1, lz + 1)
 			const uint8_t *c  = s_tile + ((lz + 1) * (kGradTileY + 2) + (ly + 1)) * kGradPitch + 4 + lx;
 			constexpr int  sy = kGradPitch, sz = (kGradTileY + 2) * kGradPitch;
-			const float    v1 = unorm8_exact3((float) c[+1 - sy - sz]);        // k.xyy = ( 1,-1,-1)
-			const float    v2 = unorm8_exact3((float) c[-1 - sy + sz]);        // k.yyx = (-1,-1, 1)
-			const float    v3 = unorm8_exact3((float) c[-1 + sy - sz]);        // k.yxy = (-1, 1,-1)
-			const float    v4 = unorm8_exact3((float) c[+1 + sy + sz]);        // k.xxx = ( 1, 1, 1)
-			grad[vidx(x, y, z, W, H)] = store_unorm8(gradient_from_taps(v1, v2, v3, v4, modifier));
+			const float    v1 = s_unorm[c[+1 - sy - sz]];        // k.xyy = ( 1,-1,-1)
+			const float    v2 = s_unorm[c[-1 - sy + sz]];        // k.yyx = (-1,-1, 1)
+			const float    v3 = s_unorm[c[-1 + sy - sz]];        // k.yxy = (-1, 1,-1)
+			const float    v4 = s_unorm[c[+1 + sy + sz]];        // k.xxx = ( 1, 1, 1)
+			// get_gradient_compute.glsl:12-20, the operations of gradient_from_taps with the short exact sqrt
+			const float gx  = 0.25f * (((v1 - v2) - v3) + v4);
+			const float gy  = 0.25f * (((-v1 - v2) + v3) + v4);
+			const float gz  = 0.25f * (((-v1 + v2) - v3) + v4);
+			const float len = sqrt_rn_normal((gx * gx + gy * gy) + gz * gz);
+			grad[vidx(x, y, z, W, H)] = store_unorm8_clamped(len * modifier);
 		}
 	}
 }
@@ -1211,6 +1245,16 @@ int launch_distance_map_anisotropic(vkv_ctx *ctx, uint8_t *const m[8], uint8_t *
 	if ((rc = launch_dm_axis<-1>(ctx, 1, m[7], swap, me, s))) return rc;          // stage2(7, -1)
 	if ((rc = launch_dm_axis<1>(ctx, 2, swap, m[6], me, s))) return rc;           // stage3(6, +1)
 	return launch_dm_axis<-1>(ctx, 2, swap, m[7], me, s);                         // stage3(7, -1)
+}
+
+int launch_check_numerics(vkv_ctx *ctx, int what, uint32_t first_bits, uint64_t count, unsigned long long *d_mismatches, hipStream_t s)
+{
+	if (count == 0)
+		return VKV_OK;
+	if ((count + 255) / 256 > 0x7fffffffull || what < 0 || what > 1)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "check_numerics: bad arguments");
+	hipLaunchKernelGGL(k_check_numerics, dim3((uint32_t) ((count + 255) / 256)), dim3(256), 0, s, what, first_bits, count, d_mismatches);
+	return check_launch(ctx, "check_numerics");
 }
 
 int launch_pack_volume(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_grad, VkvExtent3D e, void *d_packed, hipStream_t s)
