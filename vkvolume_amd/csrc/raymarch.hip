@@ -348,11 +348,17 @@ __device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const f
 		const uint8_t *fp   = packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, hwx, hwy, hwz);
 		const uint8_t *ma   = R.dmap + (probe ? cell : 0u);
 		const uint8_t *ba   = probe ? A.packed : fp;
-		dist_h              = *ma;
-		q00                 = *reinterpret_cast<const u32_align2 *>(ba);
-		q10                 = *reinterpret_cast<const u32_align2 *>(ba + 10);
-		q01                 = *reinterpret_cast<const u32_align2 *>(ba + 50);
-		q11                 = *reinterpret_cast<const u32_align2 *>(ba + 60);
+		// a wave whose live lanes all probe (the empty space in front of the volume) or all sample skips the other kind's loads:
+		// wave-uniform scalar branches
+		if (__ballot(probe) != 0ull)
+			dist_h = *ma;
+		if (__ballot(!probe) != 0ull)
+		{
+			q00 = *reinterpret_cast<const u32_align2 *>(ba);
+			q10 = *reinterpret_cast<const u32_align2 *>(ba + 10);
+			q01 = *reinterpret_cast<const u32_align2 *>(ba + 50);
+			q11 = *reinterpret_cast<const u32_align2 *>(ba + 60);
+		}
 		// keep the five loads above the divergent consume code (the compiler would otherwise sink each into its branch)
 		asm volatile("" : "+v"(dist_h), "+v"(q00), "+v"(q10), "+v"(q01), "+v"(q11));
 	}
