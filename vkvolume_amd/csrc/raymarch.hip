@@ -344,16 +344,17 @@ __device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const f
 	float          hwx = 0, hwy = 0, hwz = 0;
 	if (kHoist)
 	{
-		const uint32_t cell = ((uint32_t) uiz * (uint32_t) A.mh + (uint32_t) uiy) * (uint32_t) A.mw + (uint32_t) uix;
-		const uint8_t *fp   = packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, hwx, hwy, hwz);
-		const uint8_t *ma   = R.dmap + (probe ? cell : 0u);
-		const uint8_t *ba   = probe ? A.packed : fp;
-		// a wave whose live lanes all probe (the empty space in front of the volume) or all sample skips the other kind's loads:
-		// wave-uniform scalar branches
+		// a wave whose live lanes all probe (the empty space in front of the volume) or all sample skips the other kind's address
+		// arithmetic and loads: wave-uniform scalar branches
 		if (__ballot(probe) != 0ull)
-			dist_h = *ma;
+		{
+			const uint32_t cell = ((uint32_t) uiz * (uint32_t) A.mh + (uint32_t) uiy) * (uint32_t) A.mw + (uint32_t) uix;
+			dist_h              = R.dmap[probe ? cell : 0u];
+		}
 		if (__ballot(!probe) != 0ull)
 		{
+			const uint8_t *fp = packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, hwx, hwy, hwz);
+			const uint8_t *ba = probe ? A.packed : fp;
 			q00 = *reinterpret_cast<const u32_align2 *>(ba);
 			q10 = *reinterpret_cast<const u32_align2 *>(ba + 10);
 			q01 = *reinterpret_cast<const u32_align2 *>(ba + 50);
