@@ -33,7 +33,7 @@ extern "C" {
 #define VKV_E_NO_DEVICE (-3)        /* no HIP device / wrong architecture               */
 #define VKV_E_IO (-4)               /* file errors of the loader                        */
 
-#define VKV_TF_BITS_WORDS 2052      /* uint32 words of a vkv_transfer_function_bits() buffer */
+#define VKV_TF_BITS_WORDS 2564      /* uint32 words of a vkv_transfer_function_tables() / _bits() buffer */
 
 /* VkExtent3D stand-in (src/load_volume.h:31, src/volume_component.cpp:91-92). */
 typedef struct VkvExtent3D
@@ -157,7 +157,7 @@ typedef struct VkvRenderParams
 	const uint8_t *            d_transfer_function;        /* RGBA8 256x256, row = gradient  */
 	const uint8_t *            d_distance_maps[8];         /* [0] (or [0..7] anisotropic); unused for VKV_SKIP_NONE */
 	const void *               d_packed_volume;            /* optional: vkv_pack_volume() image of d_volume (+ d_gradient); NULL = sample the linear buffers */
-	const uint32_t *           d_transfer_function_bits;   /* optional: vkv_transfer_function_bits() of d_transfer_function; NULL = fetch the texel */
+	const uint32_t *           d_transfer_function_bits;   /* optional: vkv_transfer_function_tables() of d_transfer_function; NULL = fetch the texel */
 	float *                    d_out_color;                /* RGBA32F premultiplied, or NULL */
 	uint8_t *                  d_out_rgba8;                /* RGBA8 round-to-nearest of the above, or NULL */
 	uint32_t *                 d_out_counts;               /* 3 x u32 per pixel: volume samples, distance probes, empty samples; or NULL */
@@ -265,10 +265,20 @@ int vkv_convert_volume(vkv_ctx *ctx, const void *d_raw, int32_t type, int32_t bi
 size_t vkv_packed_volume_bytes(VkvExtent3D extent);
 int    vkv_pack_volume(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_t *d_gradient, VkvExtent3D extent, void *d_packed, void *stream);
 
-/* 1 bit per texel of the 256x256 TF texture: alpha > 0 (2048 words, row = gradient); the buffer is VKV_TF_BITS_WORDS = 2052
- * uint32 (the last four words are reserved).  Lets the integrator decide
- * "voxel_occupied" (frag:276) from LDS and fetch the RGBA texel only for occupied samples. */
-int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_transfer_function, uint32_t *d_bits_2052, void *stream);
+/* Acceleration tables of the 256x256 TF texture for the integrator (device half of Volume::update_transfer_function_texture,
+ * src/volume_component.cpp:262-278, next to the texture upload).  The buffer is VKV_TF_BITS_WORDS uint32:
+ *   words [0, 2048)  1 bit per texel: alpha > 0 (row = gradient), so "voxel_occupied" (frag:276) comes from LDS and only occupied
+ *                    samples fetch the RGBA texel;
+ *   word 2048        flags; bit 0 = "separable greyscale": every texel equals (b, b, b, b) with
+ *                    b = (uint8) clamp(alpha_i[column] * alpha_g[row] * 255, 0, 255) — the product the reference always builds
+ *                    (src/volume_component.cpp:246-261).  alpha_i / alpha_g are derived from `tf` (intensity_min, *_range_inv,
+ *                    use_gradient) and the claim is CHECKED on the device against all 65536 texels; when it holds the integrator
+ *                    takes the texel from two 256-entry LDS tables (words 2052.., float) instead of a dependent global fetch.
+ * tf == NULL (or vkv_transfer_function_bits) leaves the flag clear: any RGBA texture works through the generic path.
+ * Rebuild the tables whenever the texture changes. */
+int vkv_transfer_function_tables(vkv_ctx *ctx, const uint8_t *d_transfer_function, const VkvTransferFunctionUniform *tf,
+                                 uint32_t *d_tables, void *stream);
+int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_transfer_function, uint32_t *d_tables, void *stream);
 
 /* VolumeRenderSubpass::draw, src/volume_render_subpass.cpp:159-294 (shaders/volume_render.frag). */
 int vkv_render(vkv_ctx *ctx, const VkvRenderParams *params, void *stream);

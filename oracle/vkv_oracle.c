@@ -438,11 +438,16 @@ typedef struct
 /* optional per-ray event trace (diagnostics for the scheduling experiments in tools/): 'P' = distance probe that skipped,
  * 'O' = probe that found an occupied cell, 'S' = empty volume sample, 'A' = volume sample with alpha > 0 */
 static __thread uint8_t *g_trace;
+static __thread int32_t *g_trace_steps; /* optional: the loop index i of every event */
 static __thread uint32_t g_trace_cap, g_trace_len;
-static inline void trace_event(uint8_t c)
+static inline void trace_event(uint8_t c, int i)
 {
 	if (g_trace && g_trace_len < g_trace_cap)
+	{
 		g_trace[g_trace_len] = c;
+		if (g_trace_steps)
+			g_trace_steps[g_trace_len] = i;
+	}
 	++g_trace_len;
 }
 
@@ -661,15 +666,15 @@ static void march_pixel(const VkvRenderParams *P, const float *alpha_lut, int px
 				if (dz_ != dz_) dz_ = INFINITY;
 				float m = g_min(g_min(dx_, dy_), dz_);
 				m       = (m < 1073741824.0f) ? m : 1073741824.0f;
+				trace_event('P', i);
 				i += i_max(1, (int) ceilf(m)); /* frag:244-247 */
-				trace_event('P');
 			}
 			else
 			{ /* frag:253-261 */
 				occupied = 1;
 				ulx = uix, uly = uiy, ulz = uiz;
+				trace_event('O', i);
 				i = i_max(i - back, i_min_);
-				trace_event('O');
 			}
 		}
 		else
@@ -697,7 +702,7 @@ static void march_pixel(const VkvRenderParams *P, const float *alpha_lut, int px
 			/* get_color, transfer_function.glsl:35-38: NEAREST texel of the RGBA8 LUT */
 			const uint8_t *texel = P->d_transfer_function + ((size_t) tf_texel(gradient) * 256 + (size_t) tf_texel(intensity)) * 4;
 			occupied = texel[3] > 0; /* frag:276 */
-			trace_event(occupied ? 'A' : 'S');
+			trace_event(occupied ? 'A' : 'S', i);
 			if (occupied)
 			{
 				if (skip_mode != VKV_SKIP_NONE)
@@ -752,16 +757,21 @@ static void march_pixel(const VkvRenderParams *P, const float *alpha_lut, int px
 
 /* diagnostics: event sequence of one pixel's ray; returns its length (may exceed cap) */
 static void build_alpha_lut(const VkvTransferFunctionUniform *tf, float *lut);
-uint32_t vkvo_trace_ray(const VkvRenderParams *P, int px, int py, uint8_t *events, uint32_t cap)
+uint32_t vkvo_trace_ray_steps(const VkvRenderParams *P, int px, int py, uint8_t *events, int32_t *steps, uint32_t cap)
 {
 	float lut[256];
 	build_alpha_lut(&P->transfer_function, lut);
 	PixelOut po;
-	g_trace = events, g_trace_cap = cap, g_trace_len = 0;
+	g_trace = events, g_trace_steps = steps, g_trace_cap = cap, g_trace_len = 0;
 	float far_depth = 0.0f;
 	march_pixel(P, lut, px, py, P->d_in_depth ? P->d_in_depth + ((size_t) py * P->image_width + px) : &far_depth, &po);
-	g_trace = NULL;
+	g_trace = NULL, g_trace_steps = NULL;
 	return g_trace_len;
+}
+
+uint32_t vkvo_trace_ray(const VkvRenderParams *P, int px, int py, uint8_t *events, uint32_t cap)
+{
+	return vkvo_trace_ray_steps(P, px, py, events, NULL, cap);
 }
 
 /* opacity-correction table keyed by the TF alpha byte (frag:283); shared definition with the product:

@@ -59,6 +59,8 @@ uint64_t vkvo_render(const VkvRenderParams *params, int n_threads, uint32_t pixe
 /* diagnostics: the event sequence of one ray ('P' skip probe, 'O' probe that hit an occupied cell, 'S' empty sample,
  * 'A' sample with alpha > 0); returns the number of events */
 uint32_t vkvo_trace_ray(const VkvRenderParams *params, int px, int py, uint8_t *events, uint32_t cap);
+/* the same, also recording the loop index i (frag:215) at which every event happened */
+uint32_t vkvo_trace_ray_steps(const VkvRenderParams *params, int px, int py, uint8_t *events, int32_t *steps, uint32_t cap);
 
 /* Deterministic synthetic volumes. */
 void vkvo_synth_volume(uint8_t *volume, VkvExtent3D extent, uint32_t kind, uint32_t seed);

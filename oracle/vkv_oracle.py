@@ -236,3 +236,21 @@ def load_data(path, header):
     if rc != 0:
         raise RuntimeError("load_data failed (%d)" % rc)
     return out
+
+
+def trace_ray_steps(params, vol, grad, tf_tex, maps, px, py, cap=4096):
+    """Diagnostics (tools/): the event kinds (b'P', b'O', b'S', b'A') and loop indices of one pixel's ray."""
+    L = lib()
+    if not getattr(L, "_trace_steps_bound", False):
+        L.vkvo_trace_ray_steps.argtypes = [C.POINTER(abi.RenderParams), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.vkvo_trace_ray_steps.restype = C.c_uint32
+        L._trace_steps_bound = True
+    p = abi.RenderParams.from_buffer_copy(params)
+    p.d_volume, p.d_gradient, p.d_transfer_function = vol.ctypes.data, (grad.ctypes.data if grad is not None else None), tf_tex.ctypes.data
+    for i in range(8):
+        p.d_distance_maps[i] = maps[i].ctypes.data if maps is not None and i < len(maps) else None
+    p.d_in_depth = None
+    ev, st = np.zeros(cap, np.uint8), np.zeros(cap, np.int32)
+    n = L.vkvo_trace_ray_steps(C.byref(p), px, py, _ptr(ev), _ptr(st), cap)
+    n = min(int(n), cap)
+    return ev[:n], st[:n]

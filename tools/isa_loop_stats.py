@@ -1,0 +1,46 @@
+"""Static instruction mix of the hot loop of each kernel in a hipcc -S listing (offline, CPU): finds the innermost-but-largest
+backward branch region that contains vector memory loads and counts VALU / SALU / VMEM / LDS / DPP instructions in it.
+usage: isa_loop_stats.py file.s [name-filter]"""
+import re, sys
+s = open(sys.argv[1]).read()
+flt = sys.argv[2] if len(sys.argv) > 2 else ""
+for m in re.finditer(r'\n(_Z[^\n:]*):[^\n]*\n(.*?)\.end_amdhsa_kernel|\n(_Z[^\n:]*):[^\n]*\n(.*?)s_endpgm', s, re.S):
+    pass
+funcs = re.split(r'\n(?=_Z\w+:)', s)
+for f in funcs:
+    name = f.split(':')[0]
+    if not name.startswith('_Z') or flt not in name:
+        continue
+    body = f.split('.Lfunc_end')[0]
+    lines = body.split('\n')
+    labels, ins = {}, []
+    for l in lines:
+        t = l.strip()
+        if not t or t.startswith(';') or t.startswith('.') and not t.startswith('.LBB'):
+            continue
+        if t.startswith('.LBB') and t.split()[0].endswith(':'):
+            labels[t.split(':')[0]] = len(ins)
+            continue
+        if t.endswith(':'):
+            continue
+        ins.append(t.split(';')[0].strip())
+    loops = []
+    for i, t in enumerate(ins):
+        mm = re.match(r's_cbranch_\w+\s+(\.LBB\w+)|s_branch\s+(\.LBB\w+)', t)
+        if mm:
+            lab = mm.group(1) or mm.group(2)
+            if lab in labels and labels[lab] <= i:
+                loops.append((labels[lab], i))
+    best = None
+    for a, b in loops:
+        seg = ins[a:b + 1]
+        if any(x.startswith(('global_load', 'buffer_load')) for x in seg):
+            if best is None or (b - a) > (best[1] - best[0]):
+                best = (a, b)
+    if not best:
+        continue
+    seg = ins[best[0]:best[1] + 1]
+    c = lambda p: sum(1 for x in seg if x.startswith(p))
+    print("%-70s loop %4d instr: valu %3d (dpp %2d) salu %3d vmem-load %2d vmem-store %2d lds %2d waitcnt %2d branch %2d" % (
+        name[:70], len(seg), c('v_'), sum(1 for x in seg if 'dpp' in x or 'quad_perm' in x), c('s_') - c('s_waitcnt') - c('s_cbranch') - c('s_branch'),
+        c(('global_load', 'buffer_load')), c(('global_store', 'buffer_store')), c('ds_'), c('s_waitcnt'), c(('s_cbranch', 's_branch'))))

@@ -1,0 +1,65 @@
+// rm_lab.hip — experimental instantiations of the ray-march kernels (vkvolume_amd/csrc/raymarch_core.hpp), A/B-ed on the GPU by
+// tools/lab/run_lab.py against the product's vkv_render before a variant moves into the product.  Not part of the product.
+#include <cmath>
+#include <cstdio>
+
+#include "../../vkvolume_amd/csrc/raymarch_core.hpp"
+
+namespace
+{
+template <int SKIP, bool ERT, int GRAD, bool PACKED, int W, uint32_t FLAGS>
+int launch_er(const RayMarchArgs &a, hipStream_t s)
+{
+	const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile * W;
+	hipLaunchKernelGGL((k_raymarch_er<SKIP, ERT, GRAD, PACKED, W, FLAGS>), dim3(grid), dim3(256), 0, s, a);
+	return (int) hipGetLastError();
+}
+
+template <int SKIP, bool ERT, int GRAD>
+int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
+{
+	switch (variant)
+	{
+		case 11: return launch_er<SKIP, ERT, GRAD, true, 1, 0>(a, s);
+		case 12: return launch_er<SKIP, ERT, GRAD, true, 2, 0>(a, s);
+		case 14: return launch_er<SKIP, ERT, GRAD, true, 4, 0>(a, s);
+		case 18: return launch_er<SKIP, ERT, GRAD, true, 8, 0>(a, s);
+		case 21: return launch_er<SKIP, ERT, GRAD, true, 1, kErFull>(a, s);
+		case 22: return launch_er<SKIP, ERT, GRAD, true, 2, kErFull>(a, s);
+		case 24: return launch_er<SKIP, ERT, GRAD, true, 4, kErFull>(a, s);
+		case 41: return launch_er<SKIP, ERT, GRAD, true, 1, kErMasked>(a, s);
+		case 42: return launch_er<SKIP, ERT, GRAD, true, 2, kErMasked>(a, s);
+		case 51: return launch_er<SKIP, ERT, GRAD, true, 1, kErMasked | kErStamp>(a, s);
+		case 52: return launch_er<SKIP, ERT, GRAD, true, 2, kErMasked | kErStamp>(a, s);
+		case 31: return launch_er<SKIP, ERT, GRAD, true, 1, kErStamp>(a, s);
+		case 32: return launch_er<SKIP, ERT, GRAD, true, 2, kErStamp>(a, s);
+		case 34: return launch_er<SKIP, ERT, GRAD, true, 4, kErStamp>(a, s);
+		default: return -100;
+	}
+}
+}        // namespace
+
+// variant = 10 + W: evaluate+replay, W lanes per ray; 20 + W: every lane loads both kinds; 30 + W: stamped diagnostic build.
+// Only the bench configurations are instantiated: (distance ESS, ERT, precomputed gradient, packed) and (no ESS, no ERT, ...).
+extern "C" int vkv_lab_render(vkv_ctx *ctx, const VkvRenderParams *P, int variant, void *stream)
+{
+	float       lut[256];
+	const float sf_inv = 1.0f / P->transfer_function.sampling_factor;
+	for (int a = 0; a < 256; ++a)
+	{
+		const float v = P->transfer_function.voxel_alpha_factor * (1.0f - std::pow(1.0f - (float) a / 255.0f, sf_inv));
+		lut[a]        = std::min(std::max(v, 0.0f), 1.0f);
+	}
+	RayMarchArgs a;
+	const int    rc = vkv::fill_render_args(ctx, P, lut, a);
+	if (rc != VKV_OK || a.nblocks == 0)
+		return rc;
+	if (!a.packed || !P->transfer_function.use_gradient || !P->use_precomputed_gradient)
+		return -101;
+	const bool ert = P->options.early_ray_termination != 0;
+	if (P->options.skipping_type == VKV_SKIP_DISTANCE && ert)
+		return dispatch<VKV_SKIP_DISTANCE, true, 1>(a, variant, (hipStream_t) stream);
+	if (P->options.skipping_type == VKV_SKIP_NONE && !ert)
+		return dispatch<VKV_SKIP_NONE, false, 1>(a, variant, (hipStream_t) stream);
+	return -102;
+}

@@ -1,0 +1,160 @@
+"""GPU A/B of experimental ray-march kernel variants (tools/lab/rm_lab.hip) against the product's vkv_render.
+
+Every variant must reproduce the product's RGBA8, float colour, depth and the three counters bit for bit on all 8 bench views; then
+it is timed one frame at a time (HIP events around single launches, median per view) and with three frames in flight.
+
+    python tools/lab/run_lab.py [workload] [variants, comma separated] [--dense] [--stamps]
+"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from vkvolume_amd import abi, lib, volume as V  # noqa: E402
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+flags = [a for a in sys.argv[1:] if a.startswith("--")]
+name = args[0] if args else "c3"
+variants = [int(x) for x in args[1].split(",")] if len(args) > 1 else [0, 11, 12, 14, 21, 22, 24]
+dense = "--dense" in flags
+
+torch.cuda.set_device(0)
+ctx = lib.Context(0)
+LAB = C.CDLL(os.path.join(ROOT, "tools", "lab", "libvkv_lab.so"))
+LAB.vkv_lab_render.argtypes = [C.c_void_p, C.POINTER(abi.RenderParams), C.c_int, C.c_void_p]
+L = lib.load()
+L.vkv_debug_trace.argtypes = [C.c_void_p, C.c_void_p]
+
+v, tf, frame, skip = bench.build_scene(ctx, name)
+fw, fh = frame
+views = bench.cameras(v, fw / fh)
+if dense:
+    opts = abi.RenderOptions(skipping_type=abi.SKIP_NONE, clip_distance=1.0, early_ray_termination=False)
+else:
+    opts = abi.RenderOptions(skipping_type=skip, clip_distance=1.0, early_ray_termination=True)
+sp = V.VolumeRenderSubpass(ctx, v, opts, (fw, fh))
+params = [sp.make_params(view, proj) for view, proj in views]
+flagword = int(v.transfer_function_bits[2048].item())
+print("workload", name, "dense" if dense else "ESS+ERT", "TF separable flag:", flagword & 1, flush=True)
+
+
+def bufs():
+    return dict(rgba8=torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda"), color=torch.zeros((fh, fw, 4), dtype=torch.float32, device="cuda"),
+                counts=torch.zeros((fh, fw, 3), dtype=torch.int32, device="cuda"), depth=torch.zeros((fh, fw), dtype=torch.float32, device="cuda"))
+
+
+def set_outputs(p, b, only_rgba8=False):
+    p.d_out_rgba8 = b["rgba8"].data_ptr()
+    p.d_out_color = None if only_rgba8 else b["color"].data_ptr()
+    p.d_out_counts = None if only_rgba8 else b["counts"].data_ptr()
+    p.d_out_depth = None if only_rgba8 else b["depth"].data_ptr()
+    p.d_in_depth, p.blend_over_target = None, 0
+
+
+def launch(variant, p, stream):
+    if variant == 0:
+        ctx.render(p, stream)
+    else:
+        rc = LAB.vkv_lab_render(ctx.handle, C.byref(p), variant, stream)
+        if rc != 0:
+            raise RuntimeError("lab variant %d: rc %d" % (variant, rc))
+
+
+cur = torch.cuda.current_stream().cuda_stream
+ref = []
+for p in params:
+    b = bufs()
+    set_outputs(p, b)
+    launch(0, p, cur)
+    torch.cuda.synchronize()
+    ref.append(b)
+counts0 = ref[0]["counts"].to(torch.int64).sum((0, 1)).cpu().numpy()
+print("view 0: volume samples %d, probes %d, empty %d" % tuple(counts0), flush=True)
+
+results = {}
+for var in variants:
+    ok = True
+    if var != 0:
+        for i, p in enumerate(params):
+            b = bufs()
+            set_outputs(p, b)
+            launch(var, p, cur)
+            torch.cuda.synchronize()
+            for k in ("rgba8", "counts", "color", "depth"):
+                if not torch.equal(b[k], ref[i][k]):
+                    ok = False
+                    nbad = int((b[k] != ref[i][k]).sum().item())
+                    print("  variant %d view %d: %s differs in %d elements" % (var, i, k, nbad), flush=True)
+            del b
+    # ---- one frame at a time ----
+    b = bufs()
+    per_view = []
+    for p in params:
+        set_outputs(p, b, only_rgba8=True)
+        for _ in range(2):
+            launch(var, p, cur)
+        ts = []
+        for _ in range(7):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            s.record()
+            launch(var, p, cur)
+            e.record()
+            torch.cuda.synchronize()
+            ts.append(s.elapsed_time(e))
+        per_view.append(float(np.median(ts)))
+    single = float(np.mean(per_view))
+    # ---- three frames in flight ----
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    bb = [bufs() for _ in range(3)]
+    pp = []
+    for k in range(24):
+        q = abi.RenderParams.from_buffer_copy(params[k % 8])
+        set_outputs(q, bb[k % 3], only_rgba8=True)
+        pp.append(q)
+    def burst(n):
+        for k in range(n):
+            launch(var, pp[k % 24], streams[k % 3].cuda_stream)
+    burst(24)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    burst(240)
+    torch.cuda.synchronize()
+    fif3 = (time.perf_counter() - t0) / 240 * 1e3
+    results[var] = dict(bit_identical=ok, single_ms=round(single, 4), per_view_ms=[round(x, 3) for x in per_view], fif3_ms=round(fif3, 4))
+    print(json.dumps({"variant": var, **results[var]}), flush=True)
+    del bb, b
+
+if "--stamps" in flags:
+    for var in [int(x) for x in os.environ.get("LAB_STAMP_VARIANTS", "31,32,34").split(",")]:
+        p = params[0]
+        b = bufs()
+        set_outputs(p, b, only_rgba8=True)
+        W = var % 10
+        nwaves = ((p.tiles.tile_count + 7) // 8) * 8 * W * 4
+        trace = torch.zeros((nwaves, 8), dtype=torch.int64, device="cuda")
+        for _ in range(2):
+            launch(var, p, cur)
+        torch.cuda.synchronize()
+        L.vkv_debug_trace(ctx.handle, trace.data_ptr())
+        launch(var, p, cur)
+        torch.cuda.synchronize()
+        L.vkv_debug_trace(ctx.handle, None)
+        t = trace.cpu().numpy()
+        t = t[t[:, 1] > 0]
+        it = t[:, 2]
+        dur_us = (t[:, 1] - t[:, 0]) / 100.0
+        m = it >= 32
+        ph = t[m, 4:8].astype(np.float64) / it[m, None]
+        print("stamped variant %d: waves %d (>=32 iterations: %d), kernel span %.1f us, longest wave %d iterations" % (var, len(t), m.sum(), (t[:, 1].max() - t[:, 0].min()) / 100.0, it.max()))
+        print("  us per iteration (waves >= 32 it): median %.3f" % np.median(dur_us[m] / it[m]))
+        print("  cycles per iteration, mean over those waves: issue %.0f | memory wait %.0f | evaluate (filter, TF, skip length) %.0f | replay %.0f" % tuple(ph.mean(0)))
+        print("  same, waves with >= 150 iterations:", (t[it >= 150, 4:8].astype(np.float64) / it[it >= 150, None]).mean(0).round(0) if (it >= 150).any() else None)

@@ -9,7 +9,7 @@ VKV_E_INVALID_ARGUMENT = -1
 VKV_E_UNSUPPORTED = -2
 VKV_E_NO_DEVICE = -3
 VKV_E_IO = -4
-TF_BITS_WORDS = 2052  # VKV_TF_BITS_WORDS
+TF_BITS_WORDS = 2564  # VKV_TF_BITS_WORDS
 
 # VolumeRenderSubpass::SkippingType / Test (src/volume_render_subpass.h:58-72)
 SKIP_NONE, SKIP_BLOCK, SKIP_DISTANCE, SKIP_ANISOTROPIC_DISTANCE = 0, 1, 2, 3

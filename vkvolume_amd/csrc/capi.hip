@@ -26,7 +26,7 @@ int launch_scatter_tiles(vkv_ctx *, const void *, void *, uint32_t, uint32_t, ui
 int launch_render(vkv_ctx *, const VkvRenderParams *, const float *, hipStream_t);
 int launch_pack_volume(vkv_ctx *, const uint8_t *, const uint8_t *, VkvExtent3D, void *, hipStream_t);
 int launch_check_numerics(vkv_ctx *, int, uint32_t, uint64_t, unsigned long long *, hipStream_t);
-int launch_tf_bits(vkv_ctx *, const uint8_t *, uint32_t *, hipStream_t);
+int launch_tf_tables(vkv_ctx *, const uint8_t *, const VkvTransferFunctionUniform *, uint32_t *, hipStream_t);
 int launch_convert_volume(vkv_ctx *, const void *, int, bool, float, float, uint64_t, uint8_t *, hipStream_t);
 int launch_occupied_voxel_count(vkv_ctx *, const uint8_t *, const uint8_t *, const VkvTransferFunctionUniform *, VkvExtent3D, uint64_t *, hipStream_t);
 
@@ -402,13 +402,20 @@ int vkv_pack_volume(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_t *d_grad
 	return launch_pack_volume(ctx, d_volume, d_gradient, extent, d_packed, (hipStream_t) stream);
 }
 
-int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_tf, uint32_t *d_bits, void *stream)
+int vkv_transfer_function_tables(vkv_ctx *ctx, const uint8_t *d_tf, const VkvTransferFunctionUniform *tf, uint32_t *d_tables, void *stream)
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
-	if (!d_tf || !d_bits)
-		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "transfer_function_bits: null pointer");
-	return launch_tf_bits(ctx, d_tf, d_bits, (hipStream_t) stream);
+	if (!d_tf || !d_tables)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "transfer_function_tables: null pointer");
+	if (((uintptr_t) d_tf & 3u) != 0 || ((uintptr_t) d_tables & 3u) != 0)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "transfer_function_tables: pointers must be 4-byte aligned");
+	return launch_tf_tables(ctx, d_tf, tf, d_tables, (hipStream_t) stream);
+}
+
+int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_tf, uint32_t *d_tables, void *stream)
+{
+	return vkv_transfer_function_tables(ctx, d_tf, nullptr, d_tables, stream);
 }
 
 int vkv_render(vkv_ctx *ctx, const VkvRenderParams *P, void *stream)

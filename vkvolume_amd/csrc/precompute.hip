@@ -1282,10 +1282,56 @@ int launch_pack_volume(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_grad
 	return check_launch(ctx, "pack_volume");
 }
 
-int launch_tf_bits(vkv_ctx *ctx, const uint8_t *d_tf, uint32_t *d_bits, hipStream_t s)
+// Separable alpha tables of the reference's transfer function (src/volume_component.cpp:246-261) from the uniform's fields, and
+// the flag word.  has_tf == 0: no claim, flag clear.
+__global__ void __launch_bounds__(256) k_tf_tables_init(uint32_t *__restrict__ tables, int has_tf, float imin, float iinv, float gmin, float ginv, int use_gradient)
 {
-	hipLaunchKernelGGL(k_tf_bits, dim3(8), dim3(256), 0, s, d_tf, d_bits);
-	return check_launch(ctx, "transfer_function_bits");
+	const int   i = threadIdx.x;
+	const float x = (float) i / 255.0f;
+	float       ai = (x - imin) * iinv, ag = 1.0f;
+	ai = (ai < 0.0f) ? 0.0f : ai, ai = (1.0f < ai) ? 1.0f : ai;        // std::max / std::min as the host writes them
+	if (use_gradient)
+	{
+		ag = (x - gmin) * ginv;
+		ag = (ag < 0.0f) ? 0.0f : ag, ag = (1.0f < ag) ? 1.0f : ag;
+	}
+	tables[kTfAiWord + i] = __float_as_uint(ai);
+	tables[kTfAgWord + i] = __float_as_uint(ag);
+	if (i < 4)
+		tables[kTfFlagWord + i] = (i == 0 && has_tf) ? kTfFlagSeparable : 0u;
+}
+
+// alpha > 0 bit table + the check of the separable claim against every texel (clears the flag on the first mismatch)
+__global__ void __launch_bounds__(256) k_tf_tables(const uint8_t *__restrict__ tf_rgba8, uint32_t *__restrict__ tables, int has_tf)
+{
+	const uint32_t w = blockIdx.x * 256 + threadIdx.x;        // 2048 words of 32 texels
+	if (w >= 2048)
+		return;
+	uint32_t v = 0;
+	bool     ok = true;
+	for (int i = 0; i < 32; ++i)
+	{
+		const uint32_t t     = w * 32 + i;
+		const uint32_t texel = reinterpret_cast<const uint32_t *>(tf_rgba8)[t];
+		v |= ((texel >> 24) > 0 ? 1u : 0u) << i;
+		if (has_tf)
+		{
+			const uint32_t b = tf_separable_alpha(__uint_as_float(tables[kTfAiWord + (t & 255u)]), __uint_as_float(tables[kTfAgWord + (t >> 8)]));
+			ok               = ok && texel == b * 0x01010101u;
+		}
+	}
+	tables[w] = v;
+	if (has_tf && !ok)
+		atomicAnd(&tables[kTfFlagWord], ~kTfFlagSeparable);
+}
+
+int launch_tf_tables(vkv_ctx *ctx, const uint8_t *d_tf, const VkvTransferFunctionUniform *tf, uint32_t *d_tables, hipStream_t s)
+{
+	const int has_tf = tf != nullptr;
+	hipLaunchKernelGGL(k_tf_tables_init, dim3(1), dim3(256), 0, s, d_tables, has_tf, has_tf ? tf->intensity_min : 0.0f, has_tf ? tf->intensity_range_inv : 0.0f,
+	                   has_tf ? tf->gradient_min : 0.0f, has_tf ? tf->gradient_range_inv : 0.0f, has_tf ? (int) (tf->use_gradient != 0) : 0);
+	hipLaunchKernelGGL(k_tf_tables, dim3(8), dim3(256), 0, s, d_tf, d_tables, has_tf);
+	return check_launch(ctx, "transfer_function_tables");
 }
 
 // --- synthetic volume: host builds the shell table (same definition as DESIGN.md "Synthetic inputs") ---

@@ -1,0 +1,1176 @@
+// raymarch_core.hpp — device code of the ray-march integrator with block / Chebyshev / anisotropic-Chebyshev empty-space
+// skipping and early ray termination, for gfx950.  Included by raymarch.hip (the product's instantiations and launchers) and by
+// tools/lab/rm_lab.hip (experimental instantiations that are A/B-ed on the GPU before they move into the product).
+//
+// Replaces VolumeRenderSubpass::draw (src/volume_render_subpass.cpp:159-294) and the shaders it binds:
+// shaders/volume_render.frag (integrator), shaders/transfer_function.glsl (get_color) and the two vertex
+// shaders (ray entry; here an analytic per-pixel box / clip-plane intersection, there is no rasteriser on CDNA).
+//
+// The frag's compile-time variants (volume_render_subpass.cpp:57-92) are template parameters.  Three schedulers share the
+// per-ray set-up and finish (ray_setup / ray_finish):
+//   k_raymarch_er          "evaluate + replay": W lanes share one ray.  Every iteration the W lanes evaluate the W loop
+//                          positions i .. i+W-1 of their ray side by side (probe byte, trilinear footprint, transfer function,
+//                          skip length: uniform code, one memory round trip), then all of them replay the frag's sequential
+//                          state machine over the W results in order (registers only, quad-permute broadcasts).  The event
+//                          sequence of a ray — counters, blend order — is exactly the frag's; the number of dependent memory
+//                          round trips per ray shrinks.  W = 1 is one lane per ray.
+//   k_raymarch_tiles       round 1 kernel: one lane per ray, divergent probe / sample branches (kept for A/B)
+//   k_raymarch_persistent  resident waves pull 8x8 tiles from per-XCD queues and re-fill lanes whose rays have ended
+//                          (ballot + mbcnt compaction); bit-identical, slower (the re-fill breaks the coherence of a wave)
+#pragma once
+
+#include "vkv_device.hpp"
+
+using namespace vkv;
+
+constexpr int kTraceWords = 8;        // u64 words per wave of the diagnostic trace buffer
+
+struct RayMarchArgs
+{
+	// ray generator + RayCastUniform
+	float dir00[3], ddx[3], ddy[3];
+	float cam[3];
+	float plane_tex[4];
+	float block_size[3];
+	// CameraUniform matrices needed for gl_FragDepth (frag:319)
+	float model[16], view[16], proj[16];
+	float view_proj_inv[16], model_inv[16];        // DEPTH_ATTACHMENT only (frag:154-156)
+	// TransferFunctionUniform
+	float sampling_factor, grad_modifier;
+	// extents
+	int W, H, D, mw, mh, md;
+	const uint8_t * vol, *grad, *tf;
+	const uint8_t * packed;         // vkv_pack_volume image (PACKED variants) or null
+	int             pmx, pmy;       // macro-bricks per axis of the packed image
+	const uint32_t *tf_bits;        // vkv_transfer_function_tables buffer (alpha>0 bit table, flags, separable alpha tables) or null
+	const uint8_t * maps[8];
+	float *         out_color;
+	uint8_t *       out_rgba8;
+	uint32_t *      out_counts;
+	float *         out_depth;
+	const float *   in_depth;           // scene depth (options.depth_attachment) or null
+	uint32_t        depth_attachment, blend;
+	uint32_t        img_w, img_h, tile_w, tile_h, tiles_x, tile_first, tile_stride, tile_count, compact;
+	uint32_t        blocks_per_tile_x, blocks_per_tile, nblocks;
+	int             test;
+	unsigned long long *trace;      // diagnostic (tools/wave_trace.py): kTraceWords x u64 per wave {t_start, t_end, iterations, unit, phase sums}, or null
+	int             back;           // ceil(sampling_factor): the step back after a probe that found an occupied cell (frag:253)
+	uint32_t *      queue_heads;        // persistent scheduler: 8 tile-queue heads (one per XCD label), zeroed per launch
+	float           alpha_lut[256];     // opacity correction keyed by the TF alpha byte (frag:283)
+};
+
+// Per-lane ray state (everything main() of the frag keeps across loop iterations).
+struct Ray
+{
+	float          ex, ey, ez;         // ray_entry
+	float          sx, sy, sz;         // step_volume
+	float          six, siy, siz;      // step_dist_texel_inv (frag:195)
+	const uint8_t *dmap;               // distance map of this ray (anisotropic: chosen by direction octant, frag:209)
+	int            n_steps, i, i_min;
+	int            ulx, uly, ulz;      // u_last_alpha
+	uint32_t       ul;                 // u_last_alpha as a linear cell index (k_raymarch_er)
+	int            first_hit;
+	bool           occupied;
+	float          r, g, b, a;         // out_color
+	float          depth;
+	uint32_t       n_vol, n_dist, n_empty;
+	uint32_t       o;                  // output index of the pixel
+	bool           fragment;           // false: no fragment for this pixel (not covered, or discarded by the depth test)
+};
+
+// Linear filter, clamp-to-edge (sampler: src/volume_component.cpp:139-148); see DESIGN.md "Pinned numerics".
+__device__ __forceinline__ float sample_linear(const uint8_t *__restrict__ tex, int W, int H, int D, float px, float py, float pz)
+{
+	const float cx = __builtin_fmaf(px, (float) W, -0.5f), cy = __builtin_fmaf(py, (float) H, -0.5f), cz = __builtin_fmaf(pz, (float) D, -0.5f);
+	const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy), fz = __builtin_floorf(cz);
+	const float wx = cx - fx, wy = cy - fy, wz = cz - fz;
+	const int   ix = (int) fx, iy = (int) fy, iz = (int) fz;
+	const int   x0 = i_clamp(ix, 0, W - 1), x1 = i_clamp(ix + 1, 0, W - 1);
+	const int   y0 = i_clamp(iy, 0, H - 1), y1 = i_clamp(iy + 1, 0, H - 1);
+	const int   z0 = i_clamp(iz, 0, D - 1), z1 = i_clamp(iz + 1, 0, D - 1);
+	const size_t r00 = ((size_t) z0 * (size_t) H + (size_t) y0) * (size_t) W, r10 = ((size_t) z0 * (size_t) H + (size_t) y1) * (size_t) W;
+	const size_t r01 = ((size_t) z1 * (size_t) H + (size_t) y0) * (size_t) W, r11 = ((size_t) z1 * (size_t) H + (size_t) y1) * (size_t) W;
+	const float b000 = tex[r00 + x0], b100 = tex[r00 + x1];
+	const float b010 = tex[r10 + x0], b110 = tex[r10 + x1];
+	const float b001 = tex[r01 + x0], b101 = tex[r01 + x1];
+	const float b011 = tex[r11 + x0], b111 = tex[r11 + x1];
+	const float c00 = __builtin_fmaf(wx, b100 - b000, b000), c10 = __builtin_fmaf(wx, b110 - b010, b010);
+	const float c01 = __builtin_fmaf(wx, b101 - b001, b001), c11 = __builtin_fmaf(wx, b111 - b011, b011);
+	const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
+	return __builtin_fmaf(wz, c1 - c0, c0) * kInv255;
+}
+
+// Same filter on the packed image: the whole 2x2x2 footprint of BOTH textures sits in one 256-byte brick, the x pair of
+// a row is one (2-byte aligned) dword = (v0, g0, v1, g1).  Arithmetic identical to sample_linear, so results are too.
+typedef uint32_t u32_align2 __attribute__((aligned(2)));
+
+// address of the footprint's first dword + the three filter weights
+__device__ __forceinline__ const uint8_t *packed_footprint(const uint8_t *__restrict__ P, int W, int H, int D, int pmx, int pmy, float px, float py, float pz,
+                                                           float &wx, float &wy, float &wz)
+{
+	const float cx = __builtin_fmaf(px, (float) W, -0.5f), cy = __builtin_fmaf(py, (float) H, -0.5f), cz = __builtin_fmaf(pz, (float) D, -0.5f);
+	const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy), fz = __builtin_floorf(cz);
+	wx = cx - fx, wy = cy - fy, wz = cz - fz;
+	const int bx = i_clamp((int) fx, -1, W) + 1, by = i_clamp((int) fy, -1, H) + 1, bz = i_clamp((int) fz, -1, D) + 1;
+	// 32-bit brick index (macro-brick * 512 + brick-in-macro), one 64-bit shift for the byte offset
+	const uint32_t macro = ((uint32_t) (bz >> 5) * (uint32_t) pmy + (uint32_t) (by >> 5)) * (uint32_t) pmx + (uint32_t) (bx >> 5);
+	const uint32_t sub   = (uint32_t) ((((bz >> 2) & 7) << 6) | (((by >> 2) & 7) << 3) | ((bx >> 2) & 7));
+	const uint32_t in    = (uint32_t) ((((bz & 3) * 5 + (by & 3)) * 5 + (bx & 3)) * 2);
+	return P + (((uint64_t) (macro * 512u + sub)) << 8) + in;
+}
+
+// the four x-pair dwords (v0, g0, v1, g1) of rows (y0,z0), (y1,z0), (y0,z1), (y1,z1) -> filtered volume (and gradient) value
+template <bool WANT_G>
+__device__ __forceinline__ void packed_filter(uint32_t q00, uint32_t q10, uint32_t q01, uint32_t q11, float wx, float wy, float wz, float &out_v, float &out_g)
+{
+	{
+		const float b000 = (float) (q00 & 255u), b100 = (float) ((q00 >> 16) & 255u);
+		const float b010 = (float) (q10 & 255u), b110 = (float) ((q10 >> 16) & 255u);
+		const float b001 = (float) (q01 & 255u), b101 = (float) ((q01 >> 16) & 255u);
+		const float b011 = (float) (q11 & 255u), b111 = (float) ((q11 >> 16) & 255u);
+		const float c00 = __builtin_fmaf(wx, b100 - b000, b000), c10 = __builtin_fmaf(wx, b110 - b010, b010);
+		const float c01 = __builtin_fmaf(wx, b101 - b001, b001), c11 = __builtin_fmaf(wx, b111 - b011, b011);
+		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
+		out_v = __builtin_fmaf(wz, c1 - c0, c0) * kInv255;
+	}
+	if (WANT_G)
+	{
+		const float b000 = (float) ((q00 >> 8) & 255u), b100 = (float) (q00 >> 24);
+		const float b010 = (float) ((q10 >> 8) & 255u), b110 = (float) (q10 >> 24);
+		const float b001 = (float) ((q01 >> 8) & 255u), b101 = (float) (q01 >> 24);
+		const float b011 = (float) ((q11 >> 8) & 255u), b111 = (float) (q11 >> 24);
+		const float c00 = __builtin_fmaf(wx, b100 - b000, b000), c10 = __builtin_fmaf(wx, b110 - b010, b010);
+		const float c01 = __builtin_fmaf(wx, b101 - b001, b001), c11 = __builtin_fmaf(wx, b111 - b011, b011);
+		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
+		out_g = __builtin_fmaf(wz, c1 - c0, c0) * kInv255;
+	}
+}
+
+template <bool WANT_G>
+__device__ __forceinline__ void sample_packed(const uint8_t *__restrict__ P, int W, int H, int D, int pmx, int pmy, float px, float py, float pz,
+                                              float &out_v, float &out_g)
+{
+	float          wx, wy, wz;
+	const uint8_t *b   = packed_footprint(P, W, H, D, pmx, pmy, px, py, pz, wx, wy, wz);
+	const uint32_t q00 = *reinterpret_cast<const u32_align2 *>(b);
+	const uint32_t q10 = *reinterpret_cast<const u32_align2 *>(b + 10);
+	const uint32_t q01 = *reinterpret_cast<const u32_align2 *>(b + 50);
+	const uint32_t q11 = *reinterpret_cast<const u32_align2 *>(b + 60);
+	packed_filter<WANT_G>(q00, q10, q01, q11, wx, wy, wz, out_v, out_g);
+}
+
+__device__ __forceinline__ void mat4_mul_vec4(const float *m, const float *v, float *r)
+{
+#pragma unroll
+	for (int i = 0; i < 4; ++i)
+		r[i] = __builtin_fmaf(m[12 + i], v[3], __builtin_fmaf(m[8 + i], v[2], __builtin_fmaf(m[4 + i], v[1], m[i] * v[0])));
+}
+
+__device__ __forceinline__ uint8_t quantise_rgba8(float c) { return (uint8_t) __builtin_rintf(g_clamp(c, 0.0f, 1.0f) * 255.0f); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ray generation + frag:147-210.  Returns true when the ray has to be marched; false when the pixel is finished
+// already (not covered, grazing-ray early-out, or a RayEntry / RayExit test output) with its result in R.
+// ---------------------------------------------------------------------------------------------------------------
+template <int SKIP>
+__device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, uint32_t py, Ray &R)
+{
+	R.r = R.g = R.b = R.a = 0.0f;        // out_color = vec4(0) (frag:120)
+	R.depth = 0.0f;                      // gl_FragDepth = 0 (frag:140)
+	R.n_vol = R.n_dist = R.n_empty = 0;
+	R.n_steps = 0, R.i = 0, R.i_min = 0, R.first_hit = 0, R.ul = 0;
+	R.fragment = false;
+	const int W = A.W, H = A.H, D = A.D;
+
+	// ---- ray generation (replaces volume_render_clipped.vert + volume_render_plane_intersection.vert) ----------
+	const float fx = (float) px + 0.5f, fy = (float) py + 0.5f;
+	float       dx = __builtin_fmaf(fy, A.ddy[0], __builtin_fmaf(fx, A.ddx[0], A.dir00[0]));
+	float       dy = __builtin_fmaf(fy, A.ddy[1], __builtin_fmaf(fx, A.ddx[1], A.dir00[1]));
+	float       dz = __builtin_fmaf(fy, A.ddy[2], __builtin_fmaf(fx, A.ddx[2], A.dir00[2]));
+	{
+		const float len = __builtin_sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+		dx /= len, dy /= len, dz /= len;
+	}
+	const float ox = A.cam[0], oy = A.cam[1], oz = A.cam[2];
+	float       t_near = -INFINITY, t_far = INFINITY;
+	bool        miss   = false;
+	{
+		const float dv[3] = {dx, dy, dz}, ov[3] = {ox, oy, oz};
+#pragma unroll
+		for (int a = 0; a < 3; ++a)
+		{
+			if (dv[a] == 0.0f)
+			{
+				if (ov[a] < 0.0f || ov[a] > 1.0f)
+					miss = true;
+			}
+			else
+			{
+				const float inv = 1.0f / dv[a];
+				const float ta = (0.0f - ov[a]) * inv, tb = (1.0f - ov[a]) * inv;
+				t_near = g_max(t_near, g_min(ta, tb));
+				t_far  = g_min(t_far, g_max(ta, tb));
+			}
+		}
+	}
+	if (miss)
+		return false;
+	const float Ap = __builtin_fmaf(A.plane_tex[2], oz, __builtin_fmaf(A.plane_tex[1], oy, A.plane_tex[0] * ox)) + A.plane_tex[3];
+	const float Bp = __builtin_fmaf(A.plane_tex[2], dz, __builtin_fmaf(A.plane_tex[1], dy, A.plane_tex[0] * dx));
+	if (!(Bp > 0.0f))
+		return false;
+	const float t_plane = (0.0f - Ap) / Bp;
+	const float t0      = g_max(t_near, t_plane);
+	if (!(t0 < t_far))
+		return false;
+	const float ex = __builtin_fmaf(t0, dx, ox), ey = __builtin_fmaf(t0, dy, oy), ez = __builtin_fmaf(t0, dz, oz);        // ray_entry
+	R.fragment = true;
+
+	// ---- DEPTH_ATTACHMENT, frag:122-136: manual z-test of the front face against the scene depth (reverse-Z) ----
+	float frag_depth = 0.0f, frag_depth_front = 0.0f, position[4] = {0, 0, 0, 0};
+	if (A.depth_attachment)
+	{
+		const float pm[4] = {ex - 0.5f, ey - 0.5f, ez - 0.5f, 1.0f};        // position = proj * view * model * (ray_entry - 0.5) (clipped.vert:62)
+		float       a4[4], b4[4];
+		mat4_mul_vec4(A.model, pm, a4);
+		mat4_mul_vec4(A.view, a4, b4);
+		mat4_mul_vec4(A.proj, b4, position);
+		frag_depth       = A.in_depth[R.o];
+		frag_depth_front = position[2] / position[3];
+		if (frag_depth > frag_depth_front)
+		{        // discard
+			R.fragment = false;
+			return false;
+		}
+		R.depth = frag_depth;        // gl_FragDepth = frag_depth (frag:135)
+	}
+
+	// ---- frag:147-149 --------------------------------------------------------------------------------------
+	float rdx, rdy, rdz;
+	{
+		const float vx = ex - ox, vy = ey - oy, vz = ez - oz;
+		const float len = __builtin_sqrtf(__builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx)));
+		rdx = vx / len, rdy = vy / len, rdz = vz / len;
+	}
+	float xx, xy, xz, ray_distance;        // ray_exit
+	{
+		const float ix = 1.0f / rdx, iy = 1.0f / rdy, iz = 1.0f / rdz;
+		const float tminx = -ex * ix, tminy = -ey * iy, tminz = -ez * iz;
+		const float tmaxx = (1.0f - ex) * ix, tmaxy = (1.0f - ey) * iy, tmaxz = (1.0f - ez) * iz;
+		const float t2x = g_max(tminx, tmaxx), t2y = g_max(tminy, tmaxy), t2z = g_max(tminz, tmaxz);
+		const float tFar = g_min(g_min(t2x, t2y), t2z);
+		xx = __builtin_fmaf(tFar, rdx, ex), xy = __builtin_fmaf(tFar, rdy, ey), xz = __builtin_fmaf(tFar, rdz, ez);
+		const float vx = ex - xx, vy = ey - xy, vz = ez - xz;
+		ray_distance = __builtin_sqrtf(__builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx)));
+	}
+	if (A.depth_attachment)
+	{        // frag:152-164: stop the ray where it meets the depth buffer
+		const float clip[4] = {(position[0] * frag_depth) / frag_depth_front, (position[1] * frag_depth) / frag_depth_front,
+		                       (position[2] * frag_depth) / frag_depth_front, position[3]};
+		float       w4[4], m4[4];
+		mat4_mul_vec4(A.view_proj_inv, clip, w4);
+		w4[0] /= w4[3], w4[1] /= w4[3], w4[2] /= w4[3], w4[3] /= w4[3];
+		mat4_mul_vec4(A.model_inv, w4, m4);
+		const float ix = m4[0] + 0.5f, iy = m4[1] + 0.5f, iz = m4[2] + 0.5f;
+		const float vx = ex - ix, vy = ey - iy, vz = ez - iz;
+		const float dd = __builtin_sqrtf(__builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx)));
+		if (dd < ray_distance)
+		{
+			xx = ix, xy = iy, xz = iz;
+			ray_distance = dd;
+		}
+	}
+	if (A.test == VKV_TEST_RAY_ENTRY)
+	{
+		R.r = ex, R.g = ey, R.b = ez, R.a = 1.0f;
+		return false;
+	}
+	if (A.test == VKV_TEST_RAY_EXIT)
+	{
+		R.r = xx, R.g = xy, R.b = xz, R.a = 1.0f;
+		return false;
+	}
+
+	// ---- frag:176-187 --------------------------------------------------------------------------------------
+	const int   dim_max = max(max(W, H), D);
+	const float nf      = __builtin_ceilf((float) dim_max * ray_distance * A.sampling_factor);
+	if (!(nf >= 2.0f && nf <= 16777216.0f))
+		return false;
+	const float sx = (rdx * ray_distance) / (nf - 1.0f), sy = (rdy * ray_distance) / (nf - 1.0f), sz = (rdz * ray_distance) / (nf - 1.0f);
+	{
+		const float qx = ex + sx, qy = ey + sy, qz = ez + sz;
+		if (qx <= 0.0f || qy <= 0.0f || qz <= 0.0f || qx >= 1.0f || qy >= 1.0f || qz >= 1.0f)
+			return false;
+	}
+	R.ex = ex, R.ey = ey, R.ez = ez, R.sx = sx, R.sy = sy, R.sz = sz;
+	R.n_steps = (int) nf;
+
+	// ---- frag:191-214 --------------------------------------------------------------------------------------
+	R.six = R.siy = R.siz = 0.0f;
+	R.dmap                = nullptr;
+	if (SKIP != VKV_SKIP_NONE)
+	{
+		R.six = 1.0f / ((sx * (float) W) / A.block_size[0]);
+		R.siy = 1.0f / ((sy * (float) H) / A.block_size[1]);
+		R.siz = 1.0f / ((sz * (float) D) / A.block_size[2]);
+		if (SKIP == VKV_SKIP_ANISOTROPIC_DISTANCE)
+			R.dmap = A.maps[(rdz < 0 ? 1 : 0) + (rdy < 0 ? 2 : 0) + (rdx < 0 ? 4 : 0)];
+		else
+			R.dmap = A.maps[0];
+	}
+	R.i = 0, R.i_min = 0, R.ulx = R.uly = R.ulz = 0, R.ul = 0;
+	R.occupied  = true;
+	R.first_hit = R.n_steps;
+	return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One iteration of the frag's loop (frag:215-312): either one distance-map probe or one volume sample.
+// Returns true when the ray has ended (ran past n_steps, or early ray termination).
+// ---------------------------------------------------------------------------------------------------------------
+template <int SKIP, bool ERT, int GRAD, bool PACKED>
+__device__ __forceinline__ bool ray_event(const RayMarchArgs &A, Ray &R, const float *s_alpha, const float *s_unorm, const uint32_t *s_bits, bool tf_bits)
+{
+	const int   W = A.W, H = A.H, D = A.D;
+	const int   i  = R.i;
+	const float fi = (float) i;
+	const float posx = __builtin_fmaf(fi, R.sx, R.ex), posy = __builtin_fmaf(fi, R.sy, R.ey), posz = __builtin_fmaf(fi, R.sz, R.ez);
+	int         uix = 0, uiy = 0, uiz = 0;
+	float       ux = 0, uy = 0, uz = 0;
+	if (SKIP != VKV_SKIP_NONE)
+	{        // frag:192, 220-221 (volume_to_distance_map_u is the same for every ray)
+		const float kx = (float) W / A.block_size[0], ky = (float) H / A.block_size[1], kz = (float) D / A.block_size[2];
+		ux = kx * posx, uy = ky * posy, uz = kz * posz;
+		uix = i_clamp((int) ux, 0, A.mw - 1), uiy = i_clamp((int) uy, 0, A.mh - 1), uiz = i_clamp((int) uz, 0, A.md - 1);
+	}
+	const bool probe = SKIP != VKV_SKIP_NONE && !R.occupied && (uix != R.ulx || uiy != R.uly || uiz != R.ulz);        // frag:224
+
+	// ---- issue phase --------------------------------------------------------------------------------------------
+	// A wave usually holds probing and sampling lanes at once.  Issue this iteration's loads for BOTH kinds before either
+	// is consumed (lanes of the other kind read a dummy address that every lane shares), so the probe's and the sample's
+	// memory latencies overlap instead of adding up on the critical path of the wave.
+	constexpr bool kHoist = PACKED && GRAD != 2 && SKIP != VKV_SKIP_NONE;
+	uint32_t       dist_h = 0, q00 = 0, q10 = 0, q01 = 0, q11 = 0;
+	float          hwx = 0, hwy = 0, hwz = 0;
+	if (kHoist)
+	{
+		// a wave whose live lanes all probe (the empty space in front of the volume) or all sample skips the other kind's address
+		// arithmetic and loads: wave-uniform scalar branches
+		if (__ballot(probe) != 0ull)
+		{
+			const uint32_t cell = ((uint32_t) uiz * (uint32_t) A.mh + (uint32_t) uiy) * (uint32_t) A.mw + (uint32_t) uix;
+			dist_h              = R.dmap[probe ? cell : 0u];
+		}
+		if (__ballot(!probe) != 0ull)
+		{
+			const uint8_t *fp = packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, hwx, hwy, hwz);
+			const uint8_t *ba = probe ? A.packed : fp;
+			q00 = *reinterpret_cast<const u32_align2 *>(ba);
+			q10 = *reinterpret_cast<const u32_align2 *>(ba + 10);
+			q01 = *reinterpret_cast<const u32_align2 *>(ba + 50);
+			q11 = *reinterpret_cast<const u32_align2 *>(ba + 60);
+		}
+		// keep the five loads above the divergent consume code (the compiler would otherwise sink each into its branch)
+		asm volatile("" : "+v"(dist_h), "+v"(q00), "+v"(q10), "+v"(q01), "+v"(q11));
+	}
+
+	if (probe)
+	{        // frag:224-263
+		++R.n_dist;
+		uint32_t dist;
+		if (kHoist)
+			dist = dist_h;
+		else
+			dist = R.dmap[((uint32_t) uiz * (uint32_t) A.mh + (uint32_t) uiy) * (uint32_t) A.mw + (uint32_t) uix];
+		// Both outcomes of the probe are computed and selected (no nested branch: the two groups of lanes would serialise):
+		// dist > 0 skips forward (frag:236-247), dist == 0 marks the cell occupied and steps back (frag:248-262).
+		// r = clamp(u_i - u, -1, 0) (frag:234); the operand is never NaN, so the median-of-three instruction gives the same
+		// value as min(max(x, -1), 0)
+		const float rx = __builtin_amdgcn_fmed3f((float) uix - ux, -1.0f, 0.0f);
+		const float ry = __builtin_amdgcn_fmed3f((float) uiy - uy, -1.0f, 0.0f);
+		const float rz = __builtin_amdgcn_fmed3f((float) uiz - uz, -1.0f, 0.0f);
+		float       ax, ay, az;
+		if (SKIP == VKV_SKIP_BLOCK)
+		{        // frag:239: step(0, s) is 1 for s >= 0 (and for the impossible NaN), 0 for s < 0
+			ax = (((R.six < 0.0f) ? 0.0f : 1.0f) + rx) * R.six;
+			ay = (((R.siy < 0.0f) ? 0.0f : 1.0f) + ry) * R.siy;
+			az = (((R.siz < 0.0f) ? 0.0f : 1.0f) + rz) * R.siz;
+		}
+		else
+		{        // frag:242: step(0, -s) + sign(s) * dist is exactly dist for s > 0 and 1 - dist for s < 0 (s is never 0 or NaN:
+			 // it is the reciprocal of a finite number)
+			const float fd = (float) dist;
+			ax = (((R.six > 0.0f) ? fd : 1.0f - fd) + rx) * R.six;
+			ay = (((R.siy > 0.0f) ? fd : 1.0f - fd) + ry) * R.siy;
+			az = (((R.siz > 0.0f) ? fd : 1.0f - fd) + rz) * R.siz;
+		}
+		if (ax != ax) ax = INFINITY;
+		if (ay != ay) ay = INFINITY;
+		if (az != az) az = INFINITY;
+		float m = g_min(g_min(ax, ay), az);
+		m       = (m < 1073741824.0f) ? m : 1073741824.0f;
+		const int  i_skip = i + max(1, (int) __builtin_ceilf(m));
+		const int  i_back = max(i - (int) __builtin_ceilf(A.sampling_factor), R.i_min);
+		const bool empty  = dist > 0u;
+		R.i               = empty ? i_skip : i_back;
+		R.occupied        = !empty;
+		R.ulx = empty ? R.ulx : uix, R.uly = empty ? R.uly : uiy, R.ulz = empty ? R.ulz : uiz;
+		return R.i >= R.n_steps;
+	}
+
+	// frag:266-310
+	++R.n_vol;
+	uint32_t texel = 0;
+	{
+	float intensity, gradient = 1.0f;
+	if (kHoist)
+	{
+		float unused;
+		if (GRAD == 1)
+			packed_filter<true>(q00, q10, q01, q11, hwx, hwy, hwz, intensity, gradient);
+		else
+			packed_filter<false>(q00, q10, q01, q11, hwx, hwy, hwz, intensity, unused);
+	}
+	else if (PACKED)
+	{
+		float unused;
+		if (GRAD == 1)
+			sample_packed<true>(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, intensity, gradient);
+		else
+			sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, intensity, unused);
+	}
+	else
+	{
+		intensity = sample_linear(A.vol, W, H, D, posx, posy, posz);
+		if (GRAD == 1)
+			gradient = sample_linear(A.grad, W, H, D, posx, posy, posz);
+	}
+	if (GRAD == 2)
+	{        // frag:92-97
+		const float dix = 1.0f / (float) W, diy = 1.0f / (float) H, diz = 1.0f / (float) D;
+		float       t1, t2, t3, t4, unused;
+		if (PACKED)
+		{
+			sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx + dix, posy - diy, posz - diz, t1, unused);
+			sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx - dix, posy - diy, posz + diz, t2, unused);
+			sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx - dix, posy + diy, posz - diz, t3, unused);
+			sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx + dix, posy + diy, posz + diz, t4, unused);
+		}
+		else
+		{
+			t1 = sample_linear(A.vol, W, H, D, posx + dix, posy - diy, posz - diz);
+			t2 = sample_linear(A.vol, W, H, D, posx - dix, posy - diy, posz + diz);
+			t3 = sample_linear(A.vol, W, H, D, posx - dix, posy + diy, posz - diz);
+			t4 = sample_linear(A.vol, W, H, D, posx + dix, posy + diy, posz + diz);
+		}
+		const float gx = (((t1 - t2) - t3) + t4) * 0.25f;
+		const float gy = (((-t1 - t2) + t3) + t4) * 0.25f;
+		const float gz = (((-t1 + t2) - t3) + t4) * 0.25f;
+		const float len = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
+		gradient = g_clamp(len * A.grad_modifier, 0.0f, 1.0f);
+	}
+	// get_color (transfer_function.glsl:35-38): NEAREST texel.  With the bit table the occupied test (frag:276) comes
+	// from LDS and only occupied samples pay the dependent RGBA fetch.
+	const uint32_t tidx  = (uint32_t) tf_texel(gradient) * 256u + (uint32_t) tf_texel(intensity);
+	if (tf_bits)
+	{
+		if ((s_bits[tidx >> 5] >> (tidx & 31u)) & 1u)
+			texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
+	}
+	else
+		texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
+	}
+	const uint32_t ab = texel >> 24;
+	R.occupied        = ab > 0;
+	bool ended        = false;
+	if (R.occupied)
+	{
+		if (SKIP != VKV_SKIP_NONE)
+			R.ulx = uix, R.uly = uiy, R.ulz = uiz;
+		const float a  = s_alpha[ab];        // frag:283
+		// R8G8B8A8_UNORM -> float is exactly c / 255: read from the LDS table the workgroup filled with that division
+		const float r_ = s_unorm[texel & 255u] * a, g_ = s_unorm[(texel >> 8) & 255u] * a, b_ = s_unorm[(texel >> 16) & 255u] * a;
+		const float om = 1.0f - R.a;         // frag:287
+		R.r = __builtin_fmaf(om, r_, R.r), R.g = __builtin_fmaf(om, g_, R.g), R.b = __builtin_fmaf(om, b_, R.b);
+		R.a = __builtin_fmaf(om, a, R.a);
+		if (a > 0.0f)
+			R.first_hit = i;
+		if (ERT && R.a > 0.99f)
+		{        // frag:293-299
+			R.a   = 1.0f;
+			ended = true;
+		}
+	}
+	else
+		++R.n_empty;
+	if (!ended)
+	{
+		R.i     = i + 1;
+		R.i_min = R.i;
+		ended   = R.i >= R.n_steps;
+	}
+	return ended;
+}
+
+// frag:315-334 + the stores.  `marched` is false for pixels that never entered the loop.
+__device__ __forceinline__ void ray_finish(const RayMarchArgs &A, Ray &R, bool marched)
+{
+	if (marched)
+	{
+		if (A.out_depth && R.a > 0.0f && R.first_hit < R.n_steps)
+		{        // frag:315-321
+			const float fi   = (float) R.first_hit;
+			const float p[4] = {__builtin_fmaf(fi, R.sx, R.ex) - 0.5f, __builtin_fmaf(fi, R.sy, R.ey) - 0.5f, __builtin_fmaf(fi, R.sz, R.ez) - 0.5f, 1.0f};
+			float       a4[4], b4[4], c4[4];
+			mat4_mul_vec4(A.model, p, a4);
+			mat4_mul_vec4(A.view, a4, b4);
+			mat4_mul_vec4(A.proj, b4, c4);
+			R.depth = c4[2] / c4[3];
+		}
+		if (A.test == VKV_TEST_NUM_TEXTURE_SAMPLES)
+		{        // frag:324-334
+			const int      dim_max     = max(max(A.W, A.H), A.D);
+			const uint32_t n_steps_max = (uint32_t) (__builtin_ceilf((float) dim_max * __builtin_sqrtf(3.0f)) * A.sampling_factor);
+			const float    v           = (float) (R.n_vol + R.n_dist) / (float) n_steps_max;
+			R.r = R.g = R.b = v;
+			R.a             = 1.0f;
+		}
+	}
+	const size_t o = R.o;
+	if (!R.fragment)
+	{        // no fragment: an existing target stays as it is, a fresh one holds the clear values
+		if (A.blend)
+		{
+			if (A.out_counts)
+				A.out_counts[o * 3 + 0] = A.out_counts[o * 3 + 1] = A.out_counts[o * 3 + 2] = 0;
+			return;
+		}
+		if (A.depth_attachment)
+			R.depth = A.in_depth[o];
+	}
+	else if (A.blend)
+	{        // blend state of the subpass (src/volume_render_subpass.cpp:176-190): rgb = src + (1 - src.a) * dst, a = src.a * (1 - src.a)
+		const float om = 1.0f - R.a;
+		if (A.out_color)
+		{
+			float4 d = reinterpret_cast<float4 *>(A.out_color)[o];
+			d.x = __builtin_fmaf(om, d.x, R.r), d.y = __builtin_fmaf(om, d.y, R.g), d.z = __builtin_fmaf(om, d.z, R.b), d.w = R.a * om;
+			reinterpret_cast<float4 *>(A.out_color)[o] = d;
+		}
+		if (A.out_rgba8)
+		{
+			const uint32_t d = reinterpret_cast<uint32_t *>(A.out_rgba8)[o];
+			const float    r = __builtin_fmaf(om, unorm8(d & 255u), R.r), g = __builtin_fmaf(om, unorm8((d >> 8) & 255u), R.g),
+			            b = __builtin_fmaf(om, unorm8((d >> 16) & 255u), R.b);
+			reinterpret_cast<uint32_t *>(A.out_rgba8)[o] = (uint32_t) quantise_rgba8(r) | ((uint32_t) quantise_rgba8(g) << 8) |
+			                                               ((uint32_t) quantise_rgba8(b) << 16) | ((uint32_t) quantise_rgba8(R.a * om) << 24);
+		}
+		if (A.out_counts)
+		{
+			A.out_counts[o * 3 + 0] = R.n_vol;
+			A.out_counts[o * 3 + 1] = R.n_dist;
+			A.out_counts[o * 3 + 2] = R.n_empty;
+		}
+		if (A.out_depth)
+			A.out_depth[o] = R.depth;
+		return;
+	}
+	if (A.out_color)
+		reinterpret_cast<float4 *>(A.out_color)[o] = make_float4(R.r, R.g, R.b, R.a);
+	if (A.out_rgba8)
+		reinterpret_cast<uint32_t *>(A.out_rgba8)[o] = (uint32_t) quantise_rgba8(R.r) | ((uint32_t) quantise_rgba8(R.g) << 8) |
+		                                               ((uint32_t) quantise_rgba8(R.b) << 16) | ((uint32_t) quantise_rgba8(R.a) << 24);
+	if (A.out_counts)
+	{
+		A.out_counts[o * 3 + 0] = R.n_vol;
+		A.out_counts[o * 3 + 1] = R.n_dist;
+		A.out_counts[o * 3 + 2] = R.n_empty;
+	}
+	if (A.out_depth)
+		A.out_depth[o] = R.depth;
+}
+
+// 8x8 work unit `u` (4 per 16x16 block of the tile schedule) + ray slot in the unit -> pixel and output index.
+__device__ __forceinline__ bool unit_pixel(const RayMarchArgs &A, uint32_t u, uint32_t slot, uint32_t &px, uint32_t &py, uint32_t &o)
+{
+	const uint32_t b = u >> 2, w = u & 3u;
+	const uint32_t k = b / A.blocks_per_tile, sb = b % A.blocks_per_tile;
+	const uint32_t t = A.tile_first + k * A.tile_stride;
+	const uint32_t lx = (sb % A.blocks_per_tile_x) * 16 + (w & 1) * 8 + (slot & 7);
+	const uint32_t ly = (sb / A.blocks_per_tile_x) * 16 + (w >> 1) * 8 + (slot >> 3);
+	px = (t % A.tiles_x) * A.tile_w + lx, py = (t / A.tiles_x) * A.tile_h + ly;
+	o  = A.compact ? (k * A.tile_h + ly) * A.tile_w + lx : py * A.img_w + px;
+	return px < A.img_w && py < A.img_h;
+}
+
+__device__ __forceinline__ void stage_tables(const RayMarchArgs &A, float *s_alpha, float *s_unorm, uint32_t *s_bits)
+{
+	for (int i = threadIdx.x; i < 256; i += blockDim.x)
+	{
+		s_alpha[i] = A.alpha_lut[i];
+		s_unorm[i] = unorm8(i);        // exact IEEE division, once per workgroup
+	}
+	if (A.tf_bits)
+		for (int i = threadIdx.x; i < 2048; i += blockDim.x)
+			s_bits[i] = A.tf_bits[i];
+	__syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Static scheduler: workgroup = 16x16 pixels, wave = 8x8 pixels.
+// ---------------------------------------------------------------------------------------------------------------
+// WPB = waves per workgroup: 4 (one workgroup = one 16x16 pixel block) or 2 (half a block: wave slots and LDS are handed back
+// at a finer grain while the long rays of the other half are still running).
+template <int SKIP, bool ERT, int GRAD, bool PACKED, int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_raymarch_tiles(const RayMarchArgs A)
+{
+	__shared__ float    s_alpha[256], s_unorm[256];
+	__shared__ uint32_t s_bits[2048];
+	stage_tables(A, s_alpha, s_unorm, s_bits);
+	const bool     tf_bits = A.tf_bits != nullptr;
+	// Hardware deals workgroup ids round-robin over the 8 XCDs (own L2 each).  XCD x = id & 7 marches the schedule's
+	// tiles k = x, x + 8, x + 16, ... one after the other: neighbouring workgroups of an XCD share a tile (L2 locality)
+	// while the tiles of the frame are spread evenly over the XCDs (ESS makes screen regions differ >10x in cost; a
+	// contiguous band per XCD left most of the chip idle behind the XCD that owned the centre of the image).
+	constexpr uint32_t kParts = 4 / WPB;        // workgroups per 16x16 block
+	const uint32_t x = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+	const uint32_t k = (idx / (A.blocks_per_tile * kParts)) * 8u + x, sbp = idx % (A.blocks_per_tile * kParts);
+	const uint32_t sb = sbp / kParts, part = sbp % kParts;
+	if (k >= A.tile_count)
+		return;
+	uint32_t px, py, o;
+	if (!unit_pixel(A, (k * A.blocks_per_tile + sb) * 4 + part * WPB + (threadIdx.x >> 6), threadIdx.x & 63, px, py, o))
+		return;
+	Ray R;
+	R.o = o;
+	const unsigned long long t_start = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+	const bool marched = ray_setup<SKIP>(A, px, py, R);
+	uint32_t   iter    = 0;
+	if (marched)
+	{
+		// The frame time is the critical path of the wave with the longest ray: once a wave has run 48 events it is one of
+		// those, so let it win instruction arbitration against the younger waves on its SIMD.
+		while (!ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_unorm, s_bits, tf_bits))
+			if (__builtin_amdgcn_readfirstlane(++iter) == 48u)        // provably wave-uniform: a real scalar branch
+				__builtin_amdgcn_s_setprio(3);
+	}
+	ray_finish(A, R, marched);
+	if (A.trace)
+	{        // diagnostic only: per-wave timeline (100 MHz clock); the values never feed an output
+		uint32_t it = iter;
+		for (int o2 = 32; o2 > 0; o2 >>= 1)
+			it = max(it, (uint32_t) __shfl_xor((int) it, o2));
+		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+		if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)))
+		{
+			unsigned long long *rec = A.trace + ((size_t) blockIdx.x * WPB + (threadIdx.x >> 6)) * kTraceWords;
+			rec[0] = t_start, rec[1] = t_end, rec[2] = it, rec[3] = ((unsigned long long) __builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (k * A.blocks_per_tile + sb);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent scheduler.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kInvalidUnit  = 0xffffffffu;
+constexpr uint32_t kRefillLanes  = 16;        // re-fill a wave once this many lanes are idle
+
+// Queue q owns the schedule's tiles k = q, q + 8, ... (same tile -> XCD mapping as the static scheduler); its v-th
+// work unit is 8x8 sub-tile v % upt of its (v / upt)-th tile, upt = 4 * blocks_per_tile units per tile.
+__device__ __forceinline__ uint32_t queue_units(const RayMarchArgs &A, uint32_t q)
+{
+	const uint32_t tiles = A.tile_count > q ? (A.tile_count - q + 7u) >> 3 : 0u;
+	return tiles * A.blocks_per_tile * 4u;
+}
+
+// Pop one unit for this wave (wave-uniform result).  Starts at the wave's own queue and steals from the others once
+// it is empty.  `q` is updated to the queue that delivered.
+__device__ __forceinline__ uint32_t pop_unit(const RayMarchArgs &A, uint32_t &q)
+{
+	const uint32_t upt = A.blocks_per_tile * 4u;
+	for (uint32_t tries = 0; tries < 8; ++tries)
+	{
+		uint32_t v = 0;
+		if ((threadIdx.x & 63) == 0)
+			v = atomicAdd(&A.queue_heads[q], 1u);
+		v = __builtin_amdgcn_readfirstlane(v);
+		if (v < queue_units(A, q))
+			return ((v / upt) * 8u + q) * upt + v % upt;
+		q = (q + 1) & 7u;
+	}
+	return kInvalidUnit;
+}
+
+template <int SKIP, bool ERT, int GRAD, bool PACKED>
+__global__ void __launch_bounds__(256) k_raymarch_persistent(const RayMarchArgs A)
+{
+	__shared__ float    s_alpha[256], s_unorm[256];
+	__shared__ uint32_t s_bits[2048];
+	stage_tables(A, s_alpha, s_unorm, s_bits);
+	const bool     tf_bits = A.tf_bits != nullptr;
+	// blocks b and b + 8 share an XCD under the observed round-robin placement (speed only, never correctness)
+	uint32_t q      = blockIdx.x & 7u;
+	uint32_t unit   = pop_unit(A, q);
+	uint32_t cursor = 0;        // next unassigned ray slot of `unit`
+	bool     active = false;
+	Ray      R;
+	R.o = 0;
+
+	for (;;)
+	{
+		uint64_t idle   = __ballot(!active);
+		uint32_t n_idle = (uint32_t) __popcll(idle);
+		// ---- re-fill: idle lanes take the next ray slots of the current unit, in lane order ----
+		while (n_idle >= kRefillLanes && unit != kInvalidUnit)
+		{
+			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
+			const uint32_t take = min(n_idle, 64u - cursor);
+			if (!active && rank < take)
+			{
+				uint32_t px, py, o;
+				if (unit_pixel(A, unit, cursor + rank, px, py, o))
+				{
+					R.o    = o;
+					active = ray_setup<SKIP>(A, px, py, R);
+					if (!active)
+						ray_finish(A, R, false);        // not covered / early-out / entry-exit test: result is final
+				}
+			}
+			cursor += take;
+			if (cursor == 64)
+			{
+				unit   = pop_unit(A, q);
+				cursor = 0;
+			}
+			idle   = __ballot(!active);
+			n_idle = (uint32_t) __popcll(idle);
+		}
+		if (n_idle == 64)
+			break;        // nothing in flight and the queues are empty
+		// ---- one event per active lane ----
+		if (active)
+		{
+			if (ray_event<SKIP, ERT, GRAD, PACKED>(A, R, s_alpha, s_unorm, s_bits, tf_bits))
+			{
+				ray_finish(A, R, true);
+				active = false;
+			}
+		}
+	}
+}
+
+
+// ===============================================================================================================
+// "Evaluate + replay" scheduler (k_raymarch_er)
+// ===============================================================================================================
+// LDS tables of a workgroup.  sep = the transfer function is the separable greyscale product (kTfFlagSeparable): the texel's
+// alpha byte comes from ai[] x ag[], its colour contribution from pair[]; otherwise the alpha > 0 bit table gates the RGBA fetch.
+struct RmLds
+{
+	float alpha[256];        // opacity correction keyed by the alpha byte (frag:283)
+	union
+	{
+		struct
+		{
+			uint32_t bits[2048];
+			float    unorm[256];        // byte / 255 (exact IEEE division)
+		} g;
+		struct
+		{
+			float  ai[256], ag[256];
+			float2 pair[256];        // {alpha_lut[b], (b / 255) * alpha_lut[b]}: corrected opacity and premultiplied grey of alpha byte b
+		} s;
+	};
+};
+
+__device__ __forceinline__ bool stage_tables_er(const RayMarchArgs &A, RmLds &L)
+{
+	const bool sep = A.tf_bits != nullptr && (A.tf_bits[kTfFlagWord] & kTfFlagSeparable) != 0u;        // wave-uniform (scalar load)
+	for (int i = threadIdx.x; i < 256; i += blockDim.x)
+	{
+		const float a = A.alpha_lut[i];
+		L.alpha[i]    = a;
+		if (sep)
+		{
+			L.s.ai[i]   = __uint_as_float(A.tf_bits[kTfAiWord + i]);
+			L.s.ag[i]   = __uint_as_float(A.tf_bits[kTfAgWord + i]);
+			L.s.pair[i] = make_float2(a, unorm8(i) * a);
+		}
+		else
+			L.g.unorm[i] = unorm8(i);
+	}
+	if (!sep && A.tf_bits)
+		for (int i = threadIdx.x; i < 2048; i += blockDim.x)
+			L.g.bits[i] = A.tf_bits[i];
+	__syncthreads();
+	return sep;
+}
+
+// What the evaluation of one loop position hands to the replay.
+struct Entry
+{
+	uint32_t cell;        // linear index of the distance-map cell of the position (frag:220-221)
+	int      skip;        // probe outcome: 0 = the cell is occupied (dist == 0), else the skip length max(1, ceil(...)) (frag:244-247)
+	uint32_t tx;          // sample outcome: separable TF: the alpha byte; generic: the RGBA8 texel (0 when its alpha is 0)
+	float    a, c;        // corrected opacity of the sample and (separable TF) its premultiplied grey value
+};
+
+// value of `v` in lane KK of this lane's group of W lanes
+template <int W, int KK>
+__device__ __forceinline__ uint32_t group_bcast(uint32_t v)
+{
+	if (W == 1)
+		return v;
+	if (W == 2)
+		return (uint32_t) __builtin_amdgcn_mov_dpp((int) v, KK == 0 ? 0xA0 : 0xF5, 0xf, 0xf, true);        // quad_perm [0,0,2,2] / [1,1,3,3]
+	if (W == 4)
+		return (uint32_t) __builtin_amdgcn_mov_dpp((int) v, KK * 0x55, 0xf, 0xf, true);        // quad_perm [KK,KK,KK,KK]
+	return (uint32_t) __shfl((int) v, (int) ((threadIdx.x & 63u & ~(uint32_t) (W - 1)) + KK));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Evaluate loop position p of ray R: everything the frag's loop body reads from memory at that position, for BOTH kinds
+// of event (frag:220-247 probe, frag:266-284 sample).  want_dist / want_sample say which loads can be needed; the other
+// kind's loads read a dummy address and its results are never used.
+// ---------------------------------------------------------------------------------------------------------------
+template <int SKIP, int GRAD, bool PACKED, bool STAMP, bool MASKED>
+__device__ __forceinline__ void er_evaluate(const RayMarchArgs &A, const Ray &R, int p, int k, bool full, bool sep, const RmLds &L, Entry &E,
+                                            unsigned long long &t_issued, unsigned long long &t_returned)
+{
+	const int   W = A.W, H = A.H, D = A.D;
+	const float fp = (float) p;
+	const float posx = __builtin_fmaf(fp, R.sx, R.ex), posy = __builtin_fmaf(fp, R.sy, R.ey), posz = __builtin_fmaf(fp, R.sz, R.ez);
+	int         uix = 0, uiy = 0, uiz = 0;
+	float       ux = 0, uy = 0, uz = 0;
+	uint32_t    cell = 0;
+	if (SKIP != VKV_SKIP_NONE)
+	{        // frag:192, 220-221
+		const float kx = (float) W / A.block_size[0], ky = (float) H / A.block_size[1], kz = (float) D / A.block_size[2];
+		ux = kx * posx, uy = ky * posy, uz = kz * posz;
+		uix = i_clamp((int) ux, 0, A.mw - 1), uiy = i_clamp((int) uy, 0, A.mh - 1), uiz = i_clamp((int) uz, 0, A.md - 1);
+		cell = ((uint32_t) uiz * (uint32_t) A.mh + (uint32_t) uiy) * (uint32_t) A.mw + (uint32_t) uix;
+	}
+	// the first position of the window is the ray's next event and its kind is known (frag:224); later positions get both
+	bool want_dist = SKIP != VKV_SKIP_NONE, want_sample = true;
+	if (SKIP != VKV_SKIP_NONE && k == 0 && !full)
+	{
+		const bool probe0 = !R.occupied && cell != R.ul;
+		want_dist = probe0, want_sample = !probe0;
+	}
+	E.cell = cell;
+
+	// ---- issue phase: probe byte and footprint of this position together --------------------------------------------
+	constexpr bool kHoist = PACKED && GRAD != 2;
+	uint32_t       dist = 0, q00 = 0, q10 = 0, q01 = 0, q11 = 0;
+	float          wx = 0, wy = 0, wz = 0;
+	if (MASKED)
+	{        // the texture addresser's time per load grows with the number of active lanes (tools/micro/gather_mask.hip): lanes that
+		 // cannot need a kind of load sit it out under EXEC instead of reading a dummy address
+		if (SKIP != VKV_SKIP_NONE && want_dist)
+			dist = R.dmap[cell];
+		if (kHoist && want_sample)
+		{
+			const uint8_t *ba = packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, wx, wy, wz);
+			q00 = *reinterpret_cast<const u32_align2 *>(ba);
+			q10 = *reinterpret_cast<const u32_align2 *>(ba + 10);
+			q01 = *reinterpret_cast<const u32_align2 *>(ba + 50);
+			q11 = *reinterpret_cast<const u32_align2 *>(ba + 60);
+		}
+	}
+	else
+	{
+		if (SKIP != VKV_SKIP_NONE)
+			dist = R.dmap[want_dist ? cell : 0u];
+		if (kHoist)
+		{
+			const uint8_t *fpa = packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, wx, wy, wz);
+			const uint8_t *ba  = want_sample ? fpa : A.packed;
+			q00 = *reinterpret_cast<const u32_align2 *>(ba);
+			q10 = *reinterpret_cast<const u32_align2 *>(ba + 10);
+			q01 = *reinterpret_cast<const u32_align2 *>(ba + 50);
+			q11 = *reinterpret_cast<const u32_align2 *>(ba + 60);
+		}
+	}
+	asm volatile("" : "+v"(dist), "+v"(q00), "+v"(q10), "+v"(q01), "+v"(q11));
+	if (STAMP)
+	{        // diagnostic build only: when were the loads issued, when had they all returned
+		t_issued = __builtin_amdgcn_s_memtime();
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		asm volatile("" : "+v"(dist), "+v"(q00), "+v"(q10), "+v"(q01), "+v"(q11));
+		t_returned = __builtin_amdgcn_s_memtime();
+	}
+
+	// ---- probe outcome (frag:234-247) ---------------------------------------------------------------------------------
+	E.skip = 0;
+	if (SKIP != VKV_SKIP_NONE)
+	{
+		const float rx = __builtin_amdgcn_fmed3f((float) uix - ux, -1.0f, 0.0f);
+		const float ry = __builtin_amdgcn_fmed3f((float) uiy - uy, -1.0f, 0.0f);
+		const float rz = __builtin_amdgcn_fmed3f((float) uiz - uz, -1.0f, 0.0f);
+		float       ax, ay, az;
+		if (SKIP == VKV_SKIP_BLOCK)
+		{
+			ax = (((R.six < 0.0f) ? 0.0f : 1.0f) + rx) * R.six;
+			ay = (((R.siy < 0.0f) ? 0.0f : 1.0f) + ry) * R.siy;
+			az = (((R.siz < 0.0f) ? 0.0f : 1.0f) + rz) * R.siz;
+		}
+		else
+		{
+			const float fd = (float) dist;
+			ax = (((R.six > 0.0f) ? fd : 1.0f - fd) + rx) * R.six;
+			ay = (((R.siy > 0.0f) ? fd : 1.0f - fd) + ry) * R.siy;
+			az = (((R.siz > 0.0f) ? fd : 1.0f - fd) + rz) * R.siz;
+		}
+		// a NaN component (0 * inf on an axis-parallel ray) counts as +inf: minNum ignores it; all three cannot be NaN, and if they
+		// were the comparison below caps the result exactly as the select chain of the oracle does
+		float m = __builtin_fminf(__builtin_fminf(ax, ay), az);
+		m       = (m < 1073741824.0f) ? m : 1073741824.0f;
+		E.skip  = dist > 0u ? max(1, (int) __builtin_ceilf(m)) : 0;
+	}
+
+	// ---- sample outcome (frag:272-284) -------------------------------------------------------------------------------
+	float intensity = 0.0f, gradient = 1.0f;
+	if (kHoist)
+	{
+		float unused;
+		if (GRAD == 1)
+			packed_filter<true>(q00, q10, q01, q11, wx, wy, wz, intensity, gradient);
+		else
+			packed_filter<false>(q00, q10, q01, q11, wx, wy, wz, intensity, unused);
+	}
+	else if (want_sample)
+	{
+		float unused;
+		if (PACKED)
+		{
+			if (GRAD == 1)
+				sample_packed<true>(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, intensity, gradient);
+			else
+				sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, intensity, unused);
+		}
+		else
+		{
+			intensity = sample_linear(A.vol, W, H, D, posx, posy, posz);
+			if (GRAD == 1)
+				gradient = sample_linear(A.grad, W, H, D, posx, posy, posz);
+		}
+		if (GRAD == 2)
+		{        // frag:92-97
+			const float dix = 1.0f / (float) W, diy = 1.0f / (float) H, diz = 1.0f / (float) D;
+			float       t1, t2, t3, t4;
+			if (PACKED)
+			{
+				sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx + dix, posy - diy, posz - diz, t1, unused);
+				sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx - dix, posy - diy, posz + diz, t2, unused);
+				sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx - dix, posy + diy, posz - diz, t3, unused);
+				sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx + dix, posy + diy, posz + diz, t4, unused);
+			}
+			else
+			{
+				t1 = sample_linear(A.vol, W, H, D, posx + dix, posy - diy, posz - diz);
+				t2 = sample_linear(A.vol, W, H, D, posx - dix, posy - diy, posz + diz);
+				t3 = sample_linear(A.vol, W, H, D, posx - dix, posy + diy, posz - diz);
+				t4 = sample_linear(A.vol, W, H, D, posx + dix, posy + diy, posz + diz);
+			}
+			const float gx = (((t1 - t2) - t3) + t4) * 0.25f;
+			const float gy = (((-t1 - t2) + t3) + t4) * 0.25f;
+			const float gz = (((-t1 + t2) - t3) + t4) * 0.25f;
+			const float len = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
+			gradient = g_clamp(len * A.grad_modifier, 0.0f, 1.0f);
+		}
+	}
+	// get_color (transfer_function.glsl:35-38): NEAREST texel
+	const uint32_t ti = (uint32_t) tf_texel(intensity), tg = (uint32_t) tf_texel(gradient);
+	if (sep)
+	{
+		const uint32_t ab = tf_separable_alpha(L.s.ai[ti], L.s.ag[tg]);
+		const float2   pr = L.s.pair[ab];
+		E.tx = ab, E.a = pr.x, E.c = pr.y;
+	}
+	else
+	{
+		const uint32_t tidx  = tg * 256u + ti;
+		uint32_t       texel = 0;
+		if (A.tf_bits)
+		{
+			if (want_sample && ((L.g.bits[tidx >> 5] >> (tidx & 31u)) & 1u))
+				texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
+		}
+		else if (want_sample)
+			texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
+		texel = (texel >> 24) ? texel : 0u;
+		E.tx = texel, E.a = L.alpha[texel >> 24], E.c = 0.0f;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Replay: one step of the frag's state machine (frag:215-312) for loop position q with the evaluated entry e.
+// Nothing happens unless the ray's loop index IS q.  can_fuse: e holds the sample of q as well as the probe, so a probe
+// that finds the cell occupied and steps back onto q itself (frag:253-261) goes on to take that sample in the same step.
+// ---------------------------------------------------------------------------------------------------------------
+template <int SKIP, bool ERT>
+__device__ __forceinline__ void er_replay(const RayMarchArgs &A, Ray &R, float &grey, bool &done, const Entry &e, int q, bool can_fuse, bool sep, const RmLds &L)
+{
+	// Straight-line, predicated: the lanes of a wave disagree about almost every condition below, nested branches would
+	// only serialise short pieces of arithmetic behind EXEC-mask bookkeeping.
+	const bool act    = !done && R.i == q;
+	const bool probe  = SKIP != VKV_SKIP_NONE && act && !R.occupied && e.cell != R.ul;        // frag:224
+	const bool p_skip = probe && e.skip > 0;                                                     // frag:236-247
+	const bool p_occ  = probe && e.skip == 0;                                                    // frag:248-262
+	const int  jb     = max(q - A.back, R.i_min);
+	const bool fuse   = p_occ && can_fuse && jb == q;
+	const bool smp    = (act && !probe) || fuse;                                                 // frag:266-310
+	const uint32_t ab = sep ? e.tx : (e.tx >> 24);
+	const bool occ_s  = ab > 0u;                                                                 // frag:276
+	const bool hit    = smp && occ_s;
+	R.n_dist += probe ? 1u : 0u;
+	R.n_vol += smp ? 1u : 0u;
+	R.n_empty += (smp && !occ_s) ? 1u : 0u;
+	// frag:283-299
+	const float a  = e.a;
+	const float om = 1.0f - R.a;
+	const float na = __builtin_fmaf(om, a, R.a);
+	if (sep)
+		grey = hit ? __builtin_fmaf(om, e.c, grey) : grey;        // r = g = b: one channel is tracked
+	else
+	{
+		const float r_ = L.g.unorm[e.tx & 255u] * a, g_ = L.g.unorm[(e.tx >> 8) & 255u] * a, b_ = L.g.unorm[(e.tx >> 16) & 255u] * a;
+		const float nr = __builtin_fmaf(om, r_, R.r), ng = __builtin_fmaf(om, g_, R.g), nb = __builtin_fmaf(om, b_, R.b);
+		R.r = hit ? nr : R.r, R.g = hit ? ng : R.g, R.b = hit ? nb : R.b;
+	}
+	const bool ended = ERT && hit && na > 0.99f;
+	R.a              = hit ? (ended ? 1.0f : na) : R.a;
+	R.first_hit      = (hit && a > 0.0f) ? q : R.first_hit;
+	// state
+	R.occupied = smp ? occ_s : (p_occ ? true : R.occupied);
+	if (SKIP != VKV_SKIP_NONE)
+		R.ul = (hit || p_occ) ? e.cell : R.ul;
+	const bool adv = smp && !ended;
+	int        ni  = R.i;
+	ni             = p_skip ? q + e.skip : ni;
+	ni             = (p_occ && !fuse) ? jb : ni;
+	ni             = adv ? q + 1 : ni;
+	R.i_min        = adv ? q + 1 : R.i_min;
+	R.i            = ni;
+	done           = done || ended || (act && ni >= R.n_steps);
+}
+
+template <int SKIP, bool ERT, int W, int KK>
+__device__ __forceinline__ void er_replay_all(const RayMarchArgs &A, Ray &R, float &grey, bool &done, const Entry &mine, int j0, bool full, bool sep, const RmLds &L)
+{
+	if constexpr (KK < W)
+	{
+		Entry e;
+		e.cell = group_bcast<W, KK>(mine.cell);
+		e.skip = (int) group_bcast<W, KK>((uint32_t) mine.skip);
+		e.tx   = group_bcast<W, KK>(mine.tx);
+		e.a    = __uint_as_float(group_bcast<W, KK>(__float_as_uint(mine.a)));
+		e.c    = __uint_as_float(group_bcast<W, KK>(__float_as_uint(mine.c)));
+		er_replay<SKIP, ERT>(A, R, grey, done, e, j0 + KK, full || KK > 0, sep, L);
+		er_replay_all<SKIP, ERT, W, KK + 1>(A, R, grey, done, mine, j0, full, sep, L);
+	}
+}
+
+// ray `rb` (0..255) of 16x16 block `b` of the tile schedule -> pixel and output index.  A wave's 64/W rays form a compact patch.
+template <int W>
+__device__ __forceinline__ bool block_pixel(const RayMarchArgs &A, uint32_t b, uint32_t rb, uint32_t &px, uint32_t &py, uint32_t &o)
+{
+	constexpr uint32_t G = 64 / W, pw = G >= 32 ? 8 : (G >= 8 ? 4 : 2), ph = G / pw, ppr = 16 / pw;
+	const uint32_t wb = rb / G, g = rb % G;        // wave of the block, ray of the wave
+	const uint32_t bx = (wb % ppr) * pw + g % pw, by = (wb / ppr) * ph + g / pw;
+	const uint32_t k = b / A.blocks_per_tile, sb = b % A.blocks_per_tile;
+	const uint32_t t  = A.tile_first + k * A.tile_stride;
+	const uint32_t lx = (sb % A.blocks_per_tile_x) * 16 + bx, ly = (sb / A.blocks_per_tile_x) * 16 + by;
+	px = (t % A.tiles_x) * A.tile_w + lx, py = (t / A.tiles_x) * A.tile_h + ly;
+	o  = A.compact ? (k * A.tile_h + ly) * A.tile_w + lx : py * A.img_w + px;
+	return px < A.img_w && py < A.img_h;
+}
+
+// FLAGS
+constexpr uint32_t kErFull  = 1u;        // every lane loads probe byte AND footprint (the first position of a window too)
+constexpr uint32_t kErStamp = 2u;        // diagnostic build: per-wave phase times into the trace buffer
+constexpr uint32_t kErMasked = 4u;       // loads a lane cannot need are masked off instead of reading a dummy address
+
+template <int SKIP, bool ERT, int GRAD, bool PACKED, int W, uint32_t FLAGS>
+__global__ void __launch_bounds__(256) k_raymarch_er(const RayMarchArgs A)
+{
+	__shared__ RmLds L;
+	const bool       sep = stage_tables_er(A, L);
+	constexpr bool   kFull = (FLAGS & kErFull) != 0, kStamp = (FLAGS & kErStamp) != 0;
+	// workgroup -> (tile of the schedule, 16x16 block of the tile, part of the block): XCD x = id & 7 marches the tiles
+	// x, x + 8, ... (see k_raymarch_tiles); a block takes W workgroups of four waves
+	const uint32_t x = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+	const uint32_t k = (idx / (A.blocks_per_tile * W)) * 8u + x, sbp = idx % (A.blocks_per_tile * W);
+	const uint32_t sb = sbp / W, part = sbp % W;
+	if (k >= A.tile_count)
+		return;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint32_t       px, py, o;
+	if (!block_pixel<W>(A, k * A.blocks_per_tile + sb, (part * 4u + wave) * (64u / W) + lane / W, px, py, o))
+		return;
+	Ray R;
+	R.o = o;
+	const unsigned long long t_start = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+	const bool marched = ray_setup<SKIP>(A, px, py, R);
+	uint32_t   iter    = 0;
+	uint32_t   ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;
+	if (marched)
+	{
+		const int kk   = (int) (lane % W);
+		bool      done = false;
+		float     grey = 0.0f;        // separable greyscale TF: the one colour channel
+		while (!done)
+		{
+			unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+			if (kStamp)
+				t0 = __builtin_amdgcn_s_memtime();
+			const int j0 = R.i;
+			Entry     E;
+			er_evaluate<SKIP, GRAD, PACKED, kStamp, (FLAGS & kErMasked) != 0>(A, R, j0 + kk, kk, kFull, sep, L, E, t1, t2);
+			if (kStamp)
+			{
+				asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+				asm volatile("" : "+v"(E.cell), "+v"(E.skip), "+v"(E.tx), "+v"(E.a), "+v"(E.c));
+				t3 = __builtin_amdgcn_s_memtime();
+			}
+			er_replay_all<SKIP, ERT, W, 0>(A, R, grey, done, E, j0, kFull, sep, L);
+			if (kStamp)
+			{
+				asm volatile("" : "+v"(R.i), "+v"(R.a));
+				t4 = __builtin_amdgcn_s_memtime();
+				// top -> loads issued -> loads returned -> entry ready -> replay done
+				ph0 += (uint32_t) (t1 - t0), ph1 += (uint32_t) (t2 - t1), ph2 += (uint32_t) (t3 - t2), ph3 += (uint32_t) (t4 - t3);
+			}
+			// the frame time is the critical path of the wave with the longest ray: once a wave has run 48 iterations it is one of
+			// those, so let it win instruction arbitration against the younger waves on its SIMD
+			if (__builtin_amdgcn_readfirstlane(++iter) == 48u)
+				__builtin_amdgcn_s_setprio(3);
+		}
+		if (sep)
+			R.r = grey, R.g = grey, R.b = grey;
+	}
+	ray_finish(A, R, marched);
+	if (A.trace)
+	{        // diagnostic only: per-wave timeline (100 MHz clock); the values never feed an output
+		uint32_t it = iter;
+		for (int o2 = 32; o2 > 0; o2 >>= 1)
+		{        // the lane that marched longest carries the wave's sums
+			it  = max(it, (uint32_t) __shfl_xor((int) it, o2));
+			ph0 = max(ph0, (uint32_t) __shfl_xor((int) ph0, o2)), ph1 = max(ph1, (uint32_t) __shfl_xor((int) ph1, o2));
+			ph2 = max(ph2, (uint32_t) __shfl_xor((int) ph2, o2)), ph3 = max(ph3, (uint32_t) __shfl_xor((int) ph3, o2));
+		}
+		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+		if (lane == (uint32_t) __builtin_ctzll(__ballot(1)))
+		{
+			unsigned long long *rec = A.trace + ((size_t) blockIdx.x * 4 + wave) * kTraceWords;
+			rec[0] = t_start, rec[1] = t_end, rec[2] = it, rec[3] = ((unsigned long long) __builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (k * A.blocks_per_tile + sb);
+			rec[4] = ph0, rec[5] = ph1, rec[6] = ph2, rec[7] = ph3;
+		}
+	}
+}
+
+namespace vkv
+{
+// raymarch.hip: VkvRenderParams -> kernel arguments (shared with tools/lab)
+int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, RayMarchArgs &a);
+}        // namespace vkv

@@ -69,6 +69,24 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb)
 	return xcd * q + min(xcd, r) + idx;
 }
 
+// ---- transfer-function acceleration tables (vkv_transfer_function_tables), uint32 words ---------------------------------
+// [0, 2048)     1 bit per texel of the 256x256 texture: alpha > 0 (row = gradient)
+// [2048]        flags: kTfFlagSeparable = every texel is (b, b, b, b) with b = (uint8) clamp((ai[col] * ag[row]) * 255, 0, 255),
+//               checked on the device for all 65536 texels with the arithmetic the integrator uses
+// [2052, 2308)  ai[256] (float bits), [2308, 2564) ag[256]
+constexpr uint32_t kTfFlagWord = 2048, kTfAiWord = 2052, kTfAgWord = 2308, kTfWords = 2564;
+constexpr uint32_t kTfFlagSeparable = 1u;
+static_assert(kTfWords == VKV_TF_BITS_WORDS, "include/vkvolume_amd.h and vkv_device.hpp disagree on the table size");
+
+// the alpha byte of a separable greyscale transfer function (src/volume_component.cpp:246-261 builds exactly this product)
+__host__ __device__ __forceinline__ uint32_t tf_separable_alpha(float ai, float ag)
+{
+	float t = (ai * ag) * 255.0f;
+	t       = (t < 0.0f) ? 0.0f : t;
+	t       = (255.0f < t) ? 255.0f : t;
+	return (uint32_t) t;
+}
+
 // ---- packed sampling layout (vkv_pack_volume) -------------------------------------------------------------------
 // Padded index j in [0, W+2] holds voxel clamp(j-1, 0, W-1), so the clamp-to-edge footprint of texel index ix is always
 // the pair (b, b+1) with b = clamp(ix, -1, W) + 1.  Brick (bx,by,bz) stores padded voxels [4b, 4b+4] per axis (5^3 with

@@ -48,6 +48,7 @@ void Volume::release()
 	if (transfer_function_bits)
 		(void) hipFree(transfer_function_bits);
 	packed                 = nullptr;
+	packed_bytes           = 0;
 	transfer_function_bits = nullptr;
 }
 
@@ -150,7 +151,8 @@ void Volume::update_transfer_function_texture(DeviceContext &dc)
 	vkv_transfer_function_texture(&o, tex.data());
 	hip_check(hipMemcpyAsync(transfer_function.data, tex.data(), tex.size(), hipMemcpyHostToDevice, (hipStream_t) dc.stream), "TF upload");
 	hip_check(hipStreamSynchronize((hipStream_t) dc.stream), "TF upload");
-	vkv_check(dc, vkv_transfer_function_bits(dc.ctx, transfer_function.data, transfer_function_bits, dc.stream), "TF bit table");
+	const TransferFunctionUniform tf = get_transfer_function_uniform();
+	vkv_check(dc, vkv_transfer_function_tables(dc.ctx, transfer_function.data, &tf, transfer_function_bits, dc.stream), "TF tables");
 }
 
 void Volume::pack(DeviceContext &dc)

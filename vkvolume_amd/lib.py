@@ -16,7 +16,7 @@ EXPORTS = [
     "vkv_transfer_function_uniform", "vkv_transfer_function_texture", "vkv_build_uniforms",
     "vkv_gradient_map", "vkv_occupancy_map", "vkv_distance_map", "vkv_distance_map_anisotropic",
     "vkv_compute_distance_map", "vkv_render", "vkv_scatter_tiles", "vkv_synth_volume",
-    "vkv_packed_volume_bytes", "vkv_pack_volume", "vkv_transfer_function_bits",
+    "vkv_packed_volume_bytes", "vkv_pack_volume", "vkv_transfer_function_bits", "vkv_transfer_function_tables",
     "vkv_occupied_voxel_count", "vkv_load_header", "vkv_load_data", "vkv_convert_volume",
 ]
 
@@ -67,6 +67,7 @@ def load():
     L.vkv_packed_volume_bytes.restype = C.c_size_t
     L.vkv_pack_volume.argtypes = [vp, vp, vp, abi.Extent3D, vp, vp]
     L.vkv_transfer_function_bits.argtypes = [vp, vp, vp, vp]
+    L.vkv_transfer_function_tables.argtypes = [vp, vp, P(abi.TransferFunctionUniform), vp, vp]
     L.vkv_occupied_voxel_count.argtypes = [vp, vp, vp, P(abi.TransferFunctionUniform), abi.Extent3D, vp, vp]
     L.vkv_convert_volume.argtypes = [vp, vp, i32, i32, C.c_float, C.c_float, C.c_uint64, vp, vp]
     L.vkv_load_header.argtypes = [C.c_char_p, P(abi.VolumeHeader)]
@@ -146,6 +147,9 @@ class Context:
 
     def transfer_function_bits(self, d_tf, d_bits, stream=0):
         self.check(self._lib.vkv_transfer_function_bits(self.handle, d_tf, d_bits, stream))
+
+    def transfer_function_tables(self, d_tf, tf, d_tables, stream=0):
+        self.check(self._lib.vkv_transfer_function_tables(self.handle, d_tf, None if tf is None else C.byref(tf), d_tables, stream))
 
     def occupied_voxel_count(self, d_volume, d_gradient, tf, extent, d_count, stream=0):
         self.check(self._lib.vkv_occupied_voxel_count(self.handle, d_volume, d_gradient, C.byref(tf), extent, d_count, stream))

@@ -87,7 +87,9 @@ class Volume:
     def update_transfer_function_texture(self):
         tex = lib.transfer_function_texture(self.options)  # CPU builds the LUT (volume_component.cpp:242-261)
         self.transfer_function.copy_(torch.from_numpy(tex), non_blocking=False)
-        self.ctx.transfer_function_bits(_ptr(self.transfer_function), _ptr(self.transfer_function_bits), _stream())
+        # acceleration tables of the texture; the separable-product claim made with the uniform is checked on the device
+        self.ctx.transfer_function_tables(_ptr(self.transfer_function), self.get_transfer_function_uniform(), _ptr(self.transfer_function_bits),
+                                          _stream())
 
     def pack(self):
         """(Re)build the bricked sampling image from the linear volume (+ gradient map).  Call after the gradient map
