@@ -31,16 +31,12 @@ for f in funcs:
             lab = mm.group(1) or mm.group(2)
             if lab in labels and labels[lab] <= i:
                 loops.append((labels[lab], i))
-    best = None
-    for a, b in loops:
-        seg = ins[a:b + 1]
-        if any(x.startswith(('global_load', 'buffer_load')) for x in seg):
-            if best is None or (b - a) > (best[1] - best[0]):
-                best = (a, b)
-    if not best:
-        continue
-    seg = ins[best[0]:best[1] + 1]
-    c = lambda p: sum(1 for x in seg if x.startswith(p))
-    print("%-70s loop %4d instr: valu %3d (dpp %2d) salu %3d vmem-load %2d vmem-store %2d lds %2d waitcnt %2d branch %2d" % (
+    # outermost loops that hold at least three vector loads and one LDS access: the march loops (one per transfer-function path)
+    cand = [(a, b) for a, b in loops if sum(1 for x in ins[a:b + 1] if x.startswith(('global_load', 'buffer_load', 'flat_load'))) >= 3 and any(x.startswith('ds_') for x in ins[a:b + 1])]
+    cand = [(a, b) for a, b in cand if not any((a2 <= a and b <= b2) and (a2, b2) != (a, b) for a2, b2 in cand)]
+    for best in cand:
+      seg = ins[best[0]:best[1] + 1]
+      c = lambda p: sum(1 for x in seg if x.startswith(p))
+      print("%-70s loop %4d instr: valu %3d (dpp %2d) salu %3d vmem-load %2d vmem-store %2d lds %2d waitcnt %2d branch %2d" % (
         name[:70], len(seg), c('v_'), sum(1 for x in seg if 'dpp' in x or 'quad_perm' in x), c('s_') - c('s_waitcnt') - c('s_cbranch') - c('s_branch'),
-        c(('global_load', 'buffer_load')), c(('global_store', 'buffer_store')), c('ds_'), c('s_waitcnt'), c(('s_cbranch', 's_branch'))))
+        c(('global_load', 'buffer_load', 'flat_load')), c(('global_store', 'buffer_store')), c('ds_'), c('s_waitcnt'), c(('s_cbranch', 's_branch'))))

@@ -15,11 +15,29 @@ int launch_er(const RayMarchArgs &a, hipStream_t s)
 	return (int) hipGetLastError();
 }
 
+template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF>
+int launch_lean(const RayMarchArgs &a, hipStream_t s)
+{
+	const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile;
+	hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, LF>), dim3(grid), dim3(256), 0, s, a);
+	return (int) hipGetLastError();
+}
+
 template <int SKIP, bool ERT, int GRAD>
 int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 {
 	switch (variant)
 	{
+		case 9:        // the round 1 kernel (divergent probe / sample branches, texel fetch from memory)
+		{
+			const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile;
+			hipLaunchKernelGGL((k_raymarch_tiles<SKIP, ERT, GRAD, true, 4>), dim3(grid), dim3(256), 0, s, a);
+			return (int) hipGetLastError();
+		}
+		case 1: return launch_lean<SKIP, ERT, GRAD, true, 0>(a, s);
+		case 2: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform>(a, s);
+		case 3: return launch_lean<SKIP, ERT, GRAD, true, kLeanNt>(a, s);
+		case 4: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanNt>(a, s);
 		case 11: return launch_er<SKIP, ERT, GRAD, true, 1, 0>(a, s);
 		case 12: return launch_er<SKIP, ERT, GRAD, true, 2, 0>(a, s);
 		case 14: return launch_er<SKIP, ERT, GRAD, true, 4, 0>(a, s);
@@ -31,6 +49,11 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 		case 42: return launch_er<SKIP, ERT, GRAD, true, 2, kErMasked>(a, s);
 		case 51: return launch_er<SKIP, ERT, GRAD, true, 1, kErMasked | kErStamp>(a, s);
 		case 52: return launch_er<SKIP, ERT, GRAD, true, 2, kErMasked | kErStamp>(a, s);
+		case 61: return launch_er<SKIP, ERT, GRAD, true, 1, kErCache16>(a, s);
+		case 62: return launch_er<SKIP, ERT, GRAD, true, 2, kErCache16>(a, s);
+		case 71: return launch_er<SKIP, ERT, GRAD, true, 1, kErCache32>(a, s);
+		case 72: return launch_er<SKIP, ERT, GRAD, true, 2, kErCache32>(a, s);
+		case 81: return launch_er<SKIP, ERT, GRAD, true, 1, kErCache32 | kErStamp>(a, s);
 		case 31: return launch_er<SKIP, ERT, GRAD, true, 1, kErStamp>(a, s);
 		case 32: return launch_er<SKIP, ERT, GRAD, true, 2, kErStamp>(a, s);
 		case 34: return launch_er<SKIP, ERT, GRAD, true, 4, kErStamp>(a, s);

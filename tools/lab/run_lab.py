@@ -80,6 +80,7 @@ counts0 = ref[0]["counts"].to(torch.int64).sum((0, 1)).cpu().numpy()
 print("view 0: volume samples %d, probes %d, empty %d" % tuple(counts0), flush=True)
 
 results = {}
+STREAMS = [torch.cuda.Stream() for _ in range(3)]  # the same three streams for every variant (stream -> hardware queue mapping is luck)
 for var in variants:
     ok = True
     if var != 0:
@@ -113,7 +114,7 @@ for var in variants:
         per_view.append(float(np.median(ts)))
     single = float(np.mean(per_view))
     # ---- three frames in flight ----
-    streams = [torch.cuda.Stream() for _ in range(3)]
+    streams = STREAMS
     bb = [bufs() for _ in range(3)]
     pp = []
     for k in range(24):
@@ -125,11 +126,14 @@ for var in variants:
             launch(var, pp[k % 24], streams[k % 3].cuda_stream)
     burst(24)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    burst(240)
-    torch.cuda.synchronize()
-    fif3 = (time.perf_counter() - t0) / 240 * 1e3
-    results[var] = dict(bit_identical=ok, single_ms=round(single, 4), per_view_ms=[round(x, 3) for x in per_view], fif3_ms=round(fif3, 4))
+    reps = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        burst(240)
+        torch.cuda.synchronize()
+        reps.append((time.perf_counter() - t0) / 240 * 1e3)
+    fif3 = float(np.median(reps))
+    results[var] = dict(bit_identical=ok, single_ms=round(single, 4), per_view_ms=[round(x, 3) for x in per_view], fif3_ms=round(fif3, 4), fif3_min_max=[round(min(reps), 4), round(max(reps), 4)])
     print(json.dumps({"variant": var, **results[var]}), flush=True)
     del bb, b
 
@@ -140,7 +144,7 @@ if "--stamps" in flags:
         set_outputs(p, b, only_rgba8=True)
         W = var % 10
         nwaves = ((p.tiles.tile_count + 7) // 8) * 8 * W * 4
-        trace = torch.zeros((nwaves, 8), dtype=torch.int64, device="cuda")
+        trace = torch.zeros((nwaves, 10), dtype=torch.int64, device="cuda")
         for _ in range(2):
             launch(var, p, cur)
         torch.cuda.synchronize()
@@ -153,8 +157,8 @@ if "--stamps" in flags:
         it = t[:, 2]
         dur_us = (t[:, 1] - t[:, 0]) / 100.0
         m = it >= 32
-        ph = t[m, 4:8].astype(np.float64) / it[m, None]
+        ph = t[m][:, [8, 4, 5, 6, 7]].astype(np.float64) / it[m, None]
         print("stamped variant %d: waves %d (>=32 iterations: %d), kernel span %.1f us, longest wave %d iterations" % (var, len(t), m.sum(), (t[:, 1].max() - t[:, 0].min()) / 100.0, it.max()))
         print("  us per iteration (waves >= 32 it): median %.3f" % np.median(dur_us[m] / it[m]))
-        print("  cycles per iteration, mean over those waves: issue %.0f | memory wait %.0f | evaluate (filter, TF, skip length) %.0f | replay %.0f" % tuple(ph.mean(0)))
-        print("  same, waves with >= 150 iterations:", (t[it >= 150, 4:8].astype(np.float64) / it[it >= 150, None]).mean(0).round(0) if (it >= 150).any() else None)
+        print("  cycles per iteration, mean over those waves: addresses %.0f | load issue %.0f | memory wait %.0f | evaluate (filter, TF, skip length) %.0f | replay %.0f" % tuple(ph.mean(0)))
+        print("  same, waves with >= 150 iterations:", (t[it >= 150][:, [8, 4, 5, 6, 7]].astype(np.float64) / it[it >= 150, None]).mean(0).round(0) if (it >= 150).any() else None)

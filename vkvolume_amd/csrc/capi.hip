@@ -42,6 +42,23 @@ int set_error(vkv_ctx *ctx, int code, const char *fmt, ...)
 	return code;
 }
 
+uint8_t *stream_scratch(vkv_ctx *ctx, hipStream_t stream)
+{
+	std::lock_guard<std::mutex> lock(ctx->mutex);
+	auto                        it = ctx->scratch.find(stream);
+	if (it != ctx->scratch.end())
+		return it->second;
+	uint8_t *        p = nullptr;
+	const hipError_t e = hipMalloc((void **) &p, kScratchBytes);
+	if (e != hipSuccess)
+	{
+		set_error(ctx, (int) e, "scratch allocation: %s", hipGetErrorString(e));
+		return nullptr;
+	}
+	ctx->scratch.emplace(stream, p);
+	return p;
+}
+
 int check_launch(vkv_ctx *ctx, const char *what)
 {
 	const hipError_t e = hipGetLastError();
@@ -76,23 +93,13 @@ int vkv_create(int device_ordinal, vkv_ctx **out_ctx)
 		return VKV_E_NO_DEVICE;
 	if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("VKV_ALLOW_ANY_ARCH"))
 		return VKV_E_NO_DEVICE;        // the code object is built for gfx950 only
-	hipError_t e = hipSetDevice(device_ordinal);
-	if (e != hipSuccess)
-		return (int) e;
 	vkv_ctx *ctx = new (std::nothrow) vkv_ctx();
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
-	ctx->device          = device_ordinal;
-	ctx->error[0]        = 0;
-	ctx->workspace_bytes = kWorkspaceBytes;
-	ctx->d_trace         = nullptr;
-	e                    = hipMalloc((void **) &ctx->d_workspace, ctx->workspace_bytes);
-	if (e != hipSuccess)
-	{
-		delete ctx;
-		return (int) e;
-	}
-	*out_ctx = ctx;
+	ctx->device   = device_ordinal;
+	ctx->error[0] = 0;
+	ctx->d_trace  = nullptr;
+	*out_ctx      = ctx;        // the caller's current device is left as it is: every entry point switches to ctx->device itself
 	return VKV_OK;
 }
 
@@ -100,8 +107,11 @@ void vkv_destroy(vkv_ctx *ctx)
 {
 	if (!ctx)
 		return;
-	if (ctx->d_workspace)
-		(void) hipFree(ctx->d_workspace);
+	{
+		DeviceGuard guard(ctx->device);
+		for (auto &kv : ctx->scratch)
+			(void) hipFree(kv.second);
+	}
 	delete ctx;
 }
 
@@ -122,6 +132,7 @@ int vkv_debug_check(vkv_ctx *ctx, int32_t what, uint32_t first_bits, uint64_t co
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
 	if (!d_mismatches)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "check: null pointer");
 	return launch_check_numerics(ctx, what, first_bits, count, reinterpret_cast<unsigned long long *>(d_mismatches), (hipStream_t) stream);
@@ -256,6 +267,7 @@ int vkv_gradient_map(vkv_ctx *ctx, const uint8_t *d_volume, uint8_t *d_gradient,
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
 	if (!d_volume || !d_gradient || !tf || !extent_ok(extent))
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "gradient_map: null pointer or zero extent");
 	return launch_gradient_map(ctx, d_volume, d_gradient, extent, tf, (hipStream_t) stream);
@@ -266,6 +278,7 @@ int vkv_occupancy_map(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_t *d_gr
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
 	if (!d_volume || !d_tf || !tf || !d_map || !extent_ok(extent) || !map_extent_ok(extent, map_extent))
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "occupancy_map: null pointer or bad extent");
 	return launch_occupancy_map(ctx, d_volume, d_gradient, d_tf, tf, extent, d_map, map_extent, (hipStream_t) stream);
@@ -275,6 +288,7 @@ int vkv_distance_map(vkv_ctx *ctx, uint8_t *d_map, uint8_t *d_swap, VkvExtent3D 
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
 	if (!d_map || !d_swap || d_map == d_swap)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "distance_map: null or aliased buffers");
 	return launch_distance_map(ctx, d_map, d_swap, map_extent, (hipStream_t) stream);
@@ -284,6 +298,7 @@ int vkv_distance_map_anisotropic(vkv_ctx *ctx, uint8_t *const d_maps[8], uint8_t
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
 	if (!d_maps || !d_swap)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "distance_map_anisotropic: null pointer");
 	for (int i = 0; i < 8; ++i)
@@ -298,6 +313,7 @@ int vkv_compute_distance_map(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
 	if (skipping_type < VKV_SKIP_NONE || skipping_type > VKV_SKIP_ANISOTROPIC_DISTANCE || !d_maps)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "compute_distance_map: bad skipping_type or null maps");
 	const bool aniso = skipping_type == VKV_SKIP_ANISOTROPIC_DISTANCE;
@@ -317,6 +333,7 @@ int vkv_occupied_voxel_count(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
 	if (!d_volume || !tf || !d_count || !extent_ok(extent))
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "occupied_voxel_count: null pointer or zero extent");
 	return launch_occupied_voxel_count(ctx, d_volume, d_gradient, tf, extent, d_count, (hipStream_t) stream);
@@ -377,6 +394,7 @@ int vkv_convert_volume(vkv_ctx *ctx, const void *d_raw, int32_t type, int32_t bi
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
 	if (!d_raw || !d_out)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "convert_volume: null pointer");
 	if ((type == VKV_VOXEL_UINT16 || type == VKV_VOXEL_INT16) && (((uintptr_t) d_raw) & 1u))
@@ -395,6 +413,7 @@ int vkv_pack_volume(vkv_ctx *ctx, const uint8_t *d_volume, const uint8_t *d_grad
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
 	if (!d_volume || !d_packed || !extent_ok(extent))
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "pack_volume: null pointer or zero extent");
 	if (((uintptr_t) d_packed & 255u) != 0)
@@ -406,6 +425,7 @@ int vkv_transfer_function_tables(vkv_ctx *ctx, const uint8_t *d_tf, const VkvTra
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
 	if (!d_tf || !d_tables)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "transfer_function_tables: null pointer");
 	if (((uintptr_t) d_tf & 3u) != 0 || ((uintptr_t) d_tables & 3u) != 0)
@@ -422,6 +442,7 @@ int vkv_render(vkv_ctx *ctx, const VkvRenderParams *P, void *stream)
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
 	if (!P)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: null params");
 	const VkvRenderOptions &o = P->options;
@@ -480,6 +501,7 @@ int vkv_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, uint3
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
 	if (!d_gathered || !d_image || !image_width || !image_height || !tile_width || !tile_height || !n_ranks)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "scatter_tiles: null pointer or zero size");
 	const uint64_t tiles = (uint64_t) ((image_width + tile_width - 1) / tile_width) * ((image_height + tile_height - 1) / tile_height);
@@ -493,6 +515,7 @@ int vkv_synth_volume(vkv_ctx *ctx, uint8_t *d_volume, VkvExtent3D extent, uint32
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
 	if (!d_volume || !extent_ok(extent))
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "synth_volume: null pointer or zero extent");
 	return launch_synth_volume(ctx, d_volume, extent, kind, seed, (hipStream_t) stream);

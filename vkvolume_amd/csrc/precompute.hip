@@ -1027,7 +1027,10 @@ int launch_gradient_map(vkv_ctx *ctx, const uint8_t *d_vol, uint8_t *d_grad, Vkv
 int launch_occupancy_map(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_grad, const uint8_t *d_tf, const VkvTransferFunctionUniform *tf,
                          VkvExtent3D e, uint8_t *d_map, VkvExtent3D me, hipStream_t s)
 {
-	uint32_t *d_bits = reinterpret_cast<uint32_t *>(ctx->d_workspace + kTfBitsOffset);
+	uint8_t *scratch = stream_scratch(ctx, s);        // per stream: map updates on different streams do not share the bit table
+	if (!scratch)
+		return VKV_E_UNSUPPORTED;
+	uint32_t *d_bits = reinterpret_cast<uint32_t *>(scratch + kTfBitsOffset);
 	hipLaunchKernelGGL(k_tf_bits, dim3(8), dim3(256), 0, s, d_tf, d_bits);
 	// src/compute_distance_map.cpp:110-113
 	const int bx = (int) ((e.width + me.width - 1) / me.width), by = (int) ((e.height + me.height - 1) / me.height),
@@ -1082,7 +1085,10 @@ int launch_occupancy_map(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_gr
 int launch_occupied_voxel_count(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_grad, const VkvTransferFunctionUniform *tf, VkvExtent3D e,
                                 uint64_t *d_count, hipStream_t s)
 {
-	uint32_t *d_bits = reinterpret_cast<uint32_t *>(ctx->d_workspace + kTfBitsOffset);
+	uint8_t *scratch = stream_scratch(ctx, s);
+	if (!scratch)
+		return VKV_E_UNSUPPORTED;
+	uint32_t *d_bits = reinterpret_cast<uint32_t *>(scratch + kTfBitsOffset);
 	hipLaunchKernelGGL(k_tf_bits_analytic, dim3(8), dim3(256), 0, s, d_bits, tf->intensity_min, tf->intensity_range_inv, tf->gradient_min,
 	                   tf->gradient_range_inv);
 	const hipError_t me = hipMemsetAsync(d_count, 0, sizeof(uint64_t), s);

@@ -9,47 +9,44 @@ namespace vkv
 
 enum Scheduler
 {
-	kSchedTiles      = 0,
-	kSchedPersistent = 1
+	kSchedLean       = 0,        // k_raymarch_lean: one lane per ray, predicated loop body (default)
+	kSchedPersistent = 1         // k_raymarch_persistent: resident waves, ballot + mbcnt lane re-fill (bit-identical, slower)
 };
 
 template <int SKIP, bool ERT, int GRAD, bool PACKED>
-static int launch_one(vkv_ctx *ctx, int sched, const RayMarchArgs &a, hipStream_t s)
+static int launch_one(vkv_ctx *ctx, int sched, RayMarchArgs &a, hipStream_t s)
 {
 	if (sched == kSchedPersistent)
 	{
-		static int resident = 0;        // blocks per CU x CUs for this variant (same on every device of a node)
-		if (resident == 0)
-		{
-			int per_cu = 0, dev = 0;
-			hipDeviceProp_t prop;
-			if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-			    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_raymarch_persistent<SKIP, ERT, GRAD, PACKED>, 256, 0) != hipSuccess || per_cu < 1)
-				return set_error(ctx, VKV_E_NO_DEVICE, "render: occupancy query failed");
-			resident = per_cu * prop.multiProcessorCount;
-		}
+		int per_cu = 0;
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess ||
+		    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_raymarch_persistent<SKIP, ERT, GRAD, PACKED>, 256, 0) != hipSuccess || per_cu < 1)
+			return set_error(ctx, VKV_E_NO_DEVICE, "render: occupancy query failed");
+		const uint32_t resident = (uint32_t) per_cu * (uint32_t) prop.multiProcessorCount;
+		// the tile-queue heads live in this stream's scratch: launches on other streams have their own
+		uint8_t *scratch = stream_scratch(ctx, s);
+		if (!scratch)
+			return VKV_E_UNSUPPORTED;
+		a.queue_heads      = reinterpret_cast<uint32_t *>(scratch + kQueueHeadsOffset);
 		const hipError_t e = hipMemsetAsync(a.queue_heads, 0, 8 * sizeof(uint32_t), s);
 		if (e != hipSuccess)
 			return set_error(ctx, (int) e, "render: queue reset: %s", hipGetErrorString(e));
 		// never more workgroups than there are 8x8 units to hand out (4 waves per workgroup)
-		const uint32_t grid = (uint32_t) resident < a.nblocks ? (uint32_t) resident : a.nblocks;
+		const uint32_t grid = resident < a.nblocks ? resident : a.nblocks;
 		hipLaunchKernelGGL((k_raymarch_persistent<SKIP, ERT, GRAD, PACKED>), dim3(grid), dim3(256), 0, s, a);
 	}
 	else
 	{
 		// ids are dealt round-robin to the XCDs, each XCD walking its own tiles: pad the tile count to a multiple of 8
 		const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile;
-		static const bool half = [] { const char *e = std::getenv("VKV_RAYMARCH_WPB"); return e && e[0] == '2'; }();
-		if (half)
-			hipLaunchKernelGGL((k_raymarch_tiles<SKIP, ERT, GRAD, PACKED, 2>), dim3(grid * 2), dim3(128), 0, s, a);
-		else
-			hipLaunchKernelGGL((k_raymarch_tiles<SKIP, ERT, GRAD, PACKED, 4>), dim3(grid), dim3(256), 0, s, a);
+		hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLeanUniform>), dim3(grid), dim3(256), 0, s, a);
 	}
 	return check_launch(ctx, "render");
 }
 
 template <int SKIP, bool ERT, bool PACKED>
-static int launch_grad(vkv_ctx *ctx, int sched, int grad, const RayMarchArgs &a, hipStream_t s)
+static int launch_grad(vkv_ctx *ctx, int sched, int grad, RayMarchArgs &a, hipStream_t s)
 {
 	if (grad == 0)
 		return launch_one<SKIP, ERT, 0, PACKED>(ctx, sched, a, s);
@@ -59,7 +56,7 @@ static int launch_grad(vkv_ctx *ctx, int sched, int grad, const RayMarchArgs &a,
 }
 
 template <int SKIP>
-static int launch_ert(vkv_ctx *ctx, int sched, bool ert, int grad, const RayMarchArgs &a, hipStream_t s)
+static int launch_ert(vkv_ctx *ctx, int sched, bool ert, int grad, RayMarchArgs &a, hipStream_t s)
 {
 	if (a.packed)
 		return ert ? launch_grad<SKIP, true, true>(ctx, sched, grad, a, s) : launch_grad<SKIP, false, true>(ctx, sched, grad, a, s);
@@ -113,7 +110,7 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 		return set_error(ctx, VKV_E_UNSUPPORTED, "render: frame too large for one launch");
 	a.nblocks     = (uint32_t) nb;
 	a.test        = P->options.test;
-	a.queue_heads = reinterpret_cast<uint32_t *>(ctx->d_workspace + kQueueHeadsOffset);
+	a.queue_heads = nullptr;        // persistent scheduler: set at launch (per-stream scratch)
 	a.trace       = reinterpret_cast<unsigned long long *>(ctx->d_trace);
 	a.back        = (int) std::ceil(P->transfer_function.sampling_factor);
 	for (int i = 0; i < 256; ++i)
@@ -128,10 +125,10 @@ int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut
 	if (rc != VKV_OK || a.nblocks == 0)
 		return rc;
 
-	// scheduler: static 8x8 tiles; VKV_RAYMARCH_SCHEDULER=persistent selects the lane-refilling persistent waves
-	// (bit-identical output; measured slower so far: the re-fill breaks the spatial coherence of a wave, profiles/)
+	// scheduler: one lane per ray on static 8x8 tiles; VKV_RAYMARCH_SCHEDULER=persistent selects the lane-refilling persistent
+	// waves (bit-identical output; measured 2.7x slower: the re-fill breaks the spatial coherence of a wave)
 	const char *env   = std::getenv("VKV_RAYMARCH_SCHEDULER");        // read per call so a test can flip it
-	const int   sched = (env && env[0] == 'p') ? (int) kSchedPersistent : (int) kSchedTiles;
+	const int   sched = (env && env[0] == 'p') ? (int) kSchedPersistent : (int) kSchedLean;
 
 	const bool ert  = P->options.early_ray_termination != 0;
 	const int  grad = !P->transfer_function.use_gradient ? 0 : (P->use_precomputed_gradient ? 1 : 2);

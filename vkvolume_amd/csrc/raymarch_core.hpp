@@ -23,7 +23,7 @@
 
 using namespace vkv;
 
-constexpr int kTraceWords = 8;        // u64 words per wave of the diagnostic trace buffer
+constexpr int kTraceWords = 10;        // u64 words per wave of the diagnostic trace buffer
 
 struct RayMarchArgs
 {
@@ -806,6 +806,84 @@ __device__ __forceinline__ bool stage_tables_er(const RayMarchArgs &A, RmLds &L)
 	return sep;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-private brick cache in LDS (the reference samples through the texture unit, frag:272 / sampler
+// src/volume_component.cpp:139-148; here the 256-byte bricks a wave's rays are inside are staged in LDS).
+// A per-lane gather costs the CU's texture addresser 16-33 cycles per wave instruction whatever its width
+// (tools/micro/gather_mask.hip), four of them per sample; a brick is fetched ONCE by 16 lanes x 16 bytes (four bricks per
+// load instruction), serves every footprint of every ray of the wave that falls into it — typically for several
+// iterations — and the gathers become ds_reads.  Direct-mapped, tag = brick index, no cross-wave sharing (no barriers).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NS>
+struct BrickCache
+{
+	uint32_t tags[4][NS];
+	__attribute__((aligned(16))) uint8_t data[4][NS * 256];
+};
+
+// brick index, byte offset of the footprint's first dword inside the brick, cache slot and the three filter weights
+template <int NS>
+__device__ __forceinline__ void packed_footprint_ids(int W, int H, int D, int pmx, int pmy, float px, float py, float pz, float &wx, float &wy, float &wz,
+                                                     uint32_t &brick, uint32_t &in, uint32_t &slot)
+{
+	const float cx = __builtin_fmaf(px, (float) W, -0.5f), cy = __builtin_fmaf(py, (float) H, -0.5f), cz = __builtin_fmaf(pz, (float) D, -0.5f);
+	const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy), fz = __builtin_floorf(cz);
+	wx = cx - fx, wy = cy - fy, wz = cz - fz;
+	const int bx = i_clamp((int) fx, -1, W) + 1, by = i_clamp((int) fy, -1, H) + 1, bz = i_clamp((int) fz, -1, D) + 1;
+	const uint32_t macro = ((uint32_t) (bz >> 5) * (uint32_t) pmy + (uint32_t) (by >> 5)) * (uint32_t) pmx + (uint32_t) (bx >> 5);
+	const uint32_t sub   = (uint32_t) ((((bz >> 2) & 7) << 6) | (((by >> 2) & 7) << 3) | ((bx >> 2) & 7));
+	in    = (uint32_t) ((((bz & 3) * 5 + (by & 3)) * 5 + (bx & 3)) * 2);
+	brick = macro * 512u + sub;
+	// a wave's rays span about three bricks per axis: 3 x 3 x 3 neighbourhoods map without conflicts
+	slot = ((uint32_t) (bx >> 2) + 3u * (uint32_t) (by >> 2) + 9u * (uint32_t) (bz >> 2)) & (uint32_t) (NS - 1);
+}
+
+template <int NS>
+__device__ __forceinline__ void cached_footprint(const uint8_t *__restrict__ packed, uint8_t *cache, uint32_t *tags, bool want, uint32_t brick, uint32_t slot,
+                                                 uint32_t in, uint32_t &q00, uint32_t &q10, uint32_t &q01, uint32_t &q11)
+{
+	const uint32_t lane    = threadIdx.x & 63u;
+	bool           pending = want;
+	// every round serves at least the first missing lane, so 64 rounds are enough; the bound only keeps a logic error from hanging the GPU
+	for (int round = 0; round < 66; ++round)
+	{
+		// hits take their four row dwords now: a fill further down may evict the slot (LDS operations of a wave execute in order)
+		if (pending && tags[slot] == brick)
+		{
+			const uint8_t *b = cache + slot * 256u + in;
+			q00 = *reinterpret_cast<const u32_align2 *>(b);
+			q10 = *reinterpret_cast<const u32_align2 *>(b + 10);
+			q01 = *reinterpret_cast<const u32_align2 *>(b + 50);
+			q11 = *reinterpret_cast<const u32_align2 *>(b + 60);
+			pending = false;
+		}
+		unsigned long long sel = __ballot(pending);
+		if (sel == 0ull)
+			break;
+		// up to four missing bricks with four different slots, one per group of 16 lanes
+		uint32_t fill_brick = 0xffffffffu, fill_slot = 0;
+#pragma unroll
+		for (uint32_t g = 0; g < 4; ++g)
+		{
+			if (sel != 0ull)
+			{
+				const int      leader = __builtin_ctzll(sel);
+				const uint32_t b = (uint32_t) __builtin_amdgcn_readlane((int) brick, leader), sl = (uint32_t) __builtin_amdgcn_readlane((int) slot, leader);
+				if ((lane >> 4) == g)
+					fill_brick = b, fill_slot = sl;
+				sel &= ~__ballot(slot == sl);
+			}
+		}
+		if (fill_brick != 0xffffffffu)
+		{
+			const uint4 v = *reinterpret_cast<const uint4 *>(packed + ((uint64_t) fill_brick << 8) + (lane & 15u) * 16u);
+			*reinterpret_cast<uint4 *>(cache + fill_slot * 256u + (lane & 15u) * 16u) = v;
+			if ((lane & 15u) == 0u)
+				tags[fill_slot] = fill_brick;
+		}
+	}
+}
+
 // What the evaluation of one loop position hands to the replay.
 struct Entry
 {
@@ -833,9 +911,9 @@ __device__ __forceinline__ uint32_t group_bcast(uint32_t v)
 // of event (frag:220-247 probe, frag:266-284 sample).  want_dist / want_sample say which loads can be needed; the other
 // kind's loads read a dummy address and its results are never used.
 // ---------------------------------------------------------------------------------------------------------------
-template <int SKIP, int GRAD, bool PACKED, bool STAMP, bool MASKED>
-__device__ __forceinline__ void er_evaluate(const RayMarchArgs &A, const Ray &R, int p, int k, bool full, bool sep, const RmLds &L, Entry &E,
-                                            unsigned long long &t_issued, unsigned long long &t_returned)
+template <int SKIP, int GRAD, bool PACKED, bool STAMP, bool MASKED, int NS>
+__device__ __forceinline__ void er_evaluate(const RayMarchArgs &A, const Ray &R, int p, int k, bool full, bool idle, bool sep, const RmLds &L, uint8_t *cache,
+                                            uint32_t *tags, Entry &E, unsigned long long &t_addr, unsigned long long &t_issued, unsigned long long &t_returned)
 {
 	const int   W = A.W, H = A.H, D = A.D;
 	const float fp = (float) p;
@@ -857,13 +935,23 @@ __device__ __forceinline__ void er_evaluate(const RayMarchArgs &A, const Ray &R,
 		const bool probe0 = !R.occupied && cell != R.ul;
 		want_dist = probe0, want_sample = !probe0;
 	}
+	if (idle)        // the ray of this lane has ended (or never started): it only helps with the brick cache fills
+		want_dist = want_sample = false;
 	E.cell = cell;
 
 	// ---- issue phase: probe byte and footprint of this position together --------------------------------------------
 	constexpr bool kHoist = PACKED && GRAD != 2;
 	uint32_t       dist = 0, q00 = 0, q10 = 0, q01 = 0, q11 = 0;
 	float          wx = 0, wy = 0, wz = 0;
-	if (MASKED)
+	if (NS > 0 && kHoist)
+	{        // probe byte from memory (masked), footprint through the wave's brick cache
+		if (SKIP != VKV_SKIP_NONE && want_dist)
+			dist = R.dmap[cell];
+		uint32_t brick, in, slot;
+		packed_footprint_ids<(NS > 0 ? NS : 1)>(W, H, D, A.pmx, A.pmy, posx, posy, posz, wx, wy, wz, brick, in, slot);
+		cached_footprint<(NS > 0 ? NS : 1)>(A.packed, cache, tags, want_sample, brick, slot, in, q00, q10, q01, q11);
+	}
+	else if (MASKED)
 	{        // the texture addresser's time per load grows with the number of active lanes (tools/micro/gather_mask.hip): lanes that
 		 // cannot need a kind of load sit it out under EXEC instead of reading a dummy address
 		if (SKIP != VKV_SKIP_NONE && want_dist)
@@ -879,12 +967,22 @@ __device__ __forceinline__ void er_evaluate(const RayMarchArgs &A, const Ray &R,
 	}
 	else
 	{
-		if (SKIP != VKV_SKIP_NONE)
-			dist = R.dmap[want_dist ? cell : 0u];
+		uint32_t       dcell = want_dist ? cell : 0u;
+		const uint8_t *ba    = A.packed;
 		if (kHoist)
 		{
 			const uint8_t *fpa = packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, wx, wy, wz);
-			const uint8_t *ba  = want_sample ? fpa : A.packed;
+			ba                 = want_sample ? fpa : A.packed;
+		}
+		if (STAMP)
+		{        // diagnostic build only: all addresses are computed, no load has been issued
+			asm volatile("" : "+v"(dcell), "+v"(ba));
+			t_addr = __builtin_amdgcn_s_memtime();
+		}
+		if (SKIP != VKV_SKIP_NONE)
+			dist = R.dmap[dcell];
+		if (kHoist)
+		{
 			q00 = *reinterpret_cast<const u32_align2 *>(ba);
 			q10 = *reinterpret_cast<const u32_align2 *>(ba + 10);
 			q01 = *reinterpret_cast<const u32_align2 *>(ba + 50);
@@ -1090,43 +1188,29 @@ __device__ __forceinline__ bool block_pixel(const RayMarchArgs &A, uint32_t b, u
 constexpr uint32_t kErFull  = 1u;        // every lane loads probe byte AND footprint (the first position of a window too)
 constexpr uint32_t kErStamp = 2u;        // diagnostic build: per-wave phase times into the trace buffer
 constexpr uint32_t kErMasked = 4u;       // loads a lane cannot need are masked off instead of reading a dummy address
+constexpr uint32_t kErCache16 = 8u, kErCache32 = 16u;        // wave-private LDS brick cache with 16 / 32 slots
 
-template <int SKIP, bool ERT, int GRAD, bool PACKED, int W, uint32_t FLAGS>
-__global__ void __launch_bounds__(256) k_raymarch_er(const RayMarchArgs A)
+// The march of one wave: evaluate + replay until every ray of the wave has ended.  `sep` arrives as a literal so each copy of the
+// loop holds one transfer-function path only.
+template <int SKIP, bool ERT, int GRAD, bool PACKED, int W, uint32_t FLAGS, int NS>
+__device__ __forceinline__ void er_march(const RayMarchArgs &A, Ray &R, bool marched, const bool sep, const RmLds &L, uint8_t *cache_data, uint32_t *cache_tags,
+                                         uint32_t lane, uint32_t &iter, uint32_t &pha, uint32_t &ph0, uint32_t &ph1, uint32_t &ph2, uint32_t &ph3)
 {
-	__shared__ RmLds L;
-	const bool       sep = stage_tables_er(A, L);
-	constexpr bool   kFull = (FLAGS & kErFull) != 0, kStamp = (FLAGS & kErStamp) != 0;
-	// workgroup -> (tile of the schedule, 16x16 block of the tile, part of the block): XCD x = id & 7 marches the tiles
-	// x, x + 8, ... (see k_raymarch_tiles); a block takes W workgroups of four waves
-	const uint32_t x = blockIdx.x & 7u, idx = blockIdx.x >> 3;
-	const uint32_t k = (idx / (A.blocks_per_tile * W)) * 8u + x, sbp = idx % (A.blocks_per_tile * W);
-	const uint32_t sb = sbp / W, part = sbp % W;
-	if (k >= A.tile_count)
-		return;
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	uint32_t       px, py, o;
-	if (!block_pixel<W>(A, k * A.blocks_per_tile + sb, (part * 4u + wave) * (64u / W) + lane / W, px, py, o))
-		return;
-	Ray R;
-	R.o = o;
-	const unsigned long long t_start = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-	const bool marched = ray_setup<SKIP>(A, px, py, R);
-	uint32_t   iter    = 0;
-	uint32_t   ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;
-	if (marched)
+	constexpr bool kFull = (FLAGS & kErFull) != 0, kStamp = (FLAGS & kErStamp) != 0;
 	{
 		const int kk   = (int) (lane % W);
-		bool      done = false;
+		bool      done = !marched;
 		float     grey = 0.0f;        // separable greyscale TF: the one colour channel
-		while (!done)
+		if (done)
+			R.i = 0, R.n_steps = 0, R.occupied = true, R.sx = R.sy = R.sz = R.ex = R.ey = R.ez = 0.0f, R.six = R.siy = R.siz = 1.0f, R.dmap = A.maps[0];
+		while (__ballot(!done) != 0ull)        // wave-uniform loop
 		{
-			unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+			unsigned long long t0 = 0, ta = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
 			if (kStamp)
 				t0 = __builtin_amdgcn_s_memtime();
 			const int j0 = R.i;
 			Entry     E;
-			er_evaluate<SKIP, GRAD, PACKED, kStamp, (FLAGS & kErMasked) != 0>(A, R, j0 + kk, kk, kFull, sep, L, E, t1, t2);
+			er_evaluate<SKIP, GRAD, PACKED, kStamp, (FLAGS & kErMasked) != 0, NS>(A, R, j0 + kk, kk, kFull, done, sep, L, cache_data, cache_tags, E, ta, t1, t2);
 			if (kStamp)
 			{
 				asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1138,18 +1222,56 @@ __global__ void __launch_bounds__(256) k_raymarch_er(const RayMarchArgs A)
 			{
 				asm volatile("" : "+v"(R.i), "+v"(R.a));
 				t4 = __builtin_amdgcn_s_memtime();
-				// top -> loads issued -> loads returned -> entry ready -> replay done
-				ph0 += (uint32_t) (t1 - t0), ph1 += (uint32_t) (t2 - t1), ph2 += (uint32_t) (t3 - t2), ph3 += (uint32_t) (t4 - t3);
+				// top -> addresses ready -> loads issued -> loads returned -> entry ready -> replay done
+				if (ta == 0)
+					ta = t0;
+				pha += (uint32_t) (ta - t0), ph0 += (uint32_t) (t1 - ta), ph1 += (uint32_t) (t2 - t1), ph2 += (uint32_t) (t3 - t2), ph3 += (uint32_t) (t4 - t3);
 			}
 			// the frame time is the critical path of the wave with the longest ray: once a wave has run 48 iterations it is one of
 			// those, so let it win instruction arbitration against the younger waves on its SIMD
-			if (__builtin_amdgcn_readfirstlane(++iter) == 48u)
+			if (++iter == 48u)
 				__builtin_amdgcn_s_setprio(3);
 		}
-		if (sep)
+		if (sep && marched)
 			R.r = grey, R.g = grey, R.b = grey;
 	}
-	ray_finish(A, R, marched);
+}
+
+template <int SKIP, bool ERT, int GRAD, bool PACKED, int W, uint32_t FLAGS>
+__global__ void __launch_bounds__(256) k_raymarch_er(const RayMarchArgs A)
+{
+	constexpr int NS = (FLAGS & kErCache32) ? 32 : ((FLAGS & kErCache16) ? 16 : 0);
+	__shared__ RmLds                         L;
+	__shared__ BrickCache<(NS > 0 ? NS : 1)> BC;
+	if (NS > 0)
+		for (int i = threadIdx.x; i < 4 * NS; i += blockDim.x)
+			BC.tags[i / NS][i % NS] = 0xffffffffu;
+	const bool     sep = stage_tables_er(A, L);
+	// workgroup -> (tile of the schedule, 16x16 block of the tile, part of the block): XCD x = id & 7 marches the tiles
+	// x, x + 8, ... (see k_raymarch_tiles); a block takes W workgroups of four waves
+	const uint32_t x = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+	const uint32_t k = (idx / (A.blocks_per_tile * W)) * 8u + x, sbp = idx % (A.blocks_per_tile * W);
+	const uint32_t sb = sbp / W, part = sbp % W;
+	if (k >= A.tile_count)
+		return;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint32_t       px, py, o;
+	// no lane leaves before the end: the brick cache is filled by all 64 lanes of a wave whatever their rays are doing
+	const bool inside = block_pixel<W>(A, k * A.blocks_per_tile + sb, (part * 4u + wave) * (64u / W) + lane / W, px, py, o);
+	Ray        R;
+	R.o = o;
+	const unsigned long long t_start = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+	bool       marched = false;
+	if (inside)
+		marched = ray_setup<SKIP>(A, px, py, R);
+	uint32_t   iter    = 0;
+	uint32_t   pha = 0, ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;
+	if (sep)
+		er_march<SKIP, ERT, GRAD, PACKED, W, FLAGS, NS>(A, R, marched, true, L, BC.data[wave], BC.tags[wave], lane, iter, pha, ph0, ph1, ph2, ph3);
+	else
+		er_march<SKIP, ERT, GRAD, PACKED, W, FLAGS, NS>(A, R, marched, false, L, BC.data[wave], BC.tags[wave], lane, iter, pha, ph0, ph1, ph2, ph3);
+	if (inside)
+		ray_finish(A, R, marched);
 	if (A.trace)
 	{        // diagnostic only: per-wave timeline (100 MHz clock); the values never feed an output
 		uint32_t it = iter;
@@ -1158,13 +1280,14 @@ __global__ void __launch_bounds__(256) k_raymarch_er(const RayMarchArgs A)
 			it  = max(it, (uint32_t) __shfl_xor((int) it, o2));
 			ph0 = max(ph0, (uint32_t) __shfl_xor((int) ph0, o2)), ph1 = max(ph1, (uint32_t) __shfl_xor((int) ph1, o2));
 			ph2 = max(ph2, (uint32_t) __shfl_xor((int) ph2, o2)), ph3 = max(ph3, (uint32_t) __shfl_xor((int) ph3, o2));
+			pha = max(pha, (uint32_t) __shfl_xor((int) pha, o2));
 		}
 		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
 		if (lane == (uint32_t) __builtin_ctzll(__ballot(1)))
 		{
 			unsigned long long *rec = A.trace + ((size_t) blockIdx.x * 4 + wave) * kTraceWords;
 			rec[0] = t_start, rec[1] = t_end, rec[2] = it, rec[3] = ((unsigned long long) __builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (k * A.blocks_per_tile + sb);
-			rec[4] = ph0, rec[5] = ph1, rec[6] = ph2, rec[7] = ph3;
+			rec[4] = ph0, rec[5] = ph1, rec[6] = ph2, rec[7] = ph3, rec[8] = pha, rec[9] = 0;
 		}
 	}
 }
@@ -1174,3 +1297,261 @@ namespace vkv
 // raymarch.hip: VkvRenderParams -> kernel arguments (shared with tools/lab)
 int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, RayMarchArgs &a);
 }        // namespace vkv
+
+// ===============================================================================================================
+// k_raymarch_lean: one lane per ray, the frag's loop body as straight-line predicated code.
+// What differs from the round 1 kernel (k_raymarch_tiles), each step measured with tools/lab:
+//   * the transfer function of the reference (a separable greyscale product, checked on the device) comes from two 256-entry LDS
+//     tables, and one colour channel is blended: no dependent global texel fetch behind the sample;
+//   * loads a lane cannot need are masked off (EXEC) instead of reading a shared dummy address; the probe byte is issued before
+//     the footprint address arithmetic, the skip length is computed while the footprint is still in flight;
+//   * the state update of the frag (frag:224-310) is one block of selects: the lanes of a wave disagree about nearly every
+//     condition of it, and a lone wave issues one instruction every ~5 cycles whatever the EXEC mask (tools/micro/valu_half.hip).
+// ===============================================================================================================
+__device__ __forceinline__ int med3_i32(int x, int lo, int hi)
+{        // clamp(x, lo, hi) for lo <= hi in one instruction (the compiler only forms it when it can prove lo <= hi)
+	int r;
+	asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+	return r;
+}
+
+constexpr uint32_t kLeanUniform = 1u;        // wave-uniform branches around the probe-only and the sample-only work
+constexpr uint32_t kLeanNt      = 2u;        // non-temporal footprint loads (leave the caches to the distance map)
+
+template <bool NT>
+__device__ __forceinline__ uint32_t load_row(const uint8_t *p)
+{
+	if (NT)
+		return __builtin_nontemporal_load(reinterpret_cast<const u32_align2 *>(p));
+	return *reinterpret_cast<const u32_align2 *>(p);
+}
+
+template <int SKIP, bool ERT, int GRAD, bool PACKED, bool SEP, uint32_t LF>
+__device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const RmLds &L, uint32_t &iter)
+{
+	constexpr bool kUni = (LF & kLeanUniform) != 0, kNt = (LF & kLeanNt) != 0;
+	const int   W = A.W, H = A.H, D = A.D;
+	const float kx = SKIP != VKV_SKIP_NONE ? (float) W / A.block_size[0] : 0.0f, ky = SKIP != VKV_SKIP_NONE ? (float) H / A.block_size[1] : 0.0f,
+	            kz = SKIP != VKV_SKIP_NONE ? (float) D / A.block_size[2] : 0.0f;
+	const int   mw1 = A.mw - 1, mh1 = A.mh - 1, md1 = A.md - 1;
+	constexpr bool kHoist = PACKED && GRAD != 2;
+	float    grey = 0.0f;
+	uint32_t ul   = 0;
+	bool     occ  = true, done = false;
+	while (!done)
+	{
+		const int   i  = R.i;
+		const float fi = (float) i;
+		const float posx = __builtin_fmaf(fi, R.sx, R.ex), posy = __builtin_fmaf(fi, R.sy, R.ey), posz = __builtin_fmaf(fi, R.sz, R.ez);
+		int         uix = 0, uiy = 0, uiz = 0;
+		float       ux = 0, uy = 0, uz = 0;
+		uint32_t    cell = 0;
+		if (SKIP != VKV_SKIP_NONE)
+		{        // frag:192, 220-221
+			ux = kx * posx, uy = ky * posy, uz = kz * posz;
+			uix = med3_i32((int) ux, 0, mw1), uiy = med3_i32((int) uy, 0, mh1), uiz = med3_i32((int) uz, 0, md1);
+			cell = __umul24(__umul24((uint32_t) uiz, (uint32_t) A.mh) + (uint32_t) uiy, (uint32_t) A.mw) + (uint32_t) uix;
+		}
+		const bool probe = SKIP != VKV_SKIP_NONE && !occ && cell != ul;        // frag:224
+
+		// ---- loads: probe byte first, then the footprint of the sampling lanes ----------------------------------------
+		uint32_t dist = 0, q00 = 0, q10 = 0, q01 = 0, q11 = 0;
+		float    wx = 0, wy = 0, wz = 0;
+		if (SKIP != VKV_SKIP_NONE && probe)
+			dist = R.dmap[cell];
+		if (kHoist && !probe)
+		{
+			const uint8_t *ba = packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, wx, wy, wz);
+			q00 = load_row<kNt>(ba);
+			q10 = load_row<kNt>(ba + 10);
+			q01 = load_row<kNt>(ba + 50);
+			q11 = load_row<kNt>(ba + 60);
+		}
+		// a wave whose live lanes all probe (the empty space in front of the volume) or all sample skips the other kind's arithmetic
+		const bool any_probe = !kUni || __ballot(probe) != 0ull, any_sample = !kUni || SKIP == VKV_SKIP_NONE || __ballot(!probe) != 0ull;
+
+		// ---- probe outcome (frag:234-247); needs the probe byte only ---------------------------------------------------
+		int skip = 0;
+		if (SKIP != VKV_SKIP_NONE && any_probe)
+		{
+			const float rx = __builtin_amdgcn_fmed3f((float) uix - ux, -1.0f, 0.0f);
+			const float ry = __builtin_amdgcn_fmed3f((float) uiy - uy, -1.0f, 0.0f);
+			const float rz = __builtin_amdgcn_fmed3f((float) uiz - uz, -1.0f, 0.0f);
+			float       ax, ay, az;
+			if (SKIP == VKV_SKIP_BLOCK)
+			{
+				ax = (((R.six < 0.0f) ? 0.0f : 1.0f) + rx) * R.six;
+				ay = (((R.siy < 0.0f) ? 0.0f : 1.0f) + ry) * R.siy;
+				az = (((R.siz < 0.0f) ? 0.0f : 1.0f) + rz) * R.siz;
+			}
+			else
+			{
+				const float fd = (float) dist;
+				ax = (((R.six > 0.0f) ? fd : 1.0f - fd) + rx) * R.six;
+				ay = (((R.siy > 0.0f) ? fd : 1.0f - fd) + ry) * R.siy;
+				az = (((R.siz > 0.0f) ? fd : 1.0f - fd) + rz) * R.siz;
+			}
+			// a NaN component (0 * inf on an axis-parallel ray) counts as +inf: minNum ignores it; all three cannot be NaN, and if
+			// they were the comparison caps the result exactly as the select chain of the oracle does
+			float m = __builtin_fminf(__builtin_fminf(ax, ay), az);
+			m       = (m < 1073741824.0f) ? m : 1073741824.0f;
+			skip    = max(1, (int) __builtin_ceilf(m));
+		}
+
+		// ---- sample outcome (frag:272-284) ---------------------------------------------------------------------------
+		float    intensity = 0.0f, gradient = 1.0f;
+		uint32_t ab = 0, texel = 0;
+		float    a = 0.0f, c = 0.0f;
+		if (any_sample)
+		{
+		if (kHoist)
+		{
+			float unused;
+			if (GRAD == 1)
+				packed_filter<true>(q00, q10, q01, q11, wx, wy, wz, intensity, gradient);
+			else
+				packed_filter<false>(q00, q10, q01, q11, wx, wy, wz, intensity, unused);
+		}
+		else if (!probe)
+		{
+			float unused;
+			if (PACKED)
+				sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, intensity, unused);
+			else
+			{
+				intensity = sample_linear(A.vol, W, H, D, posx, posy, posz);
+				if (GRAD == 1)
+					gradient = sample_linear(A.grad, W, H, D, posx, posy, posz);
+			}
+			if (GRAD == 2)
+			{        // frag:92-97
+				const float dix = 1.0f / (float) W, diy = 1.0f / (float) H, diz = 1.0f / (float) D;
+				float       t1, t2, t3, t4;
+				if (PACKED)
+				{
+					sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx + dix, posy - diy, posz - diz, t1, unused);
+					sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx - dix, posy - diy, posz + diz, t2, unused);
+					sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx - dix, posy + diy, posz - diz, t3, unused);
+					sample_packed<false>(A.packed, W, H, D, A.pmx, A.pmy, posx + dix, posy + diy, posz + diz, t4, unused);
+				}
+				else
+				{
+					t1 = sample_linear(A.vol, W, H, D, posx + dix, posy - diy, posz - diz);
+					t2 = sample_linear(A.vol, W, H, D, posx - dix, posy - diy, posz + diz);
+					t3 = sample_linear(A.vol, W, H, D, posx - dix, posy + diy, posz - diz);
+					t4 = sample_linear(A.vol, W, H, D, posx + dix, posy + diy, posz + diz);
+				}
+				const float gx = (((t1 - t2) - t3) + t4) * 0.25f;
+				const float gy = (((-t1 - t2) + t3) + t4) * 0.25f;
+				const float gz = (((-t1 + t2) - t3) + t4) * 0.25f;
+				const float len = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz);
+				gradient = g_clamp(len * A.grad_modifier, 0.0f, 1.0f);
+			}
+		}
+		// get_color (transfer_function.glsl:35-38), NEAREST: intensity and gradient are >= 0 and never NaN here (a filter of bytes;
+		// a clamped length), so clamp(int(floor(u * 256)), 0, 255) is min(int(u * 256), 255)
+		const uint32_t ti = (uint32_t) min((int) (intensity * 256.0f), 255), tg = GRAD == 0 ? 255u : (uint32_t) min((int) (gradient * 256.0f), 255);
+		if (SEP)
+		{
+			ab              = tf_separable_alpha(L.s.ai[ti], L.s.ag[tg]);
+			const float2 pr = L.s.pair[ab];
+			a = pr.x, c = pr.y;
+		}
+		else
+		{
+			const uint32_t tidx = tg * 256u + ti;
+			if (!probe)
+			{
+				if (A.tf_bits)
+				{
+					if ((L.g.bits[tidx >> 5] >> (tidx & 31u)) & 1u)
+						texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
+				}
+				else
+					texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
+			}
+			ab = texel >> 24;
+			a  = L.alpha[ab];
+		}
+		}
+
+		// ---- the frag's state update (frag:224-310) as one block of selects ---------------------------------------------
+		const bool smp    = !probe;
+		const bool p_skip = probe && dist > 0u;        // frag:236-247
+		const bool p_occ  = probe && dist == 0u;       // frag:248-262
+		const bool occ_s  = ab > 0u;                   // frag:276
+		const bool hit    = smp && occ_s;
+		R.n_dist += probe ? 1u : 0u;
+		R.n_vol += smp ? 1u : 0u;
+		R.n_empty += (smp && !occ_s) ? 1u : 0u;
+		const float om = 1.0f - R.a;        // frag:287
+		const float na = __builtin_fmaf(om, a, R.a);
+		if (SEP)
+			grey = hit ? __builtin_fmaf(om, c, grey) : grey;        // r = g = b: one channel is tracked
+		else
+		{
+			const float r_ = L.g.unorm[texel & 255u] * a, g_ = L.g.unorm[(texel >> 8) & 255u] * a, b_ = L.g.unorm[(texel >> 16) & 255u] * a;
+			const float nr = __builtin_fmaf(om, r_, R.r), ng = __builtin_fmaf(om, g_, R.g), nb = __builtin_fmaf(om, b_, R.b);
+			R.r = hit ? nr : R.r, R.g = hit ? ng : R.g, R.b = hit ? nb : R.b;
+		}
+		const bool ended = ERT && hit && na > 0.99f;        // frag:293-299
+		R.a              = hit ? (ended ? 1.0f : na) : R.a;
+		R.first_hit      = (hit && a > 0.0f) ? i : R.first_hit;
+		occ              = smp ? occ_s : (p_occ || occ);
+		if (SKIP != VKV_SKIP_NONE)
+			ul = (hit || p_occ) ? cell : ul;
+		const int jb = max(i - A.back, R.i_min);
+		const int ni = p_skip ? i + skip : (p_occ ? jb : i + 1);
+		R.i_min      = smp ? i + 1 : R.i_min;
+		R.i          = ni;
+		done         = ended || ni >= R.n_steps;
+		// the frame time is the critical path of the wave with the longest ray: once a wave has run 48 iterations it is one of
+		// those, so let it win instruction arbitration against the younger waves on its SIMD
+		if (__builtin_amdgcn_readfirstlane(++iter) == 48u)
+			__builtin_amdgcn_s_setprio(3);
+	}
+	if (SEP)
+		R.r = grey, R.g = grey, R.b = grey;
+}
+
+template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF>
+__global__ void __launch_bounds__(256) k_raymarch_lean(const RayMarchArgs A)
+{
+	__shared__ RmLds L;
+	const bool       sep = stage_tables_er(A, L);
+	const uint32_t x = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+	const uint32_t k = (idx / A.blocks_per_tile) * 8u + x, sb = idx % A.blocks_per_tile;
+	if (k >= A.tile_count)
+		return;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint32_t       px, py, o;
+	if (!block_pixel<1>(A, k * A.blocks_per_tile + sb, wave * 64u + lane, px, py, o))
+		return;
+	Ray R;
+	R.o = o;
+	const unsigned long long t_start = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+	const bool marched = ray_setup<SKIP>(A, px, py, R);
+	uint32_t   iter    = 0;
+	if (marched)
+	{
+		if (sep)
+			lean_march<SKIP, ERT, GRAD, PACKED, true, LF>(A, R, L, iter);
+		else
+			lean_march<SKIP, ERT, GRAD, PACKED, false, LF>(A, R, L, iter);
+	}
+	ray_finish(A, R, marched);
+	if (A.trace)
+	{        // diagnostic only: per-wave timeline (100 MHz clock); the values never feed an output
+		uint32_t it = iter;
+		for (int o2 = 32; o2 > 0; o2 >>= 1)
+			it = max(it, (uint32_t) __shfl_xor((int) it, o2));
+		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+		if (lane == (uint32_t) __builtin_ctzll(__ballot(1)))
+		{
+			unsigned long long *rec = A.trace + ((size_t) blockIdx.x * 4 + wave) * kTraceWords;
+			rec[0] = t_start, rec[1] = t_end, rec[2] = it, rec[3] = ((unsigned long long) __builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (k * A.blocks_per_tile + sb);
+			for (int w = 4; w < kTraceWords; ++w)
+				rec[w] = 0;
+		}
+	}
+}

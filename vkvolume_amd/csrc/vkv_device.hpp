@@ -9,6 +9,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "../../include/vkvolume_amd.h"
 
 namespace vkv
@@ -81,10 +84,10 @@ static_assert(kTfWords == VKV_TF_BITS_WORDS, "include/vkvolume_amd.h and vkv_dev
 // the alpha byte of a separable greyscale transfer function (src/volume_component.cpp:246-261 builds exactly this product)
 __host__ __device__ __forceinline__ uint32_t tf_separable_alpha(float ai, float ag)
 {
-	float t = (ai * ag) * 255.0f;
-	t       = (t < 0.0f) ? 0.0f : t;
-	t       = (255.0f < t) ? 255.0f : t;
-	return (uint32_t) t;
+	// ai, ag are in [0, 1] (k_tf_tables_init clamps them), so the product needs no clamp; the min keeps a table index in range whatever
+	// the tables hold.  The flag that enables this path is only set after all 65536 texels were checked against exactly this function.
+	const uint32_t b = (uint32_t) ((ai * ag) * 255.0f);
+	return b < 255u ? b : 255u;
 }
 
 // ---- packed sampling layout (vkv_pack_volume) -------------------------------------------------------------------
@@ -117,21 +120,45 @@ __host__ __device__ __forceinline__ size_t packed_brick_offset(int bx, int by, i
 
 }        // namespace vkv
 
-// Host-side context (capi.cpp owns it).
+// Host-side context (capi.hip owns it).
+// Device scratch is handed out PER STREAM (stream_scratch): calls on one stream are ordered, so they may share a buffer; calls on
+// different streams never touch the same bytes, which makes every entry point re-entrant across streams of one context.
 struct vkv_ctx
 {
-	int      device;
-	char     error[512];
-	uint8_t *d_workspace;        // small device scratch: TF bit table (8 KiB)
-	size_t   workspace_bytes;
-	void *   d_trace;        // diagnostic wave timeline buffer (vkv_debug_trace), normally null
+	int   device;
+	char  error[512];
+	void *d_trace;        // diagnostic wave timeline buffer (vkv_debug_trace), normally null
+	std::mutex                                 mutex;
+	std::unordered_map<hipStream_t, uint8_t *> scratch;        // stream -> kScratchBytes of device memory
 };
 
 namespace vkv
 {
 int  set_error(vkv_ctx *ctx, int code, const char *fmt, ...);
 int  check_launch(vkv_ctx *ctx, const char *what);
-constexpr size_t kWorkspaceBytes = 64 * 1024;
-constexpr size_t kTfBitsOffset   = 0;        // 256*256 bits = 8 KiB
-constexpr size_t kQueueHeadsOffset = 8192;     // 8 x u32 tile-queue heads of the persistent ray-march scheduler
+// this stream's scratch buffer (allocated on first use, freed by vkv_destroy); nullptr + error set when the allocation fails
+uint8_t *stream_scratch(vkv_ctx *ctx, hipStream_t stream);
+constexpr size_t kScratchBytes     = 16 * 1024;
+constexpr size_t kTfBitsOffset     = 0;           // 256*256 bits = 8 KiB: TF bit table of the map update / the voxel count
+constexpr size_t kQueueHeadsOffset = 8192;        // 8 x u32 tile-queue heads of the persistent ray-march scheduler
+
+// Every device entry point runs on the context's device whatever the calling thread's current device is, and leaves the
+// caller's current device as it found it.
+struct DeviceGuard
+{
+	int  prev = -1;
+	bool switched = false;
+	explicit DeviceGuard(int device)
+	{
+		if (hipGetDevice(&prev) == hipSuccess && prev != device)
+			switched = hipSetDevice(device) == hipSuccess;
+	}
+	~DeviceGuard()
+	{
+		if (switched)
+			(void) hipSetDevice(prev);
+	}
+	DeviceGuard(const DeviceGuard &) = delete;
+	DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
 }        // namespace vkv
