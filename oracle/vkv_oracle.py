@@ -17,11 +17,17 @@ _LIB = None
 
 def build(force=False):
     """Compile the oracle with gcc (Makefile in this directory)."""
-    try:  # make is a no-op when the library is newer than its sources and the ABI header
+    # make is a no-op when the library is newer than its sources and the ABI header
+    try:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
-    except (OSError, subprocess.CalledProcessError):
-        if not os.path.exists(os.path.join(_HERE, "libvkv_oracle.so")):
+    except OSError:
+        # no make on this machine: a prebuilt library is acceptable only if it is not older than what it is built from
+        so = os.path.join(_HERE, "libvkv_oracle.so")
+        srcs = [os.path.join(_HERE, "vkv_oracle.c"), os.path.join(_HERE, "vkv_oracle.h"),
+                os.path.join(os.path.dirname(_HERE), "include", "vkvolume_amd.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs):
             raise
+    # a failed compile (CalledProcessError) always propagates: comparing against a stale oracle would hide real differences
 
 
 def _has_fma():

@@ -6,6 +6,9 @@
 //   vkv_offscreen [--width=W --height=H] [--imin= --imax= --gmin= --gmax=] [--blocksize=B] [--skipmode=0..3]
 //                 [--gradient_test] [--benchmark=FRAMES] [--synthetic=WxHxD[:kind[:seed]] | <volume file>]
 //                 [--azimuth=DEG --elevation=DEG] [--dump-rgba8=file] [--dump-counts=file] [--dump-params=file]
+//                 [--second-synthetic=WxHxD[:kind[:seed]] --second-offset=X,Y,Z --dump-params2=file]   a second volume in the same
+//                                  subpass (VolumeRenderSubpass::draw loops over its volumes, src/volume_render_subpass.cpp:219)
+//                 [--reload]       load the volume twice into the same Volume object
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -38,7 +41,10 @@ struct Args
 	std::string dataset;
 	std::string synthetic;
 	float       azimuth = 30.0f, elevation = 20.0f;
-	std::string dump_rgba8, dump_counts, dump_params;
+	std::string dump_rgba8, dump_counts, dump_params, dump_params2;
+	std::string second_synthetic;
+	float       second_offset[3] = {0.0f, 0.0f, 0.0f};
+	bool        reload           = false;
 };
 
 bool flag(const char *arg, const char *name, std::string &value)
@@ -82,7 +88,15 @@ Args parse(int argc, char **argv)
 		else if (flag(s, "--elevation", v)) a.elevation = std::stof(v);
 		else if (flag(s, "--dump-rgba8", v)) a.dump_rgba8 = v;
 		else if (flag(s, "--dump-counts", v)) a.dump_counts = v;
+		else if (flag(s, "--dump-params2", v)) a.dump_params2 = v;
 		else if (flag(s, "--dump-params", v)) a.dump_params = v;
+		else if (flag(s, "--second-synthetic", v)) a.second_synthetic = v;
+		else if (flag(s, "--second-offset", v))
+		{
+			if (std::sscanf(v.c_str(), "%f,%f,%f", &a.second_offset[0], &a.second_offset[1], &a.second_offset[2]) != 3)
+				throw std::runtime_error("--second-offset=X,Y,Z");
+		}
+		else if (flag(s, "--reload", v)) a.reload = true;
 		else if (s[0] != '-') a.dataset = s;
 		else throw std::runtime_error(std::string("unknown flag ") + s);
 	}
@@ -154,6 +168,8 @@ int main(int argc, char **argv)
 			if (std::sscanf(args.synthetic.c_str(), "%ux%ux%u:%u:%u", &w, &h, &d, &kind, &seed) < 3)
 				throw std::runtime_error("--synthetic=WxHxD[:kind[:seed]]");
 			volume.load_synthetic(dc, VkvExtent3D{w, h, d}, kind, seed, args.blocksize);
+			if (args.reload)        // a Volume object is reusable: the second load replaces every resource of the first
+				volume.load_synthetic(dc, VkvExtent3D{w, h, d}, kind, seed, args.blocksize);
 			volume.set_image_transform(vkv::scale(vkv::vec3{(float) w, (float) h, (float) d}));
 		}
 		else if (!args.dataset.empty())
@@ -233,7 +249,32 @@ int main(int argc, char **argv)
 			camera.projection = vkv::perspective_vulkan(vkv::radians(60.0f), (float) args.width / (float) args.height, 0.1f, 1000.0f);
 		}
 
-		VolumeRenderSubpass subpass(dc, {&volume}, camera, render_options);
+		// optional second volume: same call order, its node translated; it is blended onto the first one's result
+		Volume volume2("second");
+		std::vector<Volume *> volumes{&volume};
+		if (!args.second_synthetic.empty())
+		{
+			unsigned w = 0, h = 0, d = 0, kind = 1, seed = 0xC0FFEE03u;
+			if (std::sscanf(args.second_synthetic.c_str(), "%ux%ux%u:%u:%u", &w, &h, &d, &kind, &seed) < 3)
+				throw std::runtime_error("--second-synthetic=WxHxD[:kind[:seed]]");
+			volume2.options = volume.options;
+			volume2.load_synthetic(dc, VkvExtent3D{w, h, d}, kind, seed, args.blocksize);
+			volume2.set_image_transform(vkv::scale(vkv::vec3{(float) w, (float) h, (float) d}));
+			const auto tf2 = volume2.get_transfer_function_uniform();
+			if (volume2.options.use_precomputed_gradient)
+				compute_gradient_map.compute(volume2, tf2);
+			volume2.update_transfer_function_texture(dc);
+			compute_distance_map.compute(volume2, tf2, render_options.skipping_type);
+			float longest = 0.0f;
+			const vkv::mat4 &m = volume2.get_image_transform();
+			for (int c = 0; c < 3; ++c)
+				longest = std::max(longest, std::sqrt(m.at(0, c) * m.at(0, c) + m.at(1, c) * m.at(1, c) + m.at(2, c) * m.at(2, c)));
+			const float s2         = 100.0f / longest;
+			volume2.node_transform = vkv::translate(vkv::vec3{args.second_offset[0], args.second_offset[1], args.second_offset[2]}) * vkv::scale(vkv::vec3{s2, s2, s2});
+			volumes.push_back(&volume2);
+		}
+
+		VolumeRenderSubpass subpass(dc, volumes, camera, render_options);
 		subpass.prepare();
 		RenderTarget target;
 		target.width = args.width, target.height = args.height;
@@ -282,6 +323,12 @@ int main(int argc, char **argv)
 		{        // the exact parameter block draw() handed to vkv_render (device pointers included), for the parity tests
 			const VkvRenderParams p = subpass.make_params(volume, target, nullptr);
 			std::ofstream         f(args.dump_params, std::ios::binary);
+			f.write(reinterpret_cast<const char *>(&p), sizeof(p));
+		}
+		if (!args.dump_params2.empty() && volumes.size() > 1)
+		{
+			const VkvRenderParams p = subpass.make_params(volume2, target, nullptr, true);
+			std::ofstream         f(args.dump_params2, std::ios::binary);
 			f.write(reinterpret_cast<const char *>(&p), sizeof(p));
 		}
 		if (!args.dump_rgba8.empty())

@@ -61,7 +61,8 @@ class Volume:
         rnd = lambda x: (x + block - 1) // block  # noqa: E731  (volume_component.cpp:91-92)
         self.map_extent = abi.Extent3D(rnd(w), rnd(h), rnd(d))
         if self.options.use_precomputed_gradient:
-            self.gradient = torch.empty_like(self.volume)
+            self.gradient = torch.zeros_like(self.volume)
+        self.gradient_valid = False  # set by ComputeGradientMap.compute; the packed image must not be built from an empty map
         self.transfer_function = torch.zeros((256, 256, 4), dtype=torch.uint8, device=self.device)
         self.transfer_function_bits = torch.zeros(abi.TF_BITS_WORDS, dtype=torch.int32, device=self.device)
         self.packed = None
@@ -93,7 +94,11 @@ class Volume:
 
     def pack(self):
         """(Re)build the bricked sampling image from the linear volume (+ gradient map).  Call after the gradient map
-        is computed — the counterpart of the driver's swizzle into an optimally tiled VkImage."""
+        is computed — the counterpart of the driver's swizzle into an optimally tiled VkImage.  The packed image is a COPY:
+        call pack() again after writing to ``volume`` / ``gradient`` in place (load_* and ComputeGradientMap do it themselves)."""
+        if self.options.use_precomputed_gradient and not self.gradient_valid:
+            raise RuntimeError("Volume.pack: use_precomputed_gradient is set but no gradient map has been computed "
+                               "(run ComputeGradientMap.compute first)")
         n = self.ctx.packed_volume_bytes(self.extent)
         if self.packed is None or self.packed.numel() != n:
             self.packed = torch.empty(n, dtype=torch.uint8, device=self.device)
@@ -107,6 +112,7 @@ class ComputeGradientMap:
 
     def compute(self, volume, transfer_function_uniform):
         self.ctx.gradient_map(_ptr(volume.volume), _ptr(volume.gradient), volume.extent, transfer_function_uniform, _stream())
+        volume.gradient_valid = True
         if volume.use_packed:
             volume.pack()
 
@@ -134,11 +140,12 @@ class VolumeRenderSubpass:
         self.options = options if options is not None else abi.RenderOptions()
         self.image_size = image_size
 
-    def make_params(self, view, proj, tiles=None):
+    def make_params(self, view, proj, tiles=None, uniforms=None):
+        """``uniforms``: an already built (CameraUniform, RayCastUniform, RayGen) triple instead of vkv_build_uniforms' (tests)."""
         v = self.volume
         w, h = self.image_size
-        cam, rc, rg = lib.build_uniforms(view, proj, v.node_transform, v.image_transform, self.options.clip_distance, (w, h),
-                                         v.extent, v.map_extent)
+        cam, rc, rg = uniforms if uniforms is not None else lib.build_uniforms(
+            view, proj, v.node_transform, v.image_transform, self.options.clip_distance, (w, h), v.extent, v.map_extent)
         p = abi.RenderParams()
         p.camera, p.ray_cast, p.ray_gen = cam, rc, rg
         p.transfer_function = v.get_transfer_function_uniform()
