@@ -5,20 +5,29 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-One *step* = one frame: every ray of the frame marched through the 1024x1024x795 uint8 synthetic volume
-(BASELINE.json configs[2], "C3") with the app-default transfer function, block size 4, Chebyshev distance-map
-empty-space skipping and early ray termination, from one of 8 fixed orbit cameras (step k uses view k mod 8).
-Inputs (volume, gradient map, TF texture, distance map) are resident in HBM before the timed region.
+One *step* = one frame: every ray of the frame marched through the synthetic uint8 volume of the workload (default "c3":
+1024x1024x795, BASELINE.json configs[2]) with the app-default transfer function, block size 4, Chebyshev distance-map
+empty-space skipping and early ray termination, from one of 8 fixed orbit cameras (step k uses view k mod 8).  Inputs (volume,
+gradient map, TF texture, distance map, packed sampling image) are resident in HBM before the timed region.
 
-N = 1: the frame is 1920x1080.  N > 1 (weak scaling): the frame is (1920*sx)x(1080*sy) with sx*sy = N sampling the
-SAME frustum, cut into 16x16 tiles dealt round-robin to the ranks (volume replicated); each rank renders its tiles into
-a compact RGBA8 buffer, the buffers are gathered over RCCL to the frame's owner (rank k mod N for frame k, so that consecutive
-frames use disjoint xGMI links; --frame-owner rank0 pins it) and de-interleaved there.  The gather of frame k
-overlaps the renders of the next frames; the de-interleave runs on its own stream.  value = rays of all ranks / max-over-ranks wall time.
+The timed block is EXACTLY K steps between two fences (barrier + synchronize); the block is repeated until at least
+--min-seconds have been measured and the MEDIAN block is reported (`repeats`, `ms_per_step_min_max`).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the ray-march kernel by ALGORITHMIC bytes (SURVEY.md §8d:
-16 B per volume sample, 1 B per distance probe, 4 B per ray of RGBA8 output) over its HIP-event duration;
-`cpu_baseline` times the CPU oracle (a scalar port of the reference shaders) on a pixel-strided sample of the same frames.
+N = 1 submits the frames `--frames-per-launch` at a time through vkv_render_batch (default 8: the eight views of one orbit in one
+launch, the frames advance side by side inside one grid); `--frames-per-launch 1` renders strictly one frame per launch, and
+`--submit streams` keeps `--frames-in-flight` single-frame launches in flight on as many HIP streams (the round 1 scheme).
+The one-frame-at-a-time launch duration is always measured too (`single_frame`, outside the timed region).
+
+N > 1: the frame is cut into 16x16 tiles dealt round-robin to the ranks (volume replicated); each rank renders its tiles into a
+compact RGBA8 buffer, the buffers are gathered over RCCL to the frame's owner (rank k mod N for frame k, so that consecutive
+frames use disjoint xGMI links; --frame-owner rank0 pins it) and de-interleaved there.  `--scaling weak` (default for c2/c3/c4):
+the frame grows to (W*sx)x(H*sy), sx*sy = N, sampling the SAME frustum; `--scaling strong` (default for c5, BASELINE.json
+configs[4]): the frame stays 7680x4320 whatever N is.  value = rays of all ranks / max-over-ranks wall time.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the ray-march kernel by ALGORITHMIC bytes (16 B per volume sample,
+1 B per distance probe, 4 B per ray of RGBA8 output) of one launch over that launch's HIP-event duration; `cpu_baseline` times the
+CPU oracle (a scalar port of the reference shaders) on a pixel-strided sample of the same frames; `--verify-cpu` also compares
+those oracle pixels (three counters + RGBA8) with the device's, bit for bit.
 """
 import argparse
 import json
@@ -27,7 +36,7 @@ import os
 import sys
 import time
 
-# ROCclr multiplexes HIP streams onto 4 hardware queues by default; the frames in flight, the assembly stream and RCCL's own
+# ROCclr multiplexes HIP streams onto 4 hardware queues by default; frames in flight, the assembly stream and RCCL's own
 # stream need one each or they serialise behind each other (measured: 0.27 -> 0.20 ms per step on the gather path).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -40,23 +49,31 @@ if ROOT not in sys.path:
 
 from vkvolume_amd import abi, camera, lib, multigpu, volume as V  # noqa: E402
 
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1_traffic.json")  # PMC-measured HBM bytes per launch (own rocprofv3 passes)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_traffic.json")  # PMC-measured HBM bytes per launch (own rocprofv3 passes)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 WORKLOADS = {
-    # name: (extent WxHxD, seed, voxel size, axis-angle, frame, skipping type)
-    "c3": ((1024, 1024, 795), 0xC0FFEE03, (0.0003, 0.0003, 0.0007), (1.0, 0.0, 0.0, 90.0), (1920, 1080), abi.SKIP_DISTANCE),
-    "c2": ((512, 512, 512), 0xC0FFEE02, (1.0, 1.0, 1.0), (1.0, 0.0, 0.0, 0.0), (1920, 1080), abi.SKIP_BLOCK),
-    "c4": ((2048, 2048, 2048), 0xC0FFEE04, (1.0, 1.0, 1.0), (1.0, 0.0, 0.0, 0.0), (3840, 2160), abi.SKIP_ANISOTROPIC_DISTANCE),
-    "small": ((128, 128, 100), 0xC0FFEE03, (0.0003, 0.0003, 0.0007), (1.0, 0.0, 0.0, 90.0), (320, 192), abi.SKIP_DISTANCE),
+    # name: (extent WxHxD, seed, voxel size, axis-angle, frame, skipping type, scaling at N > 1)
+    "c3": ((1024, 1024, 795), 0xC0FFEE03, (0.0003, 0.0003, 0.0007), (1.0, 0.0, 0.0, 90.0), (1920, 1080), abi.SKIP_DISTANCE, "weak"),
+    "c3cube": ((1024, 1024, 1024), 0xC0FFEE03, (1.0, 1.0, 1.0), (1.0, 0.0, 0.0, 0.0), (1920, 1080), abi.SKIP_DISTANCE, "weak"),
+    "c2": ((512, 512, 512), 0xC0FFEE02, (1.0, 1.0, 1.0), (1.0, 0.0, 0.0, 0.0), (1920, 1080), abi.SKIP_BLOCK, "weak"),
+    "c4": ((2048, 2048, 2048), 0xC0FFEE04, (1.0, 1.0, 1.0), (1.0, 0.0, 0.0, 0.0), (3840, 2160), abi.SKIP_ANISOTROPIC_DISTANCE, "weak"),
+    "c5": ((2048, 2048, 2048), 0xC0FFEE04, (1.0, 1.0, 1.0), (1.0, 0.0, 0.0, 0.0), (7680, 4320), abi.SKIP_ANISOTROPIC_DISTANCE, "strong"),
+    "small": ((128, 128, 100), 0xC0FFEE03, (0.0003, 0.0003, 0.0007), (1.0, 0.0, 0.0, 90.0), (320, 192), abi.SKIP_DISTANCE, "weak"),
+}
+WORKLOAD_NOTE = {
+    "c3": "BASELINE.json configs[2] (stag-beetle shape)", "c3cube": "the literal 1024^3 of BASELINE.json's metric line",
+    "c2": "BASELINE.json configs[1]", "c4": "BASELINE.json configs[3]", "c5": "BASELINE.json configs[4]: fixed 7680x4320 frame, screen tiles over the ranks",
+    "small": "smoke size",
 }
 GRID = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
 TILE = 16
 N_VIEWS = 8
+B_OUT = 4  # bytes per ray of the RGBA8 frame
 
 
 def build_scene(ctx, name):
-    extent, seed, voxel, axis_angle, frame, skip = WORKLOADS[name]
+    extent, seed, voxel, axis_angle, frame, skip = WORKLOADS[name][:6]
     v = V.Volume(ctx)
     v.options = abi.VolumeOptions(intensity_min=0.1, intensity_max=1.0, gradient_min=0.0, gradient_max=0.2)  # volume_render.cpp:67-70
     v.load_synthetic(extent, kind=1, seed=seed, distance_map_block_size=4)
@@ -91,12 +108,17 @@ def main():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames-in-flight", type=int, default=3, help="render consecutive frames on this many HIP streams (each with its "
-                    "own framebuffer) so the tail of one frame overlaps the start of the next; 1 = strictly one frame at a time")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: grow the frame with N (weak) or keep it (strong); default per workload")
+    ap.add_argument("--submit", default=None, choices=["batch", "streams"], help="N = 1: vkv_render_batch launches (default) or single-frame launches "
+                    "on --frames-in-flight streams; N > 1 always uses streams")
+    ap.add_argument("--frames-per-launch", type=int, default=8, help="batch submission: frames per vkv_render_batch launch (1 = one frame per launch)")
+    ap.add_argument("--frames-in-flight", type=int, default=3, help="stream submission: consecutive frames render on this many HIP streams")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the timed block of K steps until this much time has been measured")
     ap.add_argument("--frame-owner", default="rotate", choices=["rotate", "rank0"], help="N > 1: rank that assembles frame k: k mod N "
                     "(default; the inbound xGMI links and the de-interleave of consecutive frames are then disjoint) or always rank 0")
     ap.add_argument("--force-gather", action="store_true", help="exercise the tile gather / de-interleave path with a 1-rank process group")
     ap.add_argument("--verify", action="store_true", help="after timing, check the assembled frame of the last step against a direct render")
+    ap.add_argument("--verify-cpu", action="store_true", help="compare the CPU oracle's pixels (counters + RGBA8) with the device's, bit for bit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
@@ -113,6 +135,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     use_gather = world > 1 or args.force_gather
+    submit = "streams" if use_gather else (args.submit or "batch")
     if use_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -122,7 +145,8 @@ def main():
 
     ctx = lib.Context(local_rank)  # raises if the HIP library is missing: there is no fallback path
     v, tf, frame, skip = build_scene(ctx, args.workload)
-    sx, sy = GRID[world]
+    scaling = args.scaling or WORKLOADS[args.workload][6]
+    sx, sy = GRID[world] if scaling == "weak" else (1, 1)
     fw, fh = frame[0] * sx, frame[1] * sy
     views = cameras(v, frame[0] / frame[1])  # the SAME frustum for every N
     opts = abi.RenderOptions(skipping_type=skip, clip_distance=1.0, early_ray_termination=True)
@@ -132,7 +156,7 @@ def main():
     my_pixels = tiles.tile_count * TILE * TILE if use_gather else fw * fh
     rays_per_frame_all = fw * fh  # every pixel of the frame is a ray (covered or not), summed over ranks
 
-    # ---- pre-pass (untimed): frag counters per view -> algorithmic bytes per launch ------------------------------
+    # ---- pre-pass (untimed): frag counters per view -> algorithmic bytes per frame ---------------------------------
     counts = torch.zeros((my_pixels, 3), dtype=torch.int32, device="cuda")
     n_vs, n_ds, n_cov = [], [], []
     for p in params:
@@ -144,13 +168,10 @@ def main():
         n_ds.append(int(s[1]))
         n_cov.append(int(((counts[:, 0] + counts[:, 1]) > 0).sum().item()))
     del counts
+
     # ---- outputs -------------------------------------------------------------------------------------------------
-    # `fif` frames are in flight: frame k renders on HIP stream k % fif into its own buffer, so the long tail of one
-    # frame (a few waves with 200-300 dependent events) overlaps the bulk of the next — what a swap-chain renderer
-    # (the reference) gets from its per-frame command buffers.  N = 1 renders straight into the frame; N > 1 (or
-    # --force-gather) renders this rank's tiles into a compact buffer that is gathered to rank 0 and de-interleaved.
     fif = max(1, args.frames_in_flight)
-    nbuf = fif  # frame k renders on stream k % fif into buffer k % nbuf
+    fpl = max(1, min(args.frames_per_launch, abi.MAX_BATCH, args.steps))
     gather, images, rotate = None, [], False
     if use_gather:
         nbuf = fif + 1  # one more buffer than render streams: a render does not wait for the gather of the frame fif steps back
@@ -160,32 +181,64 @@ def main():
         if rank == 0 or rotate:
             images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
     else:
-        bufs, my_rays = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(fif)], fw * fh
+        nbuf = fpl if submit == "batch" else fif
+        bufs, my_rays = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)], fw * fh
     torch.cuda.synchronize()
+    frame_bytes = [n_vs[i] * 16 + n_ds[i] * 1 + my_rays * B_OUT for i in range(N_VIEWS)]  # algorithmic bytes of one frame (this rank's part)
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(fif - 1)]
+    side = torch.cuda.Stream() if gather else None
+    freed = [None] * nbuf
+    launches = []  # (start event, stop event, algorithmic bytes) of the timed launches of the last block
+
+    # per-launch parameter blocks of the batch path: slot j of a launch renders into bufs[j]
+    batch_params = None
+    if submit == "batch":
+        batch_params = []
+        for view_i in range(N_VIEWS):
+            row = []
+            for j in range(nbuf):
+                q = abi.RenderParams.from_buffer_copy(params[view_i])
+                q.d_out_rgba8, q.d_out_color, q.d_out_counts, q.d_out_depth = bufs[j].data_ptr(), None, None, None
+                q.d_in_depth, q.blend_over_target = None, 0
+                row.append(q)
+            batch_params.append(row)
+
+    def run_batch(n_steps, timed):
+        st = streams[0]
+        k = 0
+        while k < n_steps:
+            n = min(fpl, n_steps - k)
+            plist = [batch_params[(k + j) % N_VIEWS][j] for j in range(n)]
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+            if n == 1:
+                ctx.render(plist[0], st.cuda_stream)
+            else:
+                ctx.render_batch(plist, st.cuda_stream)
+            if timed:
+                e1.record(st)
+                launches.append((e0, e1, sum(frame_bytes[(k + j) % N_VIEWS] for j in range(n)), n))
+            k += n
 
     # HIP events bracket every launch at N = 1; on the gather path every 7th (a timing event per launch costs ~25 us per step
     # there, more than 10 % of the step, once seven queues are busy)
     ev_every = 7 if use_gather else 1  # coprime with the 8 views
-    ev_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev_stop = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    # Assembly (wait for the gather, de-interleave on rank 0) has its own stream: a render stream only ever waits on the event
-    # that says its buffer is free again, never behind an assembly kernel.
-    side = torch.cuda.Stream() if gather else None
-    freed = [None] * nbuf
-
-    def run(n_steps, timed):
+    def run_streams(n_steps, timed):
         for k in range(n_steps):
             b, st = k % nbuf, streams[k % fif]
             with torch.cuda.stream(st):
                 if gather and freed[b] is not None:
                     st.wait_event(freed[b])  # frame k - nbuf: its gather has read bufs[b], its de-interleave has read flat[b]
-                if timed and k % ev_every == 0:
-                    ev_start[k].record(st)
+                ev = timed and k % ev_every == 0
+                if ev:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
                 sp.draw(params[k % N_VIEWS], rgba8=bufs[b])
-                if timed and k % ev_every == 0:
-                    ev_stop[k].record(st)
+                if ev:
+                    e1.record(st)
+                    launches.append((e0, e1, frame_bytes[k % N_VIEWS], 1))
                 if gather:
                     # RCCL gather of frame k (ordered after the render) overlaps the renders of the next frames
                     gather.start(b, k % world if rotate else 0)
@@ -198,6 +251,8 @@ def main():
                     freed[b] = torch.cuda.Event()
                     freed[b].record(side)
 
+    run = run_batch if submit == "batch" else run_streams
+
     def fence():
         if world > 1:
             dist.barrier(device_ids=[local_rank])
@@ -205,23 +260,57 @@ def main():
 
     run(args.warmup, False)
     fence()
-    t0 = time.perf_counter()
-    run(args.steps, True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    timed_steps = list(range(0, args.steps, ev_every))
-    kernel_ms = [ev_start[k].elapsed_time(ev_stop[k]) for k in timed_steps]
+    # ---- timed blocks: exactly K steps between two fences, repeated until min_seconds have been measured -----------
+    blocks, kernel_ms, kernel_bytes, kernel_frames = [], [], [], []
+    total = 0.0
+    while True:
+        del launches[:]
+        fence()
+        t0 = time.perf_counter()
+        run(args.steps, True)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        blocks.append(elapsed)
+        kernel_ms += [e0.elapsed_time(e1) for e0, e1, _, _ in launches]
+        kernel_bytes += [b for _, _, b, _ in launches]
+        kernel_frames += [n for _, _, _, n in launches]
+        total += elapsed
+        stop = total >= args.min_seconds or len(blocks) >= 4096
+        if world > 1:
+            t = torch.tensor([1.0 if stop else 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            stop = t.item() > 0
+        if stop:
+            break
+    elapsed = float(np.median(blocks))
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
-    # algorithmic bytes of this rank's launches, averaged over the launches actually timed
-    b_out = 4
-    alg_bytes = [n_vs[k % N_VIEWS] * 16 + n_ds[k % N_VIEWS] * 1 + my_rays * b_out for k in timed_steps]
-    alg_avg = sum(alg_bytes) / len(alg_bytes)
+    alg_avg = sum(kernel_bytes) / len(kernel_bytes)
     achieved_gbs = alg_avg / (kernel_ms_avg * 1e-3) / 1e9
+
+    # ---- one frame at a time (outside the timed region): the latency of a single frame's launch ---------------------
+    single = None
+    if not use_gather:
+        per_view = []
+        for i in range(N_VIEWS):
+            ts = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                sp.draw(params[i], rgba8=bufs[0])
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            per_view.append(float(np.median(ts)))
+        ms1 = float(np.mean(per_view))
+        gb1 = float(np.mean(frame_bytes)) / (ms1 * 1e-3) / 1e9
+        single = {"ms_per_launch": round(ms1, 4), "achieved": round(gb1, 2), "frac": round(gb1 / HBM_PEAK_GBS, 5),
+                  "Mray_per_s": round(rays_per_frame_all / ms1 / 1e3, 1),
+                  "note": "one vkv_render launch per frame with nothing else on the GPU: median of 5 per view, mean over the 8 views"}
 
     # whole-job sample rates need every rank's counters
     tot = torch.tensor([sum(n_vs[k % N_VIEWS] for k in range(args.steps)), sum(n_ds[k % N_VIEWS] for k in range(args.steps)),
@@ -231,55 +320,62 @@ def main():
     vs_total, ds_total, cov_total = float(tot[0].item()), float(tot[1].item()), float(tot[2].item())
 
     if args.verify:
-        verify(ctx, sp, v, views, params, args.steps, nbuf, (fw, fh), bufs, images, gather, rank, (args.steps - 1) % world if rotate else 0)
+        verify(ctx, sp, v, views, params, args.steps, nbuf, fpl if submit == "batch" else 0, (fw, fh), bufs, images, gather, rank,
+               (args.steps - 1) % world if rotate else 0)
     if rank != 0:
         dist.destroy_process_group()
         return
 
     value = rays_per_frame_all * args.steps / elapsed / 1e6
+    extent = WORKLOADS[args.workload][0]
     out = {
         "metric": "Mray/s", "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %dx%dx%d uint8 synthetic shells, %dx%d frame, %s ESS + ERT, block 4, TF imin 0.1 imax 1 gmin 0 gmax 0.2, "
-                               "8 orbit views" % (args.workload, *WORKLOADS[args.workload][0], fw, fh,
-                                                  {1: "block", 2: "Chebyshev distance-map", 3: "anisotropic"}[skip]),
+        "repeats": len(blocks), "ms_per_step_min_max": [round(min(blocks) / args.steps * 1e3, 4), round(max(blocks) / args.steps * 1e3, 4)],
+        "config": {"workload": "%s (%s): %dx%dx%d uint8 synthetic shells, %dx%d frame, %s ESS + ERT, block 4, TF imin 0.1 imax 1 gmin 0 gmax 0.2, "
+                               "8 orbit views" % (args.workload, WORKLOAD_NOTE[args.workload], *extent, fw, fh,
+                                                  {1: "block", 2: "Chebyshev distance-map", 3: "anisotropic Chebyshev distance-map"}[skip]),
                    "parallelism": "screen tiles 16x16 round-robin over %d GPU(s), RCCL gather to %s" % (
                        world, "rank k mod N for frame k" if rotate else "rank 0") if world > 1 else "1 GPU",
-                   "output": "RGBA8", "frames_in_flight": fif, "occupied_voxel_percent": round(occupied_voxel_percent(ctx, v, tf), 4)},
+                   "output": "RGBA8",
+                   "submission": ("vkv_render_batch, %d frames per launch" % fpl) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams" % (fif, fif)),
+                   "occupied_voxel_percent": round(occupied_voxel_percent(ctx, v, tf), 4)},
         "covered_Mray_per_s": round(cov_total / elapsed / 1e6, 3), "covered_fraction": round(cov_total / (rays_per_frame_all * args.steps), 4),
         "volume_samples_per_s": round(vs_total / elapsed, 1), "distance_probes_per_s": round(ds_total / elapsed, 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
-                     "achieved_aggregate": round(sum(n_vs[k % N_VIEWS] * 16 + n_ds[k % N_VIEWS] * 1 + my_rays * b_out for k in range(args.steps))
-                                                 / elapsed / 1e9, 2),
-                     "kernel": "k_raymarch", "kernel_ms_avg": round(kernel_ms_avg, 4),
+                     "kernel": "k_raymarch_lean_batch" if (submit == "batch" and fpl > 1) else "k_raymarch_lean", "kernel_ms_avg": round(kernel_ms_avg, 4),
+                     "frames_per_launch": round(sum(kernel_frames) / len(kernel_frames), 3),
                      "algorithmic_bytes_per_launch": int(alg_avg),
-                     "note": "algorithmic (requested) bytes: 16 B/volume sample + 1 B/distance probe + 4 B/ray; NOT DRAM traffic. achieved = per "
-                             "launch / HIP-event duration of that launch (launches of consecutive frames overlap when frames_in_flight > 1); "
-                             "achieved_aggregate = this rank's bytes of all timed launches / wall time; HIP events bracket every launch "
-                             "at N = 1 and every 7th launch on the gather path"},
+                     "achieved_aggregate": round(sum(frame_bytes[k % N_VIEWS] for k in range(args.steps)) / elapsed / 1e9, 2),
+                     "note": "algorithmic (requested) bytes: 16 B/volume sample + 1 B/distance probe + 4 B/ray, summed over the frames of a launch; NOT "
+                             "DRAM traffic. achieved = bytes of a launch / HIP-event duration of that launch, averaged over the timed launches; "
+                             "achieved_aggregate = this rank's bytes of one timed block / its wall time; HIP events bracket every launch at N = 1 "
+                             "and every 7th launch on the gather path (where launches of consecutive frames overlap)"},
     }
+    if single is not None:
+        out["single_frame"] = single
 
     # HBM traffic cannot be read from inside the process; it comes from separate rocprofv3 --pmc passes over this same
     # command (FETCH_SIZE and WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), committed under profiles/
     try:
         with open(TRAFFIC_FILE) as f:
             tr = json.load(f)
-        if tr.get("workload") == args.workload and world == 1:
+        if tr.get("workload") == args.workload and world == 1 and tr.get("kernel") == out["roofline"]["kernel"]:
             out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
             out["roofline"]["traffic_source"] = tr["source"]
     except (OSError, ValueError, KeyError):
         pass
 
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(v, params, (fw, fh), args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(ctx, sp, v, params, (fw, fh), args.cpu_seconds, args.verify_cpu, out)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
-def verify(ctx, sp, v, views, params, steps, nbuf, frame, bufs, images, gather, rank, owner):
+def verify(ctx, sp, v, views, params, steps, nbuf, fpl, frame, bufs, images, gather, rank, owner):
     """The frame left in the last step's buffer (on the rank that owns it) must equal a direct single-launch render of the same
     view, bit for bit."""
     if rank != owner:
@@ -289,16 +385,18 @@ def verify(ctx, sp, v, views, params, steps, nbuf, frame, bufs, images, gather, 
     direct = torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda")
     sp.draw(sp.make_params(*views[k % N_VIEWS], abi.full_frame_tiles(fw, fh, TILE, TILE)), rgba8=direct)
     torch.cuda.synchronize()
-    got = images[k % nbuf] if gather else bufs[k % nbuf].view(fh, fw, 4)
+    slot = (k % fpl) if fpl else (k % nbuf)  # batch submission: step k is slot k mod fpl of its launch
+    got = images[k % nbuf] if gather else bufs[slot].view(fh, fw, 4)
     if not torch.equal(got, direct):
         raise SystemExit("verify failed: assembled frame differs from the direct render in %d bytes" % int((got != direct).sum().item()))
     print("verify ok (rank %d): frame of step %d matches the direct render (%d non-zero bytes)" % (rank, k, int((direct != 0).sum().item())),
           file=sys.stderr)
 
 
-def cpu_baseline(v, params, frame, target_seconds):
+def cpu_baseline(ctx, sp, v, params, frame, target_seconds, verify_cpu, out):
     """Time the CPU oracle (scalar port of the reference shaders, all host cores) on every s-th pixel in x and y of the
-    same 8 frames.  The oracle is only the baseline being timed here; nothing it computes feeds the GPU result."""
+    same 8 frames.  The oracle is only the baseline being timed here; nothing it computes feeds the GPU result.  With
+    --verify-cpu the pixels it rendered are then compared with the device's frames (the oracle as the checker)."""
     from oracle import vkv_oracle as O
     cores = os.cpu_count() or 1
     vol, grad = v.volume.cpu().numpy(), v.gradient.cpu().numpy()
@@ -313,14 +411,31 @@ def cpu_baseline(v, params, frame, target_seconds):
     want = rate * target_seconds / N_VIEWS
     stride = max(1, int(math.ceil(math.sqrt(frame[0] * frame[1] / max(want, 1.0)))))
     rays, passes = 0, 0
+    last = []
     t = time.perf_counter()
     while True:
-        for p in params:
-            rays += O.render(p, vol, grad, tex, maps, n_threads=cores, pixel_stride=stride).rays
+        last = [O.render(p, vol, grad, tex, maps, n_threads=cores, pixel_stride=stride, want_rgba8=verify_cpu) for p in params]
+        rays += sum(r.rays for r in last)
         passes += 1
         dt = time.perf_counter() - t
         if dt >= target_seconds or passes >= 64:
             break
+    if verify_cpu:
+        fw, fh = frame
+        counts = torch.zeros((fh, fw, 3), dtype=torch.int32, device="cuda")
+        rgba8 = torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda")
+        sel = (slice(0, fh, stride), slice(0, fw, stride))
+        n = 0
+        for i, p in enumerate(params):
+            sp.draw(p, rgba8=rgba8, counts=counts)
+            torch.cuda.synchronize()
+            if not np.array_equal(counts.cpu().numpy().astype(np.uint32)[sel], last[i].counts[sel]):
+                raise SystemExit("verify-cpu failed: view %d: the frag counters differ from the oracle's" % i)
+            if not np.array_equal(rgba8.cpu().numpy()[sel], last[i].rgba8[sel]):
+                raise SystemExit("verify-cpu failed: view %d: RGBA8 differs from the oracle's" % i)
+            n += last[i].counts[sel].shape[0] * last[i].counts[sel].shape[1]
+        out["verified_against_cpu"] = {"views": len(params), "pixels": n, "pixel_stride": stride, "what": "3 counters + RGBA8 per pixel, bit-exact"}
+        print("verify-cpu ok: %d pixels of %d views match the oracle (counters + RGBA8)" % (n, len(params)), file=sys.stderr)
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mray/s", "cores": cores, "kind": "port",
             "sample": "oracle/vkv_oracle.c (scalar C port of the shaders, pthreads over scanlines), every %d-th pixel in x and y of the "
                       "same 8 frames, %d pass(es): %d rays in %.1f s" % (stride, passes, rays, dt)}

@@ -283,6 +283,14 @@ int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_transfer_function,
 /* VolumeRenderSubpass::draw, src/volume_render_subpass.cpp:159-294 (shaders/volume_render.frag). */
 int vkv_render(vkv_ctx *ctx, const VkvRenderParams *params, void *stream);
 
+/* Several frames in ONE launch: `count` (1 .. VKV_MAX_BATCH) parameter blocks that share the kernel variant (skipping type, ERT,
+ * gradient mode, test mode), have a packed sampling image and the same tile-schedule size; cameras, volumes and output buffers
+ * may differ (stereo pairs, orbit sweeps, the per-rank tile sets of a multi-GPU frame, the reference's frames in flight).  The
+ * frames advance side by side inside one grid, so the long tail of each is covered by the bulk of the others without relying on
+ * several hardware queues.  Output buffers of different frames must not overlap.  Results are bit-identical to `count` vkv_render calls. */
+#define VKV_MAX_BATCH 12
+int vkv_render_batch(vkv_ctx *ctx, const VkvRenderParams *params, uint32_t count, void *stream);
+
 /* Root-rank de-interleave of gathered compact tile buffers into the W×H image (multi-GPU):
  * d_gathered holds n_ranks buffers of tiles_per_rank tiles each, bytes_per_pixel per pixel. */
 int vkv_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, uint32_t image_width,

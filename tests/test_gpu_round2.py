@@ -171,3 +171,53 @@ def test_two_volumes_in_one_subpass(tmp_path, skipmode):
     assert both.sum() > 100, "the two volumes must overlap on screen for the blend to be exercised"
     assert np.array_equal(rgba8, frames[1].rgba8), "two-volume frame differs from the oracle's"
     assert np.array_equal(counts, frames[1].counts)
+
+
+@pytest.mark.parametrize("skipping_type", [abi.SKIP_NONE, abi.SKIP_DISTANCE, abi.SKIP_ANISOTROPIC_DISTANCE])
+def test_render_batch_equals_single_launches(ctx, skipping_type):
+    """vkv_render_batch: n frames (different cameras, one of them another volume) in one launch == n vkv_render calls, bit for bit."""
+    opt = abi.VolumeOptions(**T.APP_TF)
+    scenes = [T.OracleScene(O.synth_volume((80, 72, 64), 1, 70 + k), opt, 4) for k in range(2)]
+    vols = [make_gpu_volume(ctx, s) for s in scenes]
+    for v, tf in vols:
+        V.ComputeDistanceMap(ctx).compute(v, tf, skipping_type)
+    size = (144, 80)
+    ro = abi.RenderOptions(skipping_type=skipping_type, clip_distance=1.0)
+    frames = []
+    for k, az in enumerate((0.0, 50.0, 111.0, 200.0, 290.0)):
+        scene, (v, tf) = scenes[k % 2], vols[k % 2]
+        view, proj = T.orbit(az, image_size=size)
+        p = V.VolumeRenderSubpass(ctx, v, ro, size).bind(scene.params(view, proj, size, ro))
+        frames.append((scene, p))
+    st = torch.cuda.current_stream().cuda_stream
+
+    def outputs():
+        return [dict(color=torch.full((size[1], size[0], 4), -1.0, dtype=torch.float32, device="cuda"),
+                     counts=torch.full((size[1], size[0], 3), 9, dtype=torch.int32, device="cuda"),
+                     depth=torch.full((size[1], size[0]), -1.0, dtype=torch.float32, device="cuda"),
+                     rgba8=torch.full((size[1], size[0], 4), 7, dtype=torch.uint8, device="cuda")) for _ in frames]
+
+    def point(p, o):
+        p.d_out_color, p.d_out_counts, p.d_out_depth, p.d_out_rgba8 = (o[k].data_ptr() for k in ("color", "counts", "depth", "rgba8"))
+
+    single, batch = outputs(), outputs()
+    for (scene, p), o in zip(frames, single):
+        point(p, o)
+        ctx.render(p, st)
+    plist = []
+    for (scene, p), o in zip(frames, batch):
+        q = abi.RenderParams.from_buffer_copy(p)
+        point(q, o)
+        plist.append(q)
+    ctx.render_batch(plist, st)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(single, batch)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), "frame %d: %s differs between the batch and the single launch" % (i, k)
+    ref = frames[3][0].render(frames[3][1])
+    assert np.array_equal(batch[3]["counts"].cpu().numpy().astype(np.uint32), ref.counts)
+    # a frame that needs another kernel variant is refused
+    bad = abi.RenderParams.from_buffer_copy(plist[1])
+    bad.options.early_ray_termination = 0
+    with pytest.raises(lib.VkvError):
+        ctx.render_batch([plist[0], bad], st)

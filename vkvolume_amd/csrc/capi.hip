@@ -7,8 +7,10 @@
 #include <cstring>
 #include <new>
 
+#include <algorithm>
 #include <exception>
 #include <string>
+#include <vector>
 
 #include "../host/load_volume.h"
 #include "../host/vkv_math.hpp"
@@ -24,6 +26,7 @@ int launch_distance_map_anisotropic(vkv_ctx *, uint8_t *const[8], uint8_t *, Vkv
 int launch_synth_volume(vkv_ctx *, uint8_t *, VkvExtent3D, uint32_t, uint32_t, hipStream_t);
 int launch_scatter_tiles(vkv_ctx *, const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 int launch_render(vkv_ctx *, const VkvRenderParams *, const float *, hipStream_t);
+int launch_render_batch(vkv_ctx *, const VkvRenderParams *, uint32_t, const float *, hipStream_t);
 int launch_pack_volume(vkv_ctx *, const uint8_t *, const uint8_t *, VkvExtent3D, void *, hipStream_t);
 int launch_check_numerics(vkv_ctx *, int, uint32_t, uint64_t, unsigned long long *, hipStream_t);
 int launch_tf_tables(vkv_ctx *, const uint8_t *, const VkvTransferFunctionUniform *, uint32_t *, hipStream_t);
@@ -57,6 +60,46 @@ uint8_t *stream_scratch(vkv_ctx *ctx, hipStream_t stream)
 	}
 	ctx->scratch.emplace(stream, p);
 	return p;
+}
+
+const uint32_t *tile_start_order(vkv_ctx *ctx, uint32_t img_w, uint32_t img_h, uint32_t tile_w, uint32_t tile_h, uint32_t first, uint32_t stride, uint32_t count)
+{
+	if (count < 2)
+		return nullptr;
+	const uint32_t tiles_x = (img_w + tile_w - 1) / tile_w, tiles_y = (img_h + tile_h - 1) / tile_h;
+	std::lock_guard<std::mutex> lock(ctx->mutex);
+	for (const auto &t : ctx->tile_orders)
+		if (t.tiles_x == tiles_x && t.tiles_y == tiles_y && t.tile_w == tile_w && t.tile_h == tile_h && t.img_w == img_w && t.img_h == img_h && t.first == first &&
+		    t.stride == stride && t.count == count)
+			return t.d_order;
+	std::vector<std::pair<double, uint32_t>> key(count);
+	for (uint32_t k = 0; k < count; ++k)
+	{
+		const uint64_t t  = (uint64_t) first + (uint64_t) k * stride;
+		const double   cx = ((double) (t % tiles_x) + 0.5) * tile_w - 0.5 * img_w, cy = ((double) (t / tiles_x) + 0.5) * tile_h - 0.5 * img_h;
+		key[k]            = {cx * cx + cy * cy, k};
+	}
+	std::stable_sort(key.begin(), key.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+	std::vector<uint32_t> order(count);
+	for (uint32_t r = 0; r < count; ++r)
+		order[r] = key[r].second;
+	uint32_t *d = nullptr;
+	if (hipMalloc((void **) &d, (size_t) count * sizeof(uint32_t)) != hipSuccess)
+		return nullptr;
+	if (hipMemcpy(d, order.data(), (size_t) count * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+	{
+		(void) hipFree(d);
+		return nullptr;
+	}
+	if (ctx->tile_orders.size() >= 64)
+	{        // a renderer uses a handful of schedules; drop the oldest rather than grow without bound.  Launches that still read it
+		 // must have finished: synchronise before freeing
+		(void) hipDeviceSynchronize();
+		(void) hipFree(ctx->tile_orders.front().d_order);
+		ctx->tile_orders.erase(ctx->tile_orders.begin());
+	}
+	ctx->tile_orders.push_back({tiles_x, tiles_y, tile_w, tile_h, img_w, img_h, first, stride, count, d});
+	return d;
 }
 
 int check_launch(vkv_ctx *ctx, const char *what)
@@ -111,6 +154,8 @@ void vkv_destroy(vkv_ctx *ctx)
 		DeviceGuard guard(ctx->device);
 		for (auto &kv : ctx->scratch)
 			(void) hipFree(kv.second);
+		for (auto &t : ctx->tile_orders)
+			(void) hipFree(t.d_order);
 	}
 	delete ctx;
 }
@@ -438,11 +483,9 @@ int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_tf, uint32_t *d_ta
 	return vkv_transfer_function_tables(ctx, d_tf, nullptr, d_tables, stream);
 }
 
-int vkv_render(vkv_ctx *ctx, const VkvRenderParams *P, void *stream)
+// argument checks shared by vkv_render and vkv_render_batch
+static int check_render_params(vkv_ctx *ctx, const VkvRenderParams *P)
 {
-	if (!ctx)
-		return VKV_E_INVALID_ARGUMENT;
-	DeviceGuard guard(ctx->device);
 	if (!P)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: null params");
 	const VkvRenderOptions &o = P->options;
@@ -466,6 +509,8 @@ int vkv_render(vkv_ctx *ctx, const VkvRenderParams *P, void *stream)
 			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: bad map extent");
 		if ((uint64_t) P->map_extent.width * P->map_extent.height * P->map_extent.depth > 0xffffffffull)
 			return set_error(ctx, VKV_E_UNSUPPORTED, "render: distance maps with more than 2^32 cells are not supported");
+		if (P->map_extent.width >= (1u << 24) || P->map_extent.height >= (1u << 24) || P->map_extent.depth >= (1u << 24))
+			return set_error(ctx, VKV_E_UNSUPPORTED, "render: distance map axes of 2^24 cells or more are not supported");
 		const int n = o.skipping_type == VKV_SKIP_ANISOTROPIC_DISTANCE ? 8 : 1;
 		for (int i = 0; i < n; ++i)
 			if (!P->d_distance_maps[i])
@@ -483,17 +528,55 @@ int vkv_render(vkv_ctx *ctx, const VkvRenderParams *P, void *stream)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: d_packed_volume must be 256-byte aligned");
 	if (!P->d_out_color && !P->d_out_rgba8 && !P->d_out_counts && !P->d_out_depth)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: no output buffer");
+	return VKV_OK;
+}
 
-	// opacity-correction table keyed by the TF alpha byte (frag:283):
-	// lut[a] = clamp(voxel_alpha_factor * (1 - pow(1 - a/255, 1/sampling_factor)), 0, 1)
-	float       lut[256];
-	const float sf_inv = 1.0f / P->transfer_function.sampling_factor;
+// opacity-correction table keyed by the TF alpha byte (frag:283):
+// lut[a] = clamp(voxel_alpha_factor * (1 - pow(1 - a/255, 1/sampling_factor)), 0, 1)
+static void build_alpha_lut(const VkvTransferFunctionUniform &tf, float *lut)
+{
+	const float sf_inv = 1.0f / tf.sampling_factor;
 	for (int a = 0; a < 256; ++a)
 	{
-		const float v = P->transfer_function.voxel_alpha_factor * (1.0f - std::pow(1.0f - (float) a / 255.0f, sf_inv));
+		const float v = tf.voxel_alpha_factor * (1.0f - std::pow(1.0f - (float) a / 255.0f, sf_inv));
 		lut[a]        = std::min(std::max(v, 0.0f), 1.0f);
 	}
+}
+
+int vkv_render(vkv_ctx *ctx, const VkvRenderParams *P, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
+	const int   rc = check_render_params(ctx, P);
+	if (rc != VKV_OK)
+		return rc;
+	float lut[256];
+	build_alpha_lut(P->transfer_function, lut);
 	return launch_render(ctx, P, lut, (hipStream_t) stream);
+}
+
+int vkv_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t count, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
+	if (!P || count == 0 || count > VKV_MAX_BATCH)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: count must be 1 .. %d", VKV_MAX_BATCH);
+	std::vector<float> luts((size_t) count * 256);
+	for (uint32_t i = 0; i < count; ++i)
+	{
+		const int rc = check_render_params(ctx, &P[i]);
+		if (rc != VKV_OK)
+			return rc;
+		const VkvRenderParams &a = P[i], &b = P[0];
+		if (a.options.skipping_type != b.options.skipping_type || (a.options.early_ray_termination != 0) != (b.options.early_ray_termination != 0) ||
+		    (a.transfer_function.use_gradient != 0) != (b.transfer_function.use_gradient != 0) ||
+		    (a.use_precomputed_gradient != 0) != (b.use_precomputed_gradient != 0))
+			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: frame %u needs a different kernel variant than frame 0", i);
+		build_alpha_lut(a.transfer_function, luts.data() + (size_t) i * 256);
+	}
+	return launch_render_batch(ctx, P, count, luts.data(), (hipStream_t) stream);
 }
 
 int vkv_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, uint32_t image_width, uint32_t image_height, uint32_t tile_width,

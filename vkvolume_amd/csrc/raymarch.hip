@@ -1,6 +1,7 @@
 // raymarch.hip — launchers of the ray-march integrator (device code: raymarch_core.hpp).
 #include <cmath>
 #include <cstdlib>
+#include <vector>
 
 #include "raymarch_core.hpp"
 
@@ -113,6 +114,8 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 	a.queue_heads = nullptr;        // persistent scheduler: set at launch (per-stream scratch)
 	a.trace       = reinterpret_cast<unsigned long long *>(ctx->d_trace);
 	a.back        = (int) std::ceil(P->transfer_function.sampling_factor);
+	static const bool in_order = [] { const char *e = std::getenv("VKV_RAYMARCH_TILE_ORDER"); return e && e[0] == 'l'; }();        // "linear": A/B switch
+	a.tile_order  = in_order ? nullptr : tile_start_order(ctx, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count);
 	for (int i = 0; i < 256; ++i)
 		a.alpha_lut[i] = alpha_lut[i];
 	return VKV_OK;
@@ -140,6 +143,72 @@ int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut
 		case VKV_SKIP_ANISOTROPIC_DISTANCE: return launch_ert<VKV_SKIP_ANISOTROPIC_DISTANCE>(ctx, sched, ert, grad, a, s);
 		default: return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: bad skipping_type %d", P->options.skipping_type);
 	}
+}
+
+// ---- several frames in one launch --------------------------------------------------------------------------------
+template <int SKIP, bool ERT>
+static void launch_batch_grad(int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, hipStream_t s)
+{
+	if (grad == 0)
+		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 0, kLeanUniform>), dim3(grid), dim3(256), 0, s, d_frames, n, gpf);
+	else if (grad == 1)
+		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 1, kLeanUniform>), dim3(grid), dim3(256), 0, s, d_frames, n, gpf);
+	else
+		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 2, kLeanUniform>), dim3(grid), dim3(256), 0, s, d_frames, n, gpf);
+}
+
+template <int SKIP>
+static void launch_batch_ert(bool ert, int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, hipStream_t s)
+{
+	if (ert)
+		launch_batch_grad<SKIP, true>(grad, d_frames, n, grid, gpf, s);
+	else
+		launch_batch_grad<SKIP, false>(grad, d_frames, n, grid, gpf, s);
+}
+
+int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, const float *alpha_luts, hipStream_t s)
+{
+	// the argument blocks go through this stream's scratch buffer: an earlier batch on the same stream has finished with it by the
+	// time the copy (same stream) runs
+	static_assert(kMaxBatch * sizeof(RayMarchArgs) <= kScratchBytes - kBatchArgsOffset, "batch argument blocks must fit the stream scratch");
+	std::vector<RayMarchArgs> host(n);
+	for (uint32_t i = 0; i < n; ++i)
+	{
+		const int rc = fill_render_args(ctx, &P[i], alpha_luts + (size_t) i * 256, host[i]);
+		if (rc != VKV_OK)
+			return rc;
+		if (!host[i].packed)
+			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: frame %u has no packed sampling image (d_packed_volume)", i);
+		if (host[i].nblocks != host[0].nblocks || host[i].tile_count != host[0].tile_count || host[i].blocks_per_tile != host[0].blocks_per_tile)
+			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: frame %u has a different tile schedule size than frame 0", i);
+	}
+	if (host[0].nblocks == 0)
+		return VKV_OK;
+	uint8_t *scratch = stream_scratch(ctx, s);
+	if (!scratch)
+		return VKV_E_UNSUPPORTED;
+	RayMarchArgs *   d_frames = reinterpret_cast<RayMarchArgs *>(scratch + kBatchArgsOffset);
+	const hipError_t e        = hipMemcpyAsync(d_frames, host.data(), n * sizeof(RayMarchArgs), hipMemcpyHostToDevice, s);
+	if (e != hipSuccess)
+		return set_error(ctx, (int) e, "render_batch: argument upload: %s", hipGetErrorString(e));
+	const uint64_t grid = (uint64_t) ((host[0].tile_count + 7u) / 8u) * 8u * host[0].blocks_per_tile * n;
+	if (grid > 0x7fffffffull)
+		return set_error(ctx, VKV_E_UNSUPPORTED, "render_batch: too many workgroups for one launch");
+	const bool ert  = P[0].options.early_ray_termination != 0;
+	const int  grad = !P[0].transfer_function.use_gradient ? 0 : (P[0].use_precomputed_gradient ? 1 : 2);
+	// frames interleaved in groups of eight workgroups (default) or one frame after the other (VKV_RAYMARCH_BATCH_ORDER=sequential, A/B
+	// switch: measured 0.183 vs 0.169 ms per frame on C3 with 8 frames per launch)
+	static const bool sequential = [] { const char *e = std::getenv("VKV_RAYMARCH_BATCH_ORDER"); return e && e[0] == 's'; }();
+	const uint32_t    gpf        = sequential ? (uint32_t) (grid / n / 8) : 0u;
+	switch (P[0].options.skipping_type)
+	{
+		case VKV_SKIP_NONE: launch_batch_ert<VKV_SKIP_NONE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, s); break;
+		case VKV_SKIP_BLOCK: launch_batch_ert<VKV_SKIP_BLOCK>(ert, grad, d_frames, n, (uint32_t) grid, gpf, s); break;
+		case VKV_SKIP_DISTANCE: launch_batch_ert<VKV_SKIP_DISTANCE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, s); break;
+		case VKV_SKIP_ANISOTROPIC_DISTANCE: launch_batch_ert<VKV_SKIP_ANISOTROPIC_DISTANCE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, s); break;
+		default: return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: bad skipping_type %d", P[0].options.skipping_type);
+	}
+	return check_launch(ctx, "render_batch");
 }
 
 }        // namespace vkv

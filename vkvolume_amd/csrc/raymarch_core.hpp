@@ -55,6 +55,7 @@ struct RayMarchArgs
 	int             test;
 	unsigned long long *trace;      // diagnostic (tools/wave_trace.py): kTraceWords x u64 per wave {t_start, t_end, iterations, unit, phase sums}, or null
 	int             back;           // ceil(sampling_factor): the step back after a probe that found an occupied cell (frag:253)
+	const uint32_t *tile_order;     // k_raymarch_lean: the r-th tile to be started is schedule entry tile_order[r] (centre of the image first), or null
 	uint32_t *      queue_heads;        // persistent scheduler: 8 tile-queue heads (one per XCD label), zeroed per launch
 	float           alpha_lut[256];     // opacity correction keyed by the TF alpha byte (frag:283)
 };
@@ -1292,12 +1293,6 @@ __global__ void __launch_bounds__(256) k_raymarch_er(const RayMarchArgs A)
 	}
 }
 
-namespace vkv
-{
-// raymarch.hip: VkvRenderParams -> kernel arguments (shared with tools/lab)
-int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, RayMarchArgs &a);
-}        // namespace vkv
-
 // ===============================================================================================================
 // k_raymarch_lean: one lane per ray, the frag's loop body as straight-line predicated code.
 // What differs from the round 1 kernel (k_raymarch_tiles), each step measured with tools/lab:
@@ -1514,15 +1509,24 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		R.r = grey, R.g = grey, R.b = grey;
 }
 
+// the body of one workgroup: 16x16 pixels of the frame described by A; `bid` is the workgroup's id inside that frame's grid
 template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF>
-__global__ void __launch_bounds__(256) k_raymarch_lean(const RayMarchArgs A)
+__device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, RmLds &L)
 {
-	__shared__ RmLds L;
-	const bool       sep = stage_tables_er(A, L);
-	const uint32_t x = blockIdx.x & 7u, idx = blockIdx.x >> 3;
-	const uint32_t k = (idx / A.blocks_per_tile) * 8u + x, sb = idx % A.blocks_per_tile;
-	if (k >= A.tile_count)
+	const bool     sep = stage_tables_er(A, L);
+	// Hardware deals workgroup ids round-robin over the 8 XCDs (own L2 each).  XCD x = id & 7 marches the schedule's tiles
+	// k = x, x + 8, x + 16, ... one after the other: neighbouring workgroups of an XCD share a tile (L2 locality) while the tiles
+	// of the frame are spread evenly over the XCDs (ESS makes screen regions differ >10x in cost).
+	const uint32_t x = bid & 7u, idx = bid >> 3;
+	const uint32_t rank = (idx / A.blocks_per_tile) * 8u + x, sb = idx % A.blocks_per_tile;
+	if (rank >= A.tile_count)
 		return;
+	// Tiles are STARTED centre of the image first (tile_order, built by the launcher): the volume sits there, so the tiles with the
+	// long rays — the critical path of the launch — start at once and the cheap border tiles fill the tail.  Any order gives the same
+	// frame; on C3 this one shortens a single frame's launch from 0.324 to 0.306 ms and the tail of an 8-frame launch from 0.18 to
+	// 0.03 ms (bench.py).  Several single-frame launches in flight on their own streams prefer the plain order
+	// (VKV_RAYMARCH_TILE_ORDER=linear: 0.157 vs 0.167 ms per frame with three in flight) - their heavy centres then do not coincide.
+	const uint32_t k = A.tile_order ? A.tile_order[rank] : rank;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t       px, py, o;
 	if (!block_pixel<1>(A, k * A.blocks_per_tile + sb, wave * 64u + lane, px, py, o))
@@ -1548,10 +1552,45 @@ __global__ void __launch_bounds__(256) k_raymarch_lean(const RayMarchArgs A)
 		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
 		if (lane == (uint32_t) __builtin_ctzll(__ballot(1)))
 		{
-			unsigned long long *rec = A.trace + ((size_t) blockIdx.x * 4 + wave) * kTraceWords;
+			unsigned long long *rec = A.trace + ((size_t) bid * 4 + wave) * kTraceWords;
 			rec[0] = t_start, rec[1] = t_end, rec[2] = it, rec[3] = ((unsigned long long) __builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (k * A.blocks_per_tile + sb);
 			for (int w = 4; w < kTraceWords; ++w)
 				rec[w] = 0;
 		}
 	}
 }
+
+template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF>
+__global__ void __launch_bounds__(256) k_raymarch_lean(const RayMarchArgs A)
+{
+	__shared__ RmLds L;
+	lean_block<SKIP, ERT, GRAD, PACKED, LF>(A, blockIdx.x, L);
+}
+
+// Several frames in one launch (vkv_render_batch): frame f = (id / 8) % n takes every n-th group of eight workgroup ids, so the
+// frames advance side by side and the long tail of each (a few waves with hundreds of dependent events) is covered by the bulk
+// of the others — what a renderer with frames in flight gets from several queues, without depending on queue scheduling.
+// The argument blocks live in device memory (n x 1.7 KB does not fit the kernel-argument segment).
+template <int SKIP, bool ERT, int GRAD, uint32_t LF>
+__global__ void __launch_bounds__(256) k_raymarch_lean_batch(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t groups_per_frame)
+{
+	__shared__ RmLds L;
+	const uint32_t   g = blockIdx.x >> 3;
+	if (groups_per_frame == 0)
+	{        // interleaved
+		const uint32_t f = g % n;
+		lean_block<SKIP, ERT, GRAD, true, LF>(frames[f], ((g / n) << 3) | (blockIdx.x & 7u), L);
+	}
+	else
+	{        // one frame after the other
+		const uint32_t f = g / groups_per_frame;
+		lean_block<SKIP, ERT, GRAD, true, LF>(frames[f], ((g % groups_per_frame) << 3) | (blockIdx.x & 7u), L);
+	}
+}
+
+namespace vkv
+{
+// raymarch.hip: VkvRenderParams -> kernel arguments (shared with tools/lab)
+int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, RayMarchArgs &a);
+}        // namespace vkv
+

@@ -11,6 +11,7 @@
 
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "../../include/vkvolume_amd.h"
 
@@ -130,6 +131,13 @@ struct vkv_ctx
 	void *d_trace;        // diagnostic wave timeline buffer (vkv_debug_trace), normally null
 	std::mutex                                 mutex;
 	std::unordered_map<hipStream_t, uint8_t *> scratch;        // stream -> kScratchBytes of device memory
+	// start orders of tile schedules (centre of the image first), built on first use and kept: immutable device arrays
+	struct TileOrder
+	{
+		uint32_t  tiles_x, tiles_y, tile_w, tile_h, img_w, img_h, first, stride, count;
+		uint32_t *d_order;
+	};
+	std::vector<TileOrder> tile_orders;
 };
 
 namespace vkv
@@ -138,9 +146,14 @@ int  set_error(vkv_ctx *ctx, int code, const char *fmt, ...);
 int  check_launch(vkv_ctx *ctx, const char *what);
 // this stream's scratch buffer (allocated on first use, freed by vkv_destroy); nullptr + error set when the allocation fails
 uint8_t *stream_scratch(vkv_ctx *ctx, hipStream_t stream);
-constexpr size_t kScratchBytes     = 16 * 1024;
+// start order of a tile schedule: entry indices sorted by the distance of the tile's centre from the image centre (device array of
+// `count` uint32, cached per schedule shape); nullptr when the table cannot be allocated (the kernel then takes the tiles in order)
+const uint32_t *tile_start_order(vkv_ctx *ctx, uint32_t img_w, uint32_t img_h, uint32_t tile_w, uint32_t tile_h, uint32_t first, uint32_t stride, uint32_t count);
+constexpr size_t kScratchBytes     = 32 * 1024;
 constexpr size_t kTfBitsOffset     = 0;           // 256*256 bits = 8 KiB: TF bit table of the map update / the voxel count
 constexpr size_t kQueueHeadsOffset = 8192;        // 8 x u32 tile-queue heads of the persistent ray-march scheduler
+constexpr size_t kBatchArgsOffset  = 8448;        // vkv_render_batch: kMaxBatch argument blocks
+constexpr uint32_t kMaxBatch       = VKV_MAX_BATCH;
 
 // Every device entry point runs on the context's device whatever the calling thread's current device is, and leaves the
 // caller's current device as it found it.

@@ -15,7 +15,7 @@ EXPORTS = [
     "vkv_create", "vkv_destroy", "vkv_last_error", "vkv_version",
     "vkv_transfer_function_uniform", "vkv_transfer_function_texture", "vkv_build_uniforms",
     "vkv_gradient_map", "vkv_occupancy_map", "vkv_distance_map", "vkv_distance_map_anisotropic",
-    "vkv_compute_distance_map", "vkv_render", "vkv_scatter_tiles", "vkv_synth_volume",
+    "vkv_compute_distance_map", "vkv_render", "vkv_render_batch", "vkv_scatter_tiles", "vkv_synth_volume",
     "vkv_packed_volume_bytes", "vkv_pack_volume", "vkv_transfer_function_bits", "vkv_transfer_function_tables",
     "vkv_occupied_voxel_count", "vkv_load_header", "vkv_load_data", "vkv_convert_volume",
 ]
@@ -61,6 +61,7 @@ def load():
     L.vkv_compute_distance_map.argtypes = [vp, vp, vp, vp, P(abi.TransferFunctionUniform), abi.Extent3D, P(vp), vp,
                                            abi.Extent3D, i32, vp]
     L.vkv_render.argtypes = [vp, P(abi.RenderParams), vp]
+    L.vkv_render_batch.argtypes = [vp, P(abi.RenderParams), C.c_uint32, vp]
     L.vkv_scatter_tiles.argtypes = [vp, vp, vp, u32, u32, u32, u32, u32, u32, u32, vp]
     L.vkv_synth_volume.argtypes = [vp, vp, abi.Extent3D, u32, u32, vp]
     L.vkv_packed_volume_bytes.argtypes = [abi.Extent3D]
@@ -127,6 +128,11 @@ class Context:
 
     def render(self, params, stream=0):
         self.check(self._lib.vkv_render(self.handle, C.byref(params), stream))
+
+    def render_batch(self, params_list, stream=0):
+        """vkv_render_batch: several frames (same kernel variant, same tile-schedule size) in one launch."""
+        arr = (abi.RenderParams * len(params_list))(*params_list)
+        self.check(self._lib.vkv_render_batch(self.handle, arr, len(params_list), stream))
 
     def render_rc(self, params, stream=0):
         """Like render() but returns the status code instead of raising (error-path tests)."""
