@@ -103,11 +103,18 @@ def cameras(v, aspect):
 
 
 def main():
+    # rank 0 must print exactly ONE line on stdout, but RCCL writes a version banner there when it creates a communicator: keep the real
+    # stdout for the JSON line and send everything else that is written to file descriptor 1 to stderr
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--skip", default=None, choices=["none", "block", "distance", "anisotropic"], help="override the workload's empty-space-skipping mode")
+    ap.add_argument("--no-ert", action="store_true", help="early ray termination off (with --skip none: dense sampling of every step of every ray)")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: grow the frame with N (weak) or keep it (strong); default per workload")
     ap.add_argument("--submit", default=None, choices=["batch", "streams"], help="N = 1: vkv_render_batch launches (default) or single-frame launches "
                     "on --frames-in-flight streams; N > 1 always uses streams")
@@ -116,6 +123,8 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the timed block of K steps until this much time has been measured")
     ap.add_argument("--frame-owner", default="rotate", choices=["rotate", "rank0"], help="N > 1: rank that assembles frame k: k mod N "
                     "(default; the inbound xGMI links and the de-interleave of consecutive frames are then disjoint) or always rank 0")
+    ap.add_argument("--exchange", default="native", choices=["native", "torch"], help="N > 1: the tile gather through the C ABI (vkv_assemble_frame: "
+                    "ncclGather on a communicator of our own, default) or through torch.distributed.gather")
     ap.add_argument("--force-gather", action="store_true", help="exercise the tile gather / de-interleave path with a 1-rank process group")
     ap.add_argument("--verify", action="store_true", help="after timing, check the assembled frame of the last step against a direct render")
     ap.add_argument("--verify-cpu", action="store_true", help="compare the CPU oracle's pixels (counters + RGBA8) with the device's, bit for bit")
@@ -145,11 +154,15 @@ def main():
 
     ctx = lib.Context(local_rank)  # raises if the HIP library is missing: there is no fallback path
     v, tf, frame, skip = build_scene(ctx, args.workload)
+    if args.skip is not None:
+        skip = {"none": abi.SKIP_NONE, "block": abi.SKIP_BLOCK, "distance": abi.SKIP_DISTANCE, "anisotropic": abi.SKIP_ANISOTROPIC_DISTANCE}[args.skip]
+        V.ComputeDistanceMap(ctx).compute(v, tf, skip)
+        torch.cuda.synchronize()
     scaling = args.scaling or WORKLOADS[args.workload][6]
     sx, sy = GRID[world] if scaling == "weak" else (1, 1)
     fw, fh = frame[0] * sx, frame[1] * sy
     views = cameras(v, frame[0] / frame[1])  # the SAME frustum for every N
-    opts = abi.RenderOptions(skipping_type=skip, clip_distance=1.0, early_ray_termination=True)
+    opts = abi.RenderOptions(skipping_type=skip, clip_distance=1.0, early_ray_termination=not args.no_ert)
     sp = V.VolumeRenderSubpass(ctx, v, opts, (fw, fh))
     tiles = abi.full_frame_tiles(fw, fh, TILE, TILE, rank, world, compact=use_gather)
     params = [sp.make_params(view, proj, tiles) for view, proj in views]
@@ -176,10 +189,14 @@ def main():
     if use_gather:
         nbuf = fif + 1  # one more buffer than render streams: a render does not wait for the gather of the frame fif steps back
         rotate = args.frame_owner == "rotate" and world > 1
-        gather = multigpu.TileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda", n_buffers=nbuf, any_root=rotate)
+        if args.exchange == "native":
+            gather = multigpu.NativeExchange(ctx, dist, rank, world, (fw, fh), TILE, 4, n_buffers=nbuf, any_root=rotate)
+            images = gather.images or []
+        else:
+            gather = multigpu.TileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda", n_buffers=nbuf, any_root=rotate)
+            if rank == 0 or rotate:
+                images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
         bufs, my_rays = gather.buffers, gather.my_ray_count()
-        if rank == 0 or rotate:
-            images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
     else:
         nbuf = fpl if submit == "batch" else fif
         bufs, my_rays = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)], fw * fh
@@ -239,10 +256,19 @@ def main():
                 if ev:
                     e1.record(st)
                     launches.append((e0, e1, frame_bytes[k % N_VIEWS], 1))
-                if gather:
+                if gather and native:
+                    rendered = torch.cuda.Event()
+                    rendered.record(st)
+                elif gather:
                     # RCCL gather of frame k (ordered after the render) overlaps the renders of the next frames
                     gather.start(b, k % world if rotate else 0)
-            if gather:
+            if gather and native:
+                # gather + de-interleave of frame k on the assembly stream, behind its render: nothing waits on the host
+                side.wait_event(rendered)
+                gather.assemble(b, k % world if rotate else 0, side)
+                freed[b] = torch.cuda.Event()
+                freed[b].record(side)
+            elif gather:
                 with torch.cuda.stream(side):
                     flat = gather.finish(b)
                     if flat is not None:
@@ -251,6 +277,7 @@ def main():
                     freed[b] = torch.cuda.Event()
                     freed[b].record(side)
 
+    native = gather is not None and args.exchange == "native"
     run = run_batch if submit == "batch" else run_streams
 
     def fence():
@@ -323,6 +350,8 @@ def main():
         verify(ctx, sp, v, views, params, args.steps, nbuf, fpl if submit == "batch" else 0, (fw, fh), bufs, images, gather, rank,
                (args.steps - 1) % world if rotate else 0)
     if rank != 0:
+        if native:
+            gather.close()
         dist.destroy_process_group()
         return
 
@@ -333,11 +362,13 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "repeats": len(blocks), "ms_per_step_min_max": [round(min(blocks) / args.steps * 1e3, 4), round(max(blocks) / args.steps * 1e3, 4)],
-        "config": {"workload": "%s (%s): %dx%dx%d uint8 synthetic shells, %dx%d frame, %s ESS + ERT, block 4, TF imin 0.1 imax 1 gmin 0 gmax 0.2, "
+        "config": {"workload": "%s (%s): %dx%dx%d uint8 synthetic shells, %dx%d frame, %s, block 4, TF imin 0.1 imax 1 gmin 0 gmax 0.2, "
                                "8 orbit views" % (args.workload, WORKLOAD_NOTE[args.workload], *extent, fw, fh,
-                                                  {1: "block", 2: "Chebyshev distance-map", 3: "anisotropic Chebyshev distance-map"}[skip]),
+                                                  {0: "no ESS", 1: "block ESS", 2: "Chebyshev distance-map ESS", 3: "anisotropic Chebyshev distance-map ESS"}[skip]
+                                                  + (" + ERT" if not args.no_ert else ", no ERT")),
                    "parallelism": "screen tiles 16x16 round-robin over %d GPU(s), RCCL gather to %s" % (
-                       world, "rank k mod N for frame k" if rotate else "rank 0") if world > 1 else "1 GPU",
+                       world, "rank k mod N for frame k" if rotate else "rank 0") + (" (vkv_assemble_frame: ncclGather + de-interleave)" if native else " (torch.distributed.gather)")
+                   if world > 1 else "1 GPU",
                    "output": "RGBA8",
                    "submission": ("vkv_render_batch, %d frames per launch" % fpl) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams" % (fif, fif)),
                    "occupied_voxel_percent": round(occupied_voxel_percent(ctx, v, tf), 4)},
@@ -370,7 +401,9 @@ def main():
 
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ctx, sp, v, params, (fw, fh), args.cpu_seconds, args.verify_cpu, out)
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=json_out, flush=True)
+    if native:
+        gather.close()
     if dist is not None:
         dist.destroy_process_group()
 

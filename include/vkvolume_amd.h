@@ -297,6 +297,25 @@ int vkv_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, uint3
                       uint32_t image_height, uint32_t tile_width, uint32_t tile_height,
                       uint32_t n_ranks, uint32_t tiles_per_rank, uint32_t bytes_per_pixel, void *stream);
 
+/* ---- multi-GPU exchange step --------------------------------------------------------------------------------
+ * Rays are independent: a frame is cut into screen tiles dealt round-robin to the ranks (VkvTileSchedule: tile_first = rank,
+ * tile_stride = n_ranks, compact = 1), the volume is replicated, and the ONLY exchange is the gather of every rank's compact tile
+ * buffer to the frame's owner, followed by vkv_scatter_tiles there.  One process (or host thread) per GPU, one ncclComm_t each.
+ *
+ * vkv_gather_tiles enqueues that gather on `stream` with RCCL's ncclGather (rccl.h:745; 7 concurrent point-to-point transfers into
+ * the root over xGMI): every rank sends bytes_per_rank bytes from d_tiles, the root receives n_ranks * bytes_per_rank bytes into
+ * d_gathered (ignored elsewhere).  `nccl_comm` is the caller's ncclComm_t.  The RCCL library is resolved at run time: the copy
+ * already loaded into the process if there is one (so the communicator and the call come from the same library), else librccl.so.1;
+ * VKV_RCCL_LIBRARY=<path> overrides.  Returns VKV_E_UNSUPPORTED when no RCCL can be loaded, 1000 + ncclResult_t on RCCL errors. */
+int vkv_gather_tiles(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, size_t bytes_per_rank, int32_t root, void *nccl_comm, void *stream);
+
+/* The whole exchange of one frame on `stream`: vkv_gather_tiles to `root`, then (on the root only) vkv_scatter_tiles of the gathered
+ * buffers into d_image.  d_gathered is scratch of n_ranks * tiles_per_rank * tile_width * tile_height * bytes_per_pixel bytes on the
+ * root; d_image / d_gathered may be NULL on the other ranks. */
+int vkv_assemble_frame(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, void *d_image, uint32_t image_width, uint32_t image_height,
+                       uint32_t tile_width, uint32_t tile_height, uint32_t n_ranks, uint32_t rank, uint32_t tiles_per_rank,
+                       uint32_t bytes_per_pixel, int32_t root, void *nccl_comm, void *stream);
+
 /* Deterministic synthetic uint8 volume, generated on the device. kind 0 = soft
  * sphere (config C1), kind 1 = ellipsoid shells + hash noise (configs C2..C5). */
 int vkv_synth_volume(vkv_ctx *ctx, uint8_t *d_volume, VkvExtent3D extent, uint32_t kind, uint32_t seed, void *stream);

@@ -221,3 +221,46 @@ def test_render_batch_equals_single_launches(ctx, skipping_type):
     bad.options.early_ray_termination = 0
     with pytest.raises(lib.VkvError):
         ctx.render_batch([plist[0], bad], st)
+
+
+def test_native_rccl_gather_and_assemble(ctx):
+    """vkv_assemble_frame: ncclGather on the caller's communicator + de-interleave, through the C ABI (no torch.distributed).
+    One GPU here, so the communicator has one rank (created with the RCCL the process has loaded); the compact tile layout,
+    the gather and the scatter are the N > 1 code path."""
+    import ctypes as C
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid, comm = UniqueId(), C.c_void_p()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        scene = T.OracleScene(O.synth_volume((64, 56, 48), 1, 9), abi.VolumeOptions(**T.APP_TF), 4)
+        v, tf = make_gpu_volume(ctx, scene)
+        V.ComputeDistanceMap(ctx).compute(v, tf, abi.SKIP_DISTANCE)
+        size, tile = (150, 70), 16  # not a multiple of the tile
+        ro = abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0)
+        view, proj = T.orbit(25.0, image_size=size)
+        sp = V.VolumeRenderSubpass(ctx, v, ro, size)
+        sched = abi.full_frame_tiles(size[0], size[1], tile, tile, 0, 1, compact=True)
+        p = sp.make_params(view, proj, sched)
+        n = sched.tile_count * tile * tile
+        mine = torch.zeros((n, 4), dtype=torch.uint8, device="cuda")
+        gathered = torch.full((1, n, 4), 9, dtype=torch.uint8, device="cuda")
+        image = torch.full((size[1], size[0], 4), 5, dtype=torch.uint8, device="cuda")
+        direct = torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        sp.draw(p, rgba8=mine)
+        ctx.assemble_frame(mine.data_ptr(), gathered.data_ptr(), image.data_ptr(), size, (tile, tile), 1, 0, sched.tile_count, 4, 0, comm.value, st)
+        sp.draw(sp.make_params(view, proj), rgba8=direct)
+        torch.cuda.synchronize()
+        assert int(direct.sum().item()) > 0 and torch.equal(image, direct)
+        assert torch.equal(gathered[0], mine)
+        with pytest.raises(lib.VkvError):
+            ctx.assemble_frame(mine.data_ptr(), gathered.data_ptr(), image.data_ptr(), size, (tile, tile), 1, 0, sched.tile_count, 4, 3, comm.value, st)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)

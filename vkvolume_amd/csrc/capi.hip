@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
+#include <mutex>
 #include <new>
 
 #include <algorithm>
@@ -592,6 +594,84 @@ int vkv_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, uint3
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "scatter_tiles: gathered buffer holds fewer tiles than the image");
 	return launch_scatter_tiles(ctx, d_gathered, d_image, image_width, image_height, tile_width, tile_height, n_ranks, tiles_per_rank, bytes_per_pixel,
 	                            (hipStream_t) stream);
+}
+
+// ---- RCCL, resolved at run time (the library is not a link-time dependency of the product) ---------------------------------
+namespace
+{
+typedef int (*nccl_gather_fn)(const void *, void *, size_t, int /* ncclDataType_t */, int, void * /* ncclComm_t */, hipStream_t);
+typedef const char *(*nccl_error_fn)(int);
+struct Rccl
+{
+	void *         handle = nullptr;
+	nccl_gather_fn gather = nullptr;
+	nccl_error_fn  error  = nullptr;
+	bool           tried  = false;
+};
+Rccl       g_rccl;
+std::mutex g_rccl_mutex;
+
+const Rccl &rccl()
+{
+	std::lock_guard<std::mutex> lock(g_rccl_mutex);
+	if (g_rccl.tried)
+		return g_rccl;
+	g_rccl.tried = true;
+	const char *override_path = std::getenv("VKV_RCCL_LIBRARY");
+	void *      h             = nullptr;
+	if (override_path && override_path[0])
+		h = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+	// the copy the process already uses (the application's, or the one inside PyTorch): communicator and call must come from the same library
+	for (const char *name : {"librccl.so.1", "librccl.so"})
+		if (!h)
+			h = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+	for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+		if (!h)
+			h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+	if (h)
+	{
+		g_rccl.handle = h;
+		g_rccl.gather = reinterpret_cast<nccl_gather_fn>(dlsym(h, "ncclGather"));
+		g_rccl.error  = reinterpret_cast<nccl_error_fn>(dlsym(h, "ncclGetErrorString"));
+	}
+	return g_rccl;
+}
+}        // namespace
+
+int vkv_gather_tiles(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, size_t bytes_per_rank, int32_t root, void *nccl_comm, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
+	if (!d_tiles || !nccl_comm || root < 0)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "gather_tiles: null buffer / communicator or negative root");
+	if (bytes_per_rank == 0)
+		return VKV_OK;
+	const Rccl &r = rccl();
+	if (!r.gather)
+		return set_error(ctx, VKV_E_UNSUPPORTED, "gather_tiles: no RCCL library with ncclGather could be loaded (%s)", dlerror() ? dlerror() : "librccl.so.1");
+	const int rc = r.gather(d_tiles, d_gathered, bytes_per_rank, 0 /* ncclInt8 / ncclChar */, root, nccl_comm, (hipStream_t) stream);
+	if (rc != 0)
+		return set_error(ctx, 1000 + rc, "gather_tiles: ncclGather: %s", r.error ? r.error(rc) : "error");
+	return VKV_OK;
+}
+
+int vkv_assemble_frame(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, void *d_image, uint32_t image_width, uint32_t image_height, uint32_t tile_width,
+                       uint32_t tile_height, uint32_t n_ranks, uint32_t rank, uint32_t tiles_per_rank, uint32_t bytes_per_pixel, int32_t root, void *nccl_comm,
+                       void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (n_ranks == 0 || rank >= n_ranks || root < 0 || (uint32_t) root >= n_ranks)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frame: bad rank / root / n_ranks");
+	const bool is_root = rank == (uint32_t) root;
+	if (is_root && (!d_gathered || !d_image))
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frame: the root needs d_gathered and d_image");
+	const size_t bytes_per_rank = (size_t) tiles_per_rank * tile_width * tile_height * bytes_per_pixel;
+	int          rc             = vkv_gather_tiles(ctx, d_tiles, d_gathered, bytes_per_rank, root, nccl_comm, stream);
+	if (rc != VKV_OK || !is_root)
+		return rc;
+	return vkv_scatter_tiles(ctx, d_gathered, d_image, image_width, image_height, tile_width, tile_height, n_ranks, tiles_per_rank, bytes_per_pixel, stream);
 }
 
 int vkv_synth_volume(vkv_ctx *ctx, uint8_t *d_volume, VkvExtent3D extent, uint32_t kind, uint32_t seed, void *stream)

@@ -17,7 +17,7 @@ EXPORTS = [
     "vkv_gradient_map", "vkv_occupancy_map", "vkv_distance_map", "vkv_distance_map_anisotropic",
     "vkv_compute_distance_map", "vkv_render", "vkv_render_batch", "vkv_scatter_tiles", "vkv_synth_volume",
     "vkv_packed_volume_bytes", "vkv_pack_volume", "vkv_transfer_function_bits", "vkv_transfer_function_tables",
-    "vkv_occupied_voxel_count", "vkv_load_header", "vkv_load_data", "vkv_convert_volume",
+    "vkv_occupied_voxel_count", "vkv_load_header", "vkv_load_data", "vkv_convert_volume", "vkv_gather_tiles", "vkv_assemble_frame",
 ]
 
 
@@ -62,6 +62,8 @@ def load():
                                            abi.Extent3D, i32, vp]
     L.vkv_render.argtypes = [vp, P(abi.RenderParams), vp]
     L.vkv_render_batch.argtypes = [vp, P(abi.RenderParams), C.c_uint32, vp]
+    L.vkv_gather_tiles.argtypes = [vp, vp, vp, C.c_size_t, i32, vp, vp]
+    L.vkv_assemble_frame.argtypes = [vp, vp, vp, vp] + [C.c_uint32] * 8 + [i32, vp, vp]
     L.vkv_scatter_tiles.argtypes = [vp, vp, vp, u32, u32, u32, u32, u32, u32, u32, vp]
     L.vkv_synth_volume.argtypes = [vp, vp, abi.Extent3D, u32, u32, vp]
     L.vkv_packed_volume_bytes.argtypes = [abi.Extent3D]
@@ -133,6 +135,15 @@ class Context:
         """vkv_render_batch: several frames (same kernel variant, same tile-schedule size) in one launch."""
         arr = (abi.RenderParams * len(params_list))(*params_list)
         self.check(self._lib.vkv_render_batch(self.handle, arr, len(params_list), stream))
+
+    def gather_tiles(self, d_tiles, d_gathered, bytes_per_rank, root, nccl_comm, stream=0):
+        self.check(self._lib.vkv_gather_tiles(self.handle, d_tiles, d_gathered, bytes_per_rank, root, nccl_comm, stream))
+
+    def assemble_frame(self, d_tiles, d_gathered, d_image, image_size, tile_size, n_ranks, rank, tiles_per_rank, bytes_per_pixel, root, nccl_comm,
+                       stream=0):
+        """vkv_assemble_frame: ncclGather of the compact tile buffers to `root` + de-interleave there, on `stream`."""
+        self.check(self._lib.vkv_assemble_frame(self.handle, d_tiles, d_gathered, d_image, image_size[0], image_size[1], tile_size[0], tile_size[1],
+                                                n_ranks, rank, tiles_per_rank, bytes_per_pixel, root, nccl_comm, stream))
 
     def render_rc(self, params, stream=0):
         """Like render() but returns the status code instead of raising (error-path tests)."""

@@ -64,6 +64,68 @@ class TileGather:
         return self.flat[b] if self.rank == self.roots[b] else None
 
 
+class NativeExchange:
+    """The exchange step through the product's C ABI: ``vkv_assemble_frame`` = ``ncclGather`` (RCCL over xGMI) of the compact tile
+    buffers to the frame's owner + de-interleave there, enqueued on a HIP stream — no torch.distributed on the data path.
+    torch.distributed is only the bootstrap that carries the ncclUniqueId from rank 0 to the others."""
+
+    def __init__(self, ctx, dist, rank, world, frame_size, tile=16, bytes_per_pixel=4, n_buffers=2, any_root=False, rccl_path=None):
+        import ctypes as C
+        import os
+        import torch
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.frame_size, self.tile, self.bpp = frame_size, tile, bytes_per_pixel
+        fw, fh = frame_size
+        self.tiles_x, self.tiles_y = (fw + tile - 1) // tile, (fh + tile - 1) // tile
+        self.total_tiles = self.tiles_x * self.tiles_y
+        self.tiles_per_rank = (self.total_tiles + world - 1) // world
+        self.schedule = abi.full_frame_tiles(fw, fh, tile, tile, rank, world, compact=True)
+        n = self.tiles_per_rank * tile * tile
+        self.buffers = [torch.zeros((n, bytes_per_pixel), dtype=torch.uint8, device="cuda") for _ in range(n_buffers)]
+        own = rank == 0 or any_root
+        self.flat = [torch.zeros((world, n, bytes_per_pixel), dtype=torch.uint8, device="cuda") for _ in range(n_buffers)] if own else None
+        self.images = [torch.zeros((fh, fw, bytes_per_pixel), dtype=torch.uint8, device="cuda") for _ in range(n_buffers)] if own else None
+        self.any_root = any_root
+        # communicator of our own, created with the RCCL copy the process has loaded (the one vkv_gather_tiles resolves)
+        path = rccl_path or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self._rccl = C.CDLL(path)
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+
+        uid = UniqueId()
+        if rank == 0:
+            rc = self._rccl.ncclGetUniqueId(C.byref(uid))
+            if rc != 0:
+                raise RuntimeError("ncclGetUniqueId failed: %d" % rc)
+        blob = [C.string_at(C.byref(uid), 128) if rank == 0 else None]  # all 128 bytes (a c_char array reads as a NUL-terminated string)
+        if world > 1:
+            dist.broadcast_object_list(blob, src=0)
+        C.memmove(C.byref(uid), blob[0], 128)
+        self._comm = C.c_void_p()
+        self._rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        rc = self._rccl.ncclCommInitRank(C.byref(self._comm), world, uid, rank)
+        if rc != 0:
+            raise RuntimeError("ncclCommInitRank failed: %d" % rc)
+
+    my_ray_count = TileGather.my_ray_count
+
+    def assemble(self, b, root, stream):
+        """enqueue gather + de-interleave of buffer b on `stream` (a torch stream); every rank must pass the same root"""
+        if root != 0 and not self.any_root:
+            raise ValueError("NativeExchange was created for rank 0 as the only frame owner")
+        is_root = self.rank == root
+        self.ctx.assemble_frame(self.buffers[b].data_ptr(), self.flat[b].data_ptr() if is_root else None,
+                                self.images[b].data_ptr() if is_root else None, self.frame_size, (self.tile, self.tile), self.world, self.rank,
+                                self.tiles_per_rank, self.bpp, root, self._comm.value, stream.cuda_stream)
+
+    def close(self):
+        if self._comm:
+            self._rccl.ncclCommDestroy.argtypes = [__import__("ctypes").c_void_p]
+            self._rccl.ncclCommDestroy(self._comm)
+            self._comm = None
+
+
 def deinterleave_reference(flat, frame_size, tile, world):
     """numpy statement of vkv_scatter_tiles (tests only): flat[rank, k*tile*tile + ly*tile + lx, c] -> image[y, x, c]."""
     fw, fh = frame_size
