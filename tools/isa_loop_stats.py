@@ -37,6 +37,20 @@ for f in funcs:
     for best in cand:
       seg = ins[best[0]:best[1] + 1]
       c = lambda p: sum(1 for x in seg if x.startswith(p))
-      print("%-70s loop %4d instr: valu %3d (dpp %2d) salu %3d vmem-load %2d vmem-store %2d lds %2d waitcnt %2d branch %2d" % (
-        name[:70], len(seg), c('v_'), sum(1 for x in seg if 'dpp' in x or 'quad_perm' in x), c('s_') - c('s_waitcnt') - c('s_cbranch') - c('s_branch'),
+      # SIMD cycles of the loop's VALU instructions at the issue costs measured by tools/micro/valu_mix.hip (8 waves per SIMD)
+      full = ("v_fma_f32", "v_fmac_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32",
+              "v_xor_b32", "v_mov_b32", "v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_not_b32")
+      cyc = 0.0
+      for x in seg:
+          if not x.startswith("v_"): continue
+          op = x.split()[0]
+          base = op.replace("_e32", "").replace("_e64", "")
+          if "sdwa" in op or "dpp" in x: cyc += 4.2
+          elif base in full: cyc += 2.5
+          elif base in ("v_sqrt_f32", "v_rcp_f32", "v_rsq_f32", "v_exp_f32", "v_log_f32"): cyc += 8.3
+          elif base.startswith("v_pk_"): cyc += 4.3
+          elif base.startswith(("v_mad_u64", "v_mad_i64")): cyc += 8.4
+          else: cyc += 4.2
+      print("%-70s loop %4d instr: valu %3d = %4.0f SIMD cycles (dpp %2d) salu %3d vmem-load %2d vmem-store %2d lds %2d waitcnt %2d branch %2d" % (
+        name[:70], len(seg), c('v_'), cyc, sum(1 for x in seg if 'dpp' in x or 'quad_perm' in x), c('s_') - c('s_waitcnt') - c('s_cbranch') - c('s_branch'),
         c(('global_load', 'buffer_load', 'flat_load')), c(('global_store', 'buffer_store')), c('ds_'), c('s_waitcnt'), c(('s_cbranch', 's_branch'))))

@@ -19,7 +19,10 @@ template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF>
 int launch_lean(const RayMarchArgs &a, hipStream_t s)
 {
 	const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile;
-	hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, LF>), dim3(grid), dim3(256), 0, s, a);
+	const size_t   lds  = (LF & kLeanLut) ? (size_t) a.lut_words * 4 : 0;
+	if ((LF & kLeanLut) && (!a.addr_lut || lds > 48 * 1024))
+		return -103;
+	hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, LF>), dim3(grid), dim3(256), lds, s, a);
 	return (int) hipGetLastError();
 }
 
@@ -36,8 +39,11 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 		}
 		case 1: return launch_lean<SKIP, ERT, GRAD, true, 0>(a, s);
 		case 2: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform>(a, s);
-		case 3: return launch_lean<SKIP, ERT, GRAD, true, kLeanNt>(a, s);
-		case 4: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanNt>(a, s);
+		case 3: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanLut>(a, s);
+		case 4: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanBranch>(a, s);
+		case 5: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanCvt>(a, s);
+		case 6: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanLut | kLeanBranch | kLeanCvt>(a, s);
+		case 7: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanLut | kLeanCvt>(a, s);
 		case 11: return launch_er<SKIP, ERT, GRAD, true, 1, 0>(a, s);
 		case 12: return launch_er<SKIP, ERT, GRAD, true, 2, 0>(a, s);
 		case 14: return launch_er<SKIP, ERT, GRAD, true, 4, 0>(a, s);

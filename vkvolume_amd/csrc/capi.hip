@@ -64,6 +64,54 @@ uint8_t *stream_scratch(vkv_ctx *ctx, hipStream_t stream)
 	return p;
 }
 
+const uint32_t *packed_addr_lut(vkv_ctx *ctx, int W, int H, int D, uint32_t *lut_y, uint32_t *lut_z, uint32_t *words)
+{
+	std::lock_guard<std::mutex> lock(ctx->mutex);
+	for (const auto &t : ctx->addr_luts)
+		if (t.W == W && t.H == H && t.D == D)
+		{
+			*lut_y = t.lut_y, *lut_z = t.lut_z, *words = t.words;
+			return t.d_lut;
+		}
+	// two levels per axis: position inside a macro-brick (32 entries: padded index b & 31) and the macro-brick term (b >> 5)
+	const PackedDims pd  = packed_dims(W, H, D);
+	const uint32_t   nmx = (uint32_t) (W + 1) / 32 + 1, nmy = (uint32_t) (H + 1) / 32 + 1, nmz = (uint32_t) (D + 1) / 32 + 1;
+	const uint32_t   ny = 96 + nmx, nz = (ny + nmy + 1) & ~1u, total = nz + 2 * nmz;
+	std::vector<uint32_t> h(total, 0u);
+	for (uint32_t j = 0; j < 32; ++j)
+	{
+		h[j]      = (((j >> 2) & 7u) << 8) + (j & 3u) * 2u;
+		h[32 + j] = (((j >> 2) & 7u) << 11) + (j & 3u) * 10u;
+		h[64 + j] = (((j >> 2) & 7u) << 14) + (j & 3u) * 50u;
+	}
+	for (uint32_t m = 0; m < nmx; ++m)
+		h[96 + m] = m << 17;
+	for (uint32_t m = 0; m < nmy; ++m)
+		h[ny + m] = (m * (uint32_t) pd.mx) << 17;
+	for (uint32_t m = 0; m < nmz; ++m)
+	{
+		const uint64_t z = ((uint64_t) m * (uint64_t) pd.my * (uint64_t) pd.mx) << 17;
+		h[nz + 2 * m] = (uint32_t) z, h[nz + 2 * m + 1] = (uint32_t) (z >> 32);
+	}
+	uint32_t *d = nullptr;
+	if (hipMalloc((void **) &d, (size_t) total * sizeof(uint32_t)) != hipSuccess)
+		return nullptr;
+	if (hipMemcpy(d, h.data(), (size_t) total * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+	{
+		(void) hipFree(d);
+		return nullptr;
+	}
+	if (ctx->addr_luts.size() >= 32)
+	{
+		(void) hipDeviceSynchronize();
+		(void) hipFree(ctx->addr_luts.front().d_lut);
+		ctx->addr_luts.erase(ctx->addr_luts.begin());
+	}
+	ctx->addr_luts.push_back({W, H, D, ny, nz, total, d});
+	*lut_y = ny, *lut_z = nz, *words = total;
+	return d;
+}
+
 const uint32_t *tile_start_order(vkv_ctx *ctx, uint32_t img_w, uint32_t img_h, uint32_t tile_w, uint32_t tile_h, uint32_t first, uint32_t stride, uint32_t count)
 {
 	if (count < 2)
@@ -158,6 +206,8 @@ void vkv_destroy(vkv_ctx *ctx)
 			(void) hipFree(kv.second);
 		for (auto &t : ctx->tile_orders)
 			(void) hipFree(t.d_order);
+		for (auto &t : ctx->addr_luts)
+			(void) hipFree(t.d_lut);
 	}
 	delete ctx;
 }

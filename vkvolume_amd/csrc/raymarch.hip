@@ -41,7 +41,17 @@ static int launch_one(vkv_ctx *ctx, int sched, RayMarchArgs &a, hipStream_t s)
 	{
 		// ids are dealt round-robin to the XCDs, each XCD walking its own tiles: pad the tile count to a multiple of 8
 		const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile;
-		hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLeanUniform>), dim3(grid), dim3(256), 0, s, a);
+		// the per-axis address tables go to LDS when they fit (volumes up to ~2500 voxels per axis); otherwise the address is computed
+		const size_t lut_bytes = (size_t) a.lut_words * sizeof(uint32_t);
+		bool launched = false;
+		if constexpr (PACKED && GRAD != 2)
+			if (a.addr_lut && lut_bytes <= kMaxLutBytes)
+			{
+				hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLeanDefault | kLeanLut>), dim3(grid), dim3(256), lut_bytes, s, a);
+				launched = true;
+			}
+		if (!launched)
+			hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLeanDefault>), dim3(grid), dim3(256), 0, s, a);
 	}
 	return check_launch(ctx, "render");
 }
@@ -115,6 +125,10 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 	a.trace       = reinterpret_cast<unsigned long long *>(ctx->d_trace);
 	a.back        = (int) std::ceil(P->transfer_function.sampling_factor);
 	static const bool in_order = [] { const char *e = std::getenv("VKV_RAYMARCH_TILE_ORDER"); return e && e[0] == 'l'; }();        // "linear": A/B switch
+	a.addr_lut = nullptr, a.lut_y = a.lut_z = a.lut_words = 0;
+	static const bool no_lut = [] { const char *e = std::getenv("VKV_RAYMARCH_LUT"); return e && e[0] == '0'; }();        // A/B switch
+	if (a.packed && !no_lut)
+		a.addr_lut = packed_addr_lut(ctx, a.W, a.H, a.D, &a.lut_y, &a.lut_z, &a.lut_words);
 	a.tile_order  = in_order ? nullptr : tile_start_order(ctx, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count);
 	for (int i = 0; i < 256; ++i)
 		a.alpha_lut[i] = alpha_lut[i];
@@ -147,23 +161,28 @@ int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut
 
 // ---- several frames in one launch --------------------------------------------------------------------------------
 template <int SKIP, bool ERT>
-static void launch_batch_grad(int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, hipStream_t s)
+static void launch_batch_grad(int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, size_t lut_bytes, hipStream_t s)
 {
-	if (grad == 0)
-		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 0, kLeanUniform>), dim3(grid), dim3(256), 0, s, d_frames, n, gpf);
+	// lut_bytes > 0: every frame of the batch has address tables of that size (same volume extent) and they fit the LDS budget
+	if (grad == 0 && lut_bytes)
+		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 0, kLeanDefault | kLeanLut>), dim3(grid), dim3(256), lut_bytes, s, d_frames, n, gpf);
+	else if (grad == 0)
+		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 0, kLeanDefault>), dim3(grid), dim3(256), 0, s, d_frames, n, gpf);
+	else if (grad == 1 && lut_bytes)
+		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 1, kLeanDefault | kLeanLut>), dim3(grid), dim3(256), lut_bytes, s, d_frames, n, gpf);
 	else if (grad == 1)
-		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 1, kLeanUniform>), dim3(grid), dim3(256), 0, s, d_frames, n, gpf);
+		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 1, kLeanDefault>), dim3(grid), dim3(256), 0, s, d_frames, n, gpf);
 	else
-		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 2, kLeanUniform>), dim3(grid), dim3(256), 0, s, d_frames, n, gpf);
+		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 2, kLeanDefault>), dim3(grid), dim3(256), 0, s, d_frames, n, gpf);
 }
 
 template <int SKIP>
-static void launch_batch_ert(bool ert, int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, hipStream_t s)
+static void launch_batch_ert(bool ert, int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, size_t lut_bytes, hipStream_t s)
 {
 	if (ert)
-		launch_batch_grad<SKIP, true>(grad, d_frames, n, grid, gpf, s);
+		launch_batch_grad<SKIP, true>(grad, d_frames, n, grid, gpf, lut_bytes, s);
 	else
-		launch_batch_grad<SKIP, false>(grad, d_frames, n, grid, gpf, s);
+		launch_batch_grad<SKIP, false>(grad, d_frames, n, grid, gpf, lut_bytes, s);
 }
 
 int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, const float *alpha_luts, hipStream_t s)
@@ -200,12 +219,16 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	// switch: measured 0.183 vs 0.169 ms per frame on C3 with 8 frames per launch)
 	static const bool sequential = [] { const char *e = std::getenv("VKV_RAYMARCH_BATCH_ORDER"); return e && e[0] == 's'; }();
 	const uint32_t    gpf        = sequential ? (uint32_t) (grid / n / 8) : 0u;
+	size_t            lut_bytes  = (size_t) host[0].lut_words * sizeof(uint32_t);
+	for (uint32_t i = 0; i < n; ++i)
+		if (!host[i].addr_lut || host[i].lut_words != host[0].lut_words || lut_bytes > kMaxLutBytes)
+			lut_bytes = 0;
 	switch (P[0].options.skipping_type)
 	{
-		case VKV_SKIP_NONE: launch_batch_ert<VKV_SKIP_NONE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, s); break;
-		case VKV_SKIP_BLOCK: launch_batch_ert<VKV_SKIP_BLOCK>(ert, grad, d_frames, n, (uint32_t) grid, gpf, s); break;
-		case VKV_SKIP_DISTANCE: launch_batch_ert<VKV_SKIP_DISTANCE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, s); break;
-		case VKV_SKIP_ANISOTROPIC_DISTANCE: launch_batch_ert<VKV_SKIP_ANISOTROPIC_DISTANCE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, s); break;
+		case VKV_SKIP_NONE: launch_batch_ert<VKV_SKIP_NONE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, lut_bytes, s); break;
+		case VKV_SKIP_BLOCK: launch_batch_ert<VKV_SKIP_BLOCK>(ert, grad, d_frames, n, (uint32_t) grid, gpf, lut_bytes, s); break;
+		case VKV_SKIP_DISTANCE: launch_batch_ert<VKV_SKIP_DISTANCE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, lut_bytes, s); break;
+		case VKV_SKIP_ANISOTROPIC_DISTANCE: launch_batch_ert<VKV_SKIP_ANISOTROPIC_DISTANCE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, lut_bytes, s); break;
 		default: return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: bad skipping_type %d", P[0].options.skipping_type);
 	}
 	return check_launch(ctx, "render_batch");

@@ -55,6 +55,8 @@ struct RayMarchArgs
 	int             test;
 	unsigned long long *trace;      // diagnostic (tools/wave_trace.py): kTraceWords x u64 per wave {t_start, t_end, iterations, unit, phase sums}, or null
 	int             back;           // ceil(sampling_factor): the step back after a probe that found an occupied cell (frag:253)
+	const uint32_t *addr_lut;       // k_raymarch_lean: per-axis byte offsets of the packed image (see addr_lut_words), or null
+	uint32_t        lut_y, lut_z, lut_words;        // word offsets of the y and z tables inside addr_lut and its total length
 	const uint32_t *tile_order;     // k_raymarch_lean: the r-th tile to be started is schedule entry tile_order[r] (centre of the image first), or null
 	uint32_t *      queue_heads;        // persistent scheduler: 8 tile-queue heads (one per XCD label), zeroed per launch
 	float           alpha_lut[256];     // opacity correction keyed by the TF alpha byte (frag:283)
@@ -1312,6 +1314,80 @@ __device__ __forceinline__ int med3_i32(int x, int lo, int hi)
 
 constexpr uint32_t kLeanUniform = 1u;        // wave-uniform branches around the probe-only and the sample-only work
 constexpr uint32_t kLeanNt      = 2u;        // non-temporal footprint loads (leave the caches to the distance map)
+constexpr uint32_t kLeanLut     = 4u;        // footprint address = X[bx] + Y[by] + Z[bz] from per-axis tables in LDS instead of ~20 half-rate bit operations
+constexpr uint32_t kLeanBranch  = 8u;        // state update as EXEC-masked branches instead of selects (a select costs the SIMD 4.3 cycles, a move 2.4)
+constexpr uint32_t kLeanDefault = 1u | 8u | 16u;        // kLeanUniform | kLeanBranch | kLeanCvt: what the product launches (+ kLeanLut when the tables fit)
+constexpr size_t   kMaxLutBytes = 8 * 1024;           // LDS budget of the address tables (1.2 KB at 1024 voxels per axis, 1.9 KB at 2048)
+constexpr uint32_t kLeanCvt     = 16u;       // cost-aware instruction selection (tools/micro/valu_mix.hip): float subtraction of two converted bytes
+                                             // instead of integer subtraction + conversion, fma instead of select in the skip length
+
+__device__ __forceinline__ float cvt_ubyte0(uint32_t q) { float f; asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(q)); return f; }
+__device__ __forceinline__ float cvt_ubyte1(uint32_t q) { float f; asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(q)); return f; }
+__device__ __forceinline__ float cvt_ubyte2(uint32_t q) { float f; asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(q)); return f; }
+__device__ __forceinline__ float cvt_ubyte3(uint32_t q) { float f; asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(q)); return f; }
+
+// packed_filter with every byte converted by v_cvt_f32_ubyteN and the differences taken in float (exact either way: both operands are
+// integers below 256): the compiler's integer-subtract + v_cvt_f32_i32 form costs two half-rate instructions per difference, this one
+// a half-rate conversion and a full-rate subtraction
+template <bool WANT_G>
+__device__ __forceinline__ void packed_filter_cvt(uint32_t q00, uint32_t q10, uint32_t q01, uint32_t q11, float wx, float wy, float wz, float &out_v, float &out_g)
+{
+	{
+		const float b000 = cvt_ubyte0(q00), b100 = cvt_ubyte2(q00), b010 = cvt_ubyte0(q10), b110 = cvt_ubyte2(q10);
+		const float b001 = cvt_ubyte0(q01), b101 = cvt_ubyte2(q01), b011 = cvt_ubyte0(q11), b111 = cvt_ubyte2(q11);
+		const float c00 = __builtin_fmaf(wx, b100 - b000, b000), c10 = __builtin_fmaf(wx, b110 - b010, b010);
+		const float c01 = __builtin_fmaf(wx, b101 - b001, b001), c11 = __builtin_fmaf(wx, b111 - b011, b011);
+		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
+		out_v = __builtin_fmaf(wz, c1 - c0, c0) * kInv255;
+	}
+	if (WANT_G)
+	{
+		const float b000 = cvt_ubyte1(q00), b100 = cvt_ubyte3(q00), b010 = cvt_ubyte1(q10), b110 = cvt_ubyte3(q10);
+		const float b001 = cvt_ubyte1(q01), b101 = cvt_ubyte3(q01), b011 = cvt_ubyte1(q11), b111 = cvt_ubyte3(q11);
+		const float c00 = __builtin_fmaf(wx, b100 - b000, b000), c10 = __builtin_fmaf(wx, b110 - b010, b010);
+		const float c01 = __builtin_fmaf(wx, b101 - b001, b001), c11 = __builtin_fmaf(wx, b111 - b011, b011);
+		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
+		out_g = __builtin_fmaf(wz, c1 - c0, c0) * kInv255;
+	}
+}
+
+// LDS copy of the two-level per-axis address tables (dynamic shared memory of the kernels that use kLeanLut; ~1.5 KB):
+// words [0, 32) x position inside a macro-brick, [32, 64) y, [64, 96) z; then the macro-brick terms: x at word 96, y at A.lut_y,
+// z (64-bit, already an address inside the packed image) at A.lut_z.
+extern __shared__ __align__(16) uint32_t s_addr_lut[];
+constexpr uint32_t kLutXm = 96;
+
+__device__ __forceinline__ void stage_addr_lut(const RayMarchArgs &A)
+{
+	for (uint32_t i = threadIdx.x; i < A.lut_z; i += blockDim.x)
+		s_addr_lut[i] = A.addr_lut[i];
+	const uint64_t base = reinterpret_cast<uint64_t>(A.packed);
+	for (uint32_t i = threadIdx.x; 2 * i + A.lut_z < A.lut_words; i += blockDim.x)
+	{
+		const uint64_t z = (((uint64_t) A.addr_lut[A.lut_z + 2 * i + 1]) << 32 | A.addr_lut[A.lut_z + 2 * i]) + base;
+		s_addr_lut[A.lut_z + 2 * i] = (uint32_t) z, s_addr_lut[A.lut_z + 2 * i + 1] = (uint32_t) (z >> 32);
+	}
+}
+
+// Address of the footprint's first dword from the tables.  bx = clamp(ix, -1, W) + 1 as in packed_footprint, but computed as 4 * bx
+// straight from the float (fma(fx, 4, 4) is exact: fx is a small integer): 4 * bx & 124 is the byte offset into the in-macro table,
+// (4 * bx >> 5) & ~3 the byte offset into the macro table.  Both terms of an axis and the three axes add up to the offset
+// packed_footprint computes with ~20 half-rate shift / mask / multiply instructions; the LDS pipe is otherwise idle in this loop.
+__device__ __forceinline__ const uint8_t *packed_footprint_lut(const RayMarchArgs &A, float px, float py, float pz, float &wx, float &wy, float &wz)
+{
+	const float cx = __builtin_fmaf(px, (float) A.W, -0.5f), cy = __builtin_fmaf(py, (float) A.H, -0.5f), cz = __builtin_fmaf(pz, (float) A.D, -0.5f);
+	const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy), fz = __builtin_floorf(cz);
+	wx = cx - fx, wy = cy - fy, wz = cz - fz;
+	const uint32_t tx = (uint32_t) med3_i32((int) __builtin_fmaf(fx, 4.0f, 4.0f), 0, 4 * (A.W + 1));
+	const uint32_t ty = (uint32_t) med3_i32((int) __builtin_fmaf(fy, 4.0f, 4.0f), 0, 4 * (A.H + 1));
+	const uint32_t tz = (uint32_t) med3_i32((int) __builtin_fmaf(fz, 4.0f, 4.0f), 0, 4 * (A.D + 1));
+	const char *   lut = reinterpret_cast<const char *>(s_addr_lut);
+	const uint32_t xi = *reinterpret_cast<const uint32_t *>(lut + (tx & 124u)), xm = *reinterpret_cast<const uint32_t *>(lut + 4u * kLutXm + ((tx >> 5) & ~3u));
+	const uint32_t yi = *reinterpret_cast<const uint32_t *>(lut + 128u + (ty & 124u)), ym = *reinterpret_cast<const uint32_t *>(lut + 4u * A.lut_y + ((ty >> 5) & ~3u));
+	const uint32_t zi = *reinterpret_cast<const uint32_t *>(lut + 256u + (tz & 124u));
+	const uint64_t zm = *reinterpret_cast<const uint64_t *>(lut + 4u * A.lut_z + ((tz >> 4) & ~7u));
+	return reinterpret_cast<const uint8_t *>(zm + (((xi + xm) + (yi + ym)) + zi));
+}
 
 template <bool NT>
 __device__ __forceinline__ uint32_t load_row(const uint8_t *p)
@@ -1324,7 +1400,8 @@ __device__ __forceinline__ uint32_t load_row(const uint8_t *p)
 template <int SKIP, bool ERT, int GRAD, bool PACKED, bool SEP, uint32_t LF>
 __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const RmLds &L, uint32_t &iter)
 {
-	constexpr bool kUni = (LF & kLeanUniform) != 0, kNt = (LF & kLeanNt) != 0;
+	constexpr bool kUni = (LF & kLeanUniform) != 0, kNt = (LF & kLeanNt) != 0, kLut = (LF & kLeanLut) != 0, kBranch = (LF & kLeanBranch) != 0,
+	               kCvt = (LF & kLeanCvt) != 0;
 	const int   W = A.W, H = A.H, D = A.D;
 	const float kx = SKIP != VKV_SKIP_NONE ? (float) W / A.block_size[0] : 0.0f, ky = SKIP != VKV_SKIP_NONE ? (float) H / A.block_size[1] : 0.0f,
 	            kz = SKIP != VKV_SKIP_NONE ? (float) D / A.block_size[2] : 0.0f;
@@ -1333,6 +1410,8 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	float    grey = 0.0f;
 	uint32_t ul   = 0;
 	bool     occ  = true, done = false;
+	const float sgx = R.six > 0.0f ? 1.0f : -1.0f, sgy = R.siy > 0.0f ? 1.0f : -1.0f, sgz = R.siz > 0.0f ? 1.0f : -1.0f;
+	const float ofx = R.six > 0.0f ? 0.0f : 1.0f, ofy = R.siy > 0.0f ? 0.0f : 1.0f, ofz = R.siz > 0.0f ? 0.0f : 1.0f;
 	while (!done)
 	{
 		const int   i  = R.i;
@@ -1356,7 +1435,8 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			dist = R.dmap[cell];
 		if (kHoist && !probe)
 		{
-			const uint8_t *ba = packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, wx, wy, wz);
+			const uint8_t *ba = kLut ? packed_footprint_lut(A, posx, posy, posz, wx, wy, wz)
+			                         : packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, wx, wy, wz);
 			q00 = load_row<kNt>(ba);
 			q10 = load_row<kNt>(ba + 10);
 			q01 = load_row<kNt>(ba + 50);
@@ -1379,6 +1459,13 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 				ay = (((R.siy < 0.0f) ? 0.0f : 1.0f) + ry) * R.siy;
 				az = (((R.siz < 0.0f) ? 0.0f : 1.0f) + rz) * R.siz;
 			}
+			else if (kCvt)
+			{        // step(0, -s) + sign(s) * dist = fd for s > 0, 1 - fd for s < 0: one fma with per-ray constants (exact: the product is exact)
+				const float fd = (float) dist;
+				ax = (__builtin_fmaf(sgx, fd, ofx) + rx) * R.six;
+				ay = (__builtin_fmaf(sgy, fd, ofy) + ry) * R.siy;
+				az = (__builtin_fmaf(sgz, fd, ofz) + rz) * R.siz;
+			}
 			else
 			{
 				const float fd = (float) dist;
@@ -1399,7 +1486,15 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		float    a = 0.0f, c = 0.0f;
 		if (any_sample)
 		{
-		if (kHoist)
+		if (kHoist && kCvt)
+		{
+			float unused;
+			if (GRAD == 1)
+				packed_filter_cvt<true>(q00, q10, q01, q11, wx, wy, wz, intensity, gradient);
+			else
+				packed_filter_cvt<false>(q00, q10, q01, q11, wx, wy, wz, intensity, unused);
+		}
+		else if (kHoist)
 		{
 			float unused;
 			if (GRAD == 1)
@@ -1470,6 +1565,60 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		}
 		}
 
+		if (kBranch)
+		{        // ---- the frag's state update (frag:224-310) under EXEC: plain moves and adds instead of selects ------------------
+			if (probe)
+			{
+				++R.n_dist;
+				if (dist > 0u)
+					R.i = i + skip;        // frag:244-247
+				else
+				{        // frag:253-261
+					occ = true;
+					ul  = cell;
+					R.i = max(i - A.back, R.i_min);
+				}
+				done = R.i >= R.n_steps;
+			}
+			else
+			{
+				++R.n_vol;
+				occ        = ab > 0u;        // frag:276
+				bool ended = false;
+				if (occ)
+				{
+					if (SKIP != VKV_SKIP_NONE)
+						ul = cell;
+					const float om = 1.0f - R.a;        // frag:287
+					if (SEP)
+						grey = __builtin_fmaf(om, c, grey);
+					else
+					{
+						const float r_ = L.g.unorm[texel & 255u] * a, g_ = L.g.unorm[(texel >> 8) & 255u] * a, b_ = L.g.unorm[(texel >> 16) & 255u] * a;
+						R.r = __builtin_fmaf(om, r_, R.r), R.g = __builtin_fmaf(om, g_, R.g), R.b = __builtin_fmaf(om, b_, R.b);
+					}
+					R.a = __builtin_fmaf(om, a, R.a);
+					if (a > 0.0f)
+						R.first_hit = i;
+					if (ERT && R.a > 0.99f)
+					{        // frag:293-299
+						R.a   = 1.0f;
+						ended = true;
+					}
+				}
+				else
+					++R.n_empty;
+				if (!ended)
+				{
+					R.i     = i + 1;
+					R.i_min = R.i;
+				}
+				done = ended || R.i >= R.n_steps;
+			}
+			if (__builtin_amdgcn_readfirstlane(++iter) == 48u)
+				__builtin_amdgcn_s_setprio(3);
+			continue;
+		}
 		// ---- the frag's state update (frag:224-310) as one block of selects ---------------------------------------------
 		const bool smp    = !probe;
 		const bool p_skip = probe && dist > 0u;        // frag:236-247
@@ -1513,7 +1662,6 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF>
 __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, RmLds &L)
 {
-	const bool     sep = stage_tables_er(A, L);
 	// Hardware deals workgroup ids round-robin over the 8 XCDs (own L2 each).  XCD x = id & 7 marches the schedule's tiles
 	// k = x, x + 8, x + 16, ... one after the other: neighbouring workgroups of an XCD share a tile (L2 locality) while the tiles
 	// of the frame are spread evenly over the XCDs (ESS makes screen regions differ >10x in cost).
@@ -1529,20 +1677,30 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 	const uint32_t k = A.tile_order ? A.tile_order[rank] : rank;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t       px, py, o;
-	if (!block_pixel<1>(A, k * A.blocks_per_tile + sb, wave * 64u + lane, px, py, o))
-		return;
+	const bool     inside = block_pixel<1>(A, k * A.blocks_per_tile + sb, wave * 64u + lane, px, py, o);
 	Ray R;
 	R.o = o;
 	const unsigned long long t_start = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-	const bool marched = ray_setup<SKIP>(A, px, py, R);
-	uint32_t   iter    = 0;
-	if (marched)
+	bool marched = false;
+	if (inside)
+		marched = ray_setup<SKIP>(A, px, py, R);
+	uint32_t iter = 0;
+	// 60 % of the workgroups of a frame hold no ray that enters the volume: they skip the LDS tables (and their barrier) altogether
+	if (__syncthreads_or(marched ? 1 : 0))
 	{
-		if (sep)
-			lean_march<SKIP, ERT, GRAD, PACKED, true, LF>(A, R, L, iter);
-		else
-			lean_march<SKIP, ERT, GRAD, PACKED, false, LF>(A, R, L, iter);
+		if ((LF & kLeanLut) != 0 && PACKED && GRAD != 2)
+			stage_addr_lut(A);        // before the barrier of stage_tables_er
+		const bool sep = stage_tables_er(A, L);
+		if (marched)
+		{
+			if (sep)
+				lean_march<SKIP, ERT, GRAD, PACKED, true, LF>(A, R, L, iter);
+			else
+				lean_march<SKIP, ERT, GRAD, PACKED, false, LF>(A, R, L, iter);
+		}
 	}
+	if (!inside)
+		return;
 	ray_finish(A, R, marched);
 	if (A.trace)
 	{        // diagnostic only: per-wave timeline (100 MHz clock); the values never feed an output

@@ -138,6 +138,14 @@ struct vkv_ctx
 		uint32_t *d_order;
 	};
 	std::vector<TileOrder> tile_orders;
+	// per-axis address tables of the packed sampling image, per volume extent (immutable device arrays)
+	struct AddrLut
+	{
+		int       W, H, D;
+		uint32_t  lut_y, lut_z, words;
+		uint32_t *d_lut;
+	};
+	std::vector<AddrLut> addr_luts;
 };
 
 namespace vkv
@@ -148,6 +156,11 @@ int  check_launch(vkv_ctx *ctx, const char *what);
 uint8_t *stream_scratch(vkv_ctx *ctx, hipStream_t stream);
 // start order of a tile schedule: entry indices sorted by the distance of the tile's centre from the image centre (device array of
 // `count` uint32, cached per schedule shape); nullptr when the table cannot be allocated (the kernel then takes the tiles in order)
+// Per-axis byte offsets of the packed sampling image: the offset of the footprint whose padded base texel is (bx, by, bz) is
+// X(bx) + Y(by) + Z(bz) (the brick index and the position inside the brick are sums of per-axis terms), each in two levels:
+// in-macro-brick term of b & 31 + macro-brick term of b >> 5.  Layout of the device array (uint32 words): in-macro tables of x, y, z
+// at 0, 32, 64; macro terms of x at 96, of y at *lut_y, of z as 64-bit values at *lut_z (even); nullptr if it cannot be allocated.
+const uint32_t *packed_addr_lut(vkv_ctx *ctx, int W, int H, int D, uint32_t *lut_y, uint32_t *lut_z, uint32_t *words);
 const uint32_t *tile_start_order(vkv_ctx *ctx, uint32_t img_w, uint32_t img_h, uint32_t tile_w, uint32_t tile_h, uint32_t first, uint32_t stride, uint32_t count);
 constexpr size_t kScratchBytes     = 32 * 1024;
 constexpr size_t kTfBitsOffset     = 0;           // 256*256 bits = 8 KiB: TF bit table of the map update / the voxel count
