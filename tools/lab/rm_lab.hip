@@ -26,11 +26,29 @@ int launch_lean(const RayMarchArgs &a, hipStream_t s)
 	return (int) hipGetLastError();
 }
 
+template <int SKIP, bool ERT, int GRAD, uint32_t LF, int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_lab_lean_wpb(const RayMarchArgs A)
+{
+	__shared__ RmLds L;
+	lean_block<SKIP, ERT, GRAD, true, LF, WPB>(A, blockIdx.x, L);
+}
+
+template <int SKIP, bool ERT, int GRAD, int WPB>
+int launch_wpb(const RayMarchArgs &a, hipStream_t s)
+{
+	const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile * (4 / WPB);
+	hipLaunchKernelGGL((k_lab_lean_wpb<SKIP, ERT, GRAD, kLeanDefault | kLeanLut, WPB>), dim3(grid), dim3(WPB * 64), (size_t) a.lut_words * 4, s, a);
+	return (int) hipGetLastError();
+}
+
 template <int SKIP, bool ERT, int GRAD>
 int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 {
 	switch (variant)
 	{
+		case 102: return launch_wpb<SKIP, ERT, GRAD, 2>(a, s);
+		case 101: return launch_wpb<SKIP, ERT, GRAD, 1>(a, s);
+		case 104: return launch_wpb<SKIP, ERT, GRAD, 4>(a, s);
 		case 9:        // the round 1 kernel (divergent probe / sample branches, texel fetch from memory)
 		{
 			const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile;

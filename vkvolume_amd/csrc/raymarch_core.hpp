@@ -1659,13 +1659,15 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 }
 
 // the body of one workgroup: 16x16 pixels of the frame described by A; `bid` is the workgroup's id inside that frame's grid
-template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF>
+template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF, int WPB = 4>
 __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, RmLds &L)
 {
 	// Hardware deals workgroup ids round-robin over the 8 XCDs (own L2 each).  XCD x = id & 7 marches the schedule's tiles
 	// k = x, x + 8, x + 16, ... one after the other: neighbouring workgroups of an XCD share a tile (L2 locality) while the tiles
 	// of the frame are spread evenly over the XCDs (ESS makes screen regions differ >10x in cost).
-	const uint32_t x = bid & 7u, idx = bid >> 3;
+	// WPB = waves per workgroup (4: a workgroup is a 16x16 block; 2 / 1: a half / a quarter of it, its parts stay on one XCD)
+	constexpr uint32_t kParts = 4 / WPB;
+	const uint32_t x = bid & 7u, idx = (bid >> 3) / kParts, part = (bid >> 3) % kParts;
 	const uint32_t rank = (idx / A.blocks_per_tile) * 8u + x, sb = idx % A.blocks_per_tile;
 	if (rank >= A.tile_count)
 		return;
@@ -1677,7 +1679,7 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 	const uint32_t k = A.tile_order ? A.tile_order[rank] : rank;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t       px, py, o;
-	const bool     inside = block_pixel<1>(A, k * A.blocks_per_tile + sb, wave * 64u + lane, px, py, o);
+	const bool     inside = block_pixel<1>(A, k * A.blocks_per_tile + sb, (part * WPB + wave) * 64u + lane, px, py, o);
 	Ray R;
 	R.o = o;
 	const unsigned long long t_start = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -1710,7 +1712,7 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
 		if (lane == (uint32_t) __builtin_ctzll(__ballot(1)))
 		{
-			unsigned long long *rec = A.trace + ((size_t) bid * 4 + wave) * kTraceWords;
+			unsigned long long *rec = A.trace + ((size_t) bid * WPB + wave) * kTraceWords;
 			rec[0] = t_start, rec[1] = t_end, rec[2] = it, rec[3] = ((unsigned long long) __builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (k * A.blocks_per_tile + sb);
 			for (int w = 4; w < kTraceWords; ++w)
 				rec[w] = 0;
