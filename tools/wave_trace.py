@@ -15,7 +15,7 @@ sp = V.VolumeRenderSubpass(ctx, v, abi.RenderOptions(skipping_type=skip, clip_di
 p = sp.make_params(*views[view])
 rgba8 = torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda")
 nblocks = ((p.tiles.tile_count + 7) // 8) * 8
-trace = torch.zeros((nblocks * 4, 4), dtype=torch.int64, device="cuda")
+trace = torch.zeros((nblocks * 4, 10), dtype=torch.int64, device="cuda")  # kTraceWords = 10 per wave
 for _ in range(3): sp.draw(p, rgba8=rgba8)
 torch.cuda.synchronize()
 L = lib.load(); L.vkv_debug_trace.argtypes = [C.c_void_p, C.c_void_p]

@@ -15,7 +15,7 @@ sp = V.VolumeRenderSubpass(ctx, v, abi.RenderOptions(skipping_type=skip, clip_di
 params = [sp.make_params(*vw) for vw in views]
 bufs = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(fif)]
 nblocks = ((params[0].tiles.tile_count + 7) // 8) * 8
-traces = [torch.zeros((nblocks * 4, 4), dtype=torch.int64, device="cuda") for _ in range(n_frames)]
+traces = [torch.zeros((nblocks * 4, 10), dtype=torch.int64, device="cuda") for _ in range(n_frames)]  # kTraceWords = 10 per wave
 streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(fif - 1)]
 L = lib.load(); L.vkv_debug_trace.argtypes = [C.c_void_p, C.c_void_p]
 for k in range(16):
