@@ -794,22 +794,29 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 __global__ void __launch_bounds__(256) k_pack_volume_tiled(const uint8_t *__restrict__ vol, const uint8_t *__restrict__ grad, uint8_t *__restrict__ packed,
                                                            int W, int H, int D, PackedDims pd, uint32_t groups_x)
 {
-	constexpr int kTX = 36, kRows = 81;        // tile: [9][9][36] texels of (v | g << 8); 33 used in x
-	__shared__ uint16_t s_tile[kRows * kTX];
+	// tile: [9][9] rows of (v | g << 8) texels; staged dword column c (voxels 4 * (bx0 - 1 + c) ..) sits at texels 4c .. 4c + 3, so the
+	// padded tile column jx (voxel x = 4 * bx0 - 1 + jx) is texel jx + 3; 36 texels staged, 33 used
+	constexpr int kTX = 40, kRows = 81;
+	__shared__ __align__(8) uint16_t s_tile[kRows * kTX];
 	// x-neighbouring workgroups stage parts of the same 128-byte lines: consecutive groups go to one XCD (own L2)
 	const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
 	const int      bx0 = (int) (bid % groups_x) * 8, by0 = (int) (bid / groups_x) * 2, bz0 = (int) blockIdx.y * 2;
 	const int wd  = W >> 2;
-	// ---- stage: row = (jz, jy) of the padded tile, 9 dwords per row starting one dword left of the tile
+	// ---- stage: row = (jz, jy) of the padded tile, 9 dwords per row starting one dword left of the tile; a lane's (row, column) advance by
+	// constants from one of its three loads to the next (256 = 28 * 9 + 4), so the divisions are done once
 	{
 		constexpr int kIter = (kRows * 9 + 255) / 256;        // 3 x 2 dwords per thread, all in flight before the first LDS store
 		uint32_t      v4[kIter], g4[kIter];
+		const int     row0 = (int) threadIdx.x / 9, c0 = (int) threadIdx.x - row0 * 9;
 #pragma unroll
 		for (int j = 0; j < kIter; ++j)
 		{
-			const int it  = min((int) threadIdx.x + 256 * j, kRows * 9 - 1);
-			const int row = it / 9, c = it - row * 9;
-			const int y = min(max(by0 * 4 + row % 9 - 1, 0), H - 1), z = min(max(bz0 * 4 + row / 9 - 1, 0), D - 1);
+			int row = row0 + 28 * j, c = c0 + 4 * j;
+			if (c >= 9)
+				c -= 9, ++row;
+			row           = min(row, kRows - 1);
+			const int ry = row % 9, rz = row / 9;
+			const int y = min(max(by0 * 4 + ry - 1, 0), H - 1), z = min(max(bz0 * 4 + rz - 1, 0), D - 1);
 			const int dc = min(max(bx0 - 1 + c, 0), wd - 1);
 			const size_t o = ((size_t) z * H + y) * (size_t) W;
 			v4[j]          = reinterpret_cast<const uint32_t *>(vol + o)[dc];
@@ -818,17 +825,14 @@ __global__ void __launch_bounds__(256) k_pack_volume_tiled(const uint8_t *__rest
 #pragma unroll
 		for (int j = 0; j < kIter; ++j)
 		{
-			const int it = (int) threadIdx.x + 256 * j;
-			if (it >= kRows * 9)
+			int row = row0 + 28 * j, c = c0 + 4 * j;
+			if (c >= 9)
+				c -= 9, ++row;
+			if (row >= kRows)
 				break;
-			const int row = it / 9, c = it - row * 9;
-#pragma unroll
-			for (int k = 0; k < 4; ++k)
-			{
-				const int jx = 4 * c - 3 + k;        // padded tile column of voxel x = 4 * (bx0 - 1 + c) + k
-				if (jx >= 0 && jx <= 32)
-					s_tile[row * kTX + jx] = (uint16_t) (((v4[j] >> (8 * k)) & 255u) | (((g4[j] >> (8 * k)) & 255u) << 8));
-			}
+			// bytes (v0 v1 v2 v3), (g0 g1 g2 g3) -> texel pairs (v0 g0 v1 g1), (v2 g2 v3 g3): one byte permute each, one 8-byte LDS store
+			const uint32_t lo = __builtin_amdgcn_perm(g4[j], v4[j], 0x05010400u), hi = __builtin_amdgcn_perm(g4[j], v4[j], 0x07030602u);
+			*reinterpret_cast<uint2 *>(&s_tile[row * kTX + 4 * c]) = make_uint2(lo, hi);
 		}
 	}
 	__syncthreads();
@@ -840,30 +844,36 @@ __global__ void __launch_bounds__(256) k_pack_volume_tiled(const uint8_t *__rest
 			const int row = it / 33, jx = it - row * 33;
 			const int x = bx0 * 4 + jx - 1;
 			if (x < 0)
-				s_tile[row * kTX + jx] = s_tile[row * kTX + 1 - bx0 * 4];
+				s_tile[row * kTX + jx + 3] = s_tile[row * kTX + 3 + 1 - bx0 * 4];
 			else if (x >= W)
-				s_tile[row * kTX + jx] = s_tile[row * kTX + W - bx0 * 4];
+				s_tile[row * kTX + jx + 3] = s_tile[row * kTX + 3 + W - bx0 * 4];
 		}
 		__syncthreads();
 	}
-	// ---- write: 32 bricks x 16 pieces of 16 bytes (a store instruction costs the same per lane whatever its width)
-	for (int it = threadIdx.x; it < 32 * 16; it += 256)
+	// ---- write: 32 bricks x 16 pieces of 16 bytes (a store instruction costs the same per lane whatever its width).  A lane keeps its piece
+	// q of every brick it writes (bricks b, b + 16), so the positions of its eight texels inside a brick's 5^3 block are computed once
+	const int q = (int) threadIdx.x & 15;
+	int       off[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k)
 	{
-		const int b = it >> 4, q = it & 15;
+		const int t = 8 * q + k;        // texel of the 5^3 brick, x fastest; 125..127 are padding
+		const int lx = t % 5, ly = (t / 5) % 5, lz = t / 25;
+		off[k]       = t < 125 ? (lz * 9 + ly) * kTX + lx + 3 : -1;
+	}
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		const int b = ((int) threadIdx.x >> 4) + 16 * j;
 		const int bx = bx0 + (b & 7), by = by0 + ((b >> 3) & 1), bz = bz0 + (b >> 4);
 		if (bx >= pd.bx || by >= pd.by || bz >= pd.bz)
 			continue;
-		uint32_t w[4] = {0, 0, 0, 0};
+		const int base = (((b >> 4) * 4) * 9 + ((b >> 3) & 1) * 4) * kTX + (b & 7) * 4;
+		uint32_t  w[4] = {0, 0, 0, 0};
 #pragma unroll
 		for (int k = 0; k < 8; ++k)
-		{
-			const int t = 8 * q + k;        // texel of the 5^3 brick, x fastest; 125..127 are padding
-			if (t < 125)
-			{
-				const int lx = t % 5, ly = (t / 5) % 5, lz = t / 25;
-				w[k >> 1] |= (uint32_t) s_tile[(((b >> 4) * 4 + lz) * 9 + ((b >> 3) & 1) * 4 + ly) * kTX + (b & 7) * 4 + lx] << (16 * (k & 1));
-			}
-		}
+			if (off[k] >= 0)
+				w[k >> 1] |= (uint32_t) s_tile[base + off[k]] << (16 * (k & 1));
 		reinterpret_cast<uint4 *>(packed + packed_brick_offset(bx, by, bz, pd.mx, pd.my))[q] = make_uint4(w[0], w[1], w[2], w[3]);
 	}
 }
