@@ -1389,12 +1389,17 @@ __device__ __forceinline__ const uint8_t *packed_footprint_lut(const RayMarchArg
 	return reinterpret_cast<const uint8_t *>(zm + (((xi + xm) + (yi + ym)) + zi));
 }
 
+// A footprint address that comes out of the LDS address tables is an integer: tell the compiler it points to global memory, or it emits
+// flat_load (which also counts on lgkmcnt, so every wait for an LDS read would wait for the footprint as well).
+typedef const __attribute__((address_space(1))) u32_align2 *global_row_ptr;
+
 template <bool NT>
 __device__ __forceinline__ uint32_t load_row(const uint8_t *p)
 {
+	global_row_ptr g = (global_row_ptr) (uintptr_t) p;
 	if (NT)
-		return __builtin_nontemporal_load(reinterpret_cast<const u32_align2 *>(p));
-	return *reinterpret_cast<const u32_align2 *>(p);
+		return __builtin_nontemporal_load(g);
+	return *g;
 }
 
 template <int SKIP, bool ERT, int GRAD, bool PACKED, bool SEP, uint32_t LF>
