@@ -336,7 +336,7 @@ def main():
         ms1 = float(np.mean(per_view))
         gb1 = float(np.mean(frame_bytes)) / (ms1 * 1e-3) / 1e9
         single = {"ms_per_launch": round(ms1, 4), "achieved": round(gb1, 2), "frac": round(gb1 / HBM_PEAK_GBS, 5),
-                  "Mray_per_s": round(rays_per_frame_all / ms1 / 1e3, 1),
+                  "Mray_per_s": round(rays_per_frame_all / ms1 / 1e3, 1), "per_view_ms": [round(x, 4) for x in per_view],
                   "note": "one vkv_render launch per frame with nothing else on the GPU: median of 5 per view, mean over the 8 views"}
 
     # whole-job sample rates need every rank's counters
@@ -469,7 +469,13 @@ def cpu_baseline(ctx, sp, v, params, frame, target_seconds, verify_cpu, out):
             n += last[i].counts[sel].shape[0] * last[i].counts[sel].shape[1]
         out["verified_against_cpu"] = {"views": len(params), "pixels": n, "pixel_stride": stride, "what": "3 counters + RGBA8 per pixel, bit-exact"}
         print("verify-cpu ok: %d pixels of %d views match the oracle (counters + RGBA8)" % (n, len(params)), file=sys.stderr)
+    # the same port on ONE thread (SURVEY.md §8d asks for both figures): view 0 on a sparser sample, about two seconds
+    s1 = max(stride, int(math.ceil(math.sqrt(frame[0] * frame[1] / max(rate / cores * 2.0, 1.0)))))
+    t1 = time.perf_counter()
+    r1 = O.render(params[0], vol, grad, tex, maps, n_threads=1, pixel_stride=s1)
+    dt1 = max(time.perf_counter() - t1, 1e-9)
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mray/s", "cores": cores, "kind": "port",
+            "value_1_thread": round(r1.rays / dt1 / 1e6, 5),
             "sample": "oracle/vkv_oracle.c (scalar C port of the shaders, pthreads over scanlines), every %d-th pixel in x and y of the "
                       "same 8 frames, %d pass(es): %d rays in %.1f s" % (stride, passes, rays, dt)}
 
