@@ -37,7 +37,7 @@ struct Args
 	uint32_t    blocksize = 4, skipmode = 2;                             // :71-80
 	bool        gradient_test = false;
 	int         benchmark     = 0;
-	int         frames_in_flight = 3;        // benchmark mode: frames rendered concurrently, like the reference's swap-chain images
+	int         frames_in_flight = 8;        // benchmark mode: frames rendered concurrently (one vkv_render_batch launch), like the reference's swap-chain images
 	std::string dataset;
 	std::string synthetic;
 	float       azimuth = 30.0f, elevation = 20.0f;
@@ -302,11 +302,17 @@ int main(int argc, char **argv)
 				}
 			}
 			const auto t0 = std::chrono::steady_clock::now();
-			for (int f = 0; f < frames; ++f)
-			{
-				dc.stream = streams[f % fif];
-				subpass.draw(benchmark ? targets[f % fif] : target);
+			if (benchmark && volumes.size() == 1 && fif > 1 && fif <= VKV_MAX_BATCH)
+			{        // the frames in flight share one launch
+				for (int f = 0; f < frames; f += fif)
+					subpass.draw_batch(std::vector<RenderTarget>(targets.begin(), targets.begin() + std::min(fif, frames - f)));
 			}
+			else
+				for (int f = 0; f < frames; ++f)
+				{
+					dc.stream = streams[f % fif];
+					subpass.draw(benchmark ? targets[f % fif] : target);
+				}
 			for (int i = 0; i < fif; ++i)
 				(void) hipStreamSynchronize(streams[i]);
 			const double ms = ms_since(t0);

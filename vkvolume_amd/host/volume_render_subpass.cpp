@@ -60,3 +60,22 @@ void VolumeRenderSubpass::draw(const RenderTarget &target, const VkvTileSchedule
 			throw std::runtime_error(std::string("VolumeRenderSubpass::draw: ") + vkv_last_error(dc.ctx));
 	}
 }
+
+void VolumeRenderSubpass::draw_batch(const std::vector<RenderTarget> &targets, const VkvTileSchedule *tiles)
+{
+	if (volumes.size() != 1 || targets.empty() || targets.size() > VKV_MAX_BATCH)
+	{
+		for (const RenderTarget &t : targets)
+			draw(t, tiles);
+		return;
+	}
+	Volume *volume = volumes.front();
+	if (!volume->get_packed_volume())
+		volume->pack(dc);
+	std::vector<VkvRenderParams> params;
+	params.reserve(targets.size());
+	for (const RenderTarget &t : targets)
+		params.push_back(make_params(*volume, t, tiles, t.blend));
+	if (vkv_render_batch(dc.ctx, params.data(), (uint32_t) params.size(), dc.stream) != VKV_OK)
+		throw std::runtime_error(std::string("VolumeRenderSubpass::draw_batch: ") + vkv_last_error(dc.ctx));
+}

@@ -66,6 +66,11 @@ class VolumeRenderSubpass
 	// this launch (null = the whole frame).
 	void draw(const RenderTarget &target, const VkvTileSchedule *tiles = nullptr);
 
+	// Several frames of the same subpass in ONE launch (vkv_render_batch): the reference keeps a few swap-chain images in flight
+	// (per-image command buffers); here their ray-marches share a grid, so the long tail of one frame is covered by the others.
+	// One volume, up to VKV_MAX_BATCH targets with distinct output buffers; falls back to draw() per target otherwise.
+	void draw_batch(const std::vector<RenderTarget> &targets, const VkvTileSchedule *tiles = nullptr);
+
 	// the parameter block of one volume (what draw() binds), exposed for tests / the multi-GPU driver
 	VkvRenderParams make_params(Volume &volume, const RenderTarget &target, const VkvTileSchedule *tiles, bool blend = false) const;
 
