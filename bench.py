@@ -123,8 +123,9 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the timed block of K steps until this much time has been measured")
     ap.add_argument("--frame-owner", default="rotate", choices=["rotate", "rank0"], help="N > 1: rank that assembles frame k: k mod N "
                     "(default; the inbound xGMI links and the de-interleave of consecutive frames are then disjoint) or always rank 0")
-    ap.add_argument("--exchange", default="native", choices=["native", "torch"], help="N > 1: the tile gather through the C ABI (vkv_assemble_frame: "
-                    "ncclGather on a communicator of our own, default) or through torch.distributed.gather")
+    ap.add_argument("--exchange", default="torch", choices=["native", "torch"], help="N > 1: the tile gather through torch.distributed.gather (default: "
+                    "0.170 ms per step in the one-rank pipeline test) or through the C ABI (vkv_gather_tiles / vkv_scatter_tiles: ncclGather on a "
+                    "communicator of our own, no torch.distributed on the data path; 0.190 ms per step in the same test)")
     ap.add_argument("--force-gather", action="store_true", help="exercise the tile gather / de-interleave path with a 1-rank process group")
     ap.add_argument("--verify", action="store_true", help="after timing, check the assembled frame of the last step against a direct render")
     ap.add_argument("--verify-cpu", action="store_true", help="compare the CPU oracle's pixels (counters + RGBA8) with the device's, bit for bit")
@@ -203,7 +204,10 @@ def main():
     torch.cuda.synchronize()
     frame_bytes = [n_vs[i] * 16 + n_ds[i] * 1 + my_rays * B_OUT for i in range(N_VIEWS)]  # algorithmic bytes of one frame (this rank's part)
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(fif - 1)]
-    side = torch.cuda.Stream() if gather else None
+    # the exchange streams get the higher priority: their small kernels (RCCL's gather, the de-interleave) must not queue behind the render
+    # workgroups of the next frames (native exchange with a one-rank group: 0.25 -> 0.19 ms per step)
+    side = torch.cuda.Stream(priority=-1) if gather else None
+    xchg = torch.cuda.Stream(priority=-1) if gather else None  # native exchange: RCCL's gather here, the de-interleave on `side`
     freed = [None] * nbuf
     launches = []  # (start event, stop event, algorithmic bytes) of the timed launches of the last block
 
@@ -264,10 +268,10 @@ def main():
                     gather.start(b, k % world if rotate else 0)
             if gather and native:
                 # gather + de-interleave of frame k on the assembly stream, behind its render: nothing waits on the host
-                side.wait_event(rendered)
-                gather.assemble(b, k % world if rotate else 0, side)
+                xchg.wait_event(rendered)
+                last = gather.assemble(b, k % world if rotate else 0, xchg, side)
                 freed[b] = torch.cuda.Event()
-                freed[b].record(side)
+                freed[b].record(last)
             elif gather:
                 with torch.cuda.stream(side):
                     flat = gather.finish(b)
@@ -288,13 +292,14 @@ def main():
     run(args.warmup, False)
     fence()
     # ---- timed blocks: exactly K steps between two fences, repeated until min_seconds have been measured -----------
-    blocks, kernel_ms, kernel_bytes, kernel_frames = [], [], [], []
+    blocks, kernel_ms, kernel_bytes, kernel_frames, enqueue_times = [], [], [], [], []
     total = 0.0
     while True:
         del launches[:]
         fence()
         t0 = time.perf_counter()
         run(args.steps, True)
+        host_enqueue = time.perf_counter() - t0  # the host's share: how long the loop took to enqueue the block
         fence()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -302,6 +307,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         blocks.append(elapsed)
+        enqueue_times.append(host_enqueue)
         kernel_ms += [e0.elapsed_time(e1) for e0, e1, _, _ in launches]
         kernel_bytes += [b for _, _, b, _ in launches]
         kernel_frames += [n for _, _, _, n in launches]
@@ -361,7 +367,7 @@ def main():
         "metric": "Mray/s", "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "repeats": len(blocks), "ms_per_step_min_max": [round(min(blocks) / args.steps * 1e3, 4), round(max(blocks) / args.steps * 1e3, 4)],
+        "repeats": len(blocks), "host_enqueue_ms_per_step": round(float(np.median(enqueue_times)) / args.steps * 1e3, 4), "ms_per_step_min_max": [round(min(blocks) / args.steps * 1e3, 4), round(max(blocks) / args.steps * 1e3, 4)],
         "config": {"workload": "%s (%s): %dx%dx%d uint8 synthetic shells, %dx%d frame, %s, block 4, TF imin 0.1 imax 1 gmin 0 gmax 0.2, "
                                "8 orbit views" % (args.workload, WORKLOAD_NOTE[args.workload], *extent, fw, fh,
                                                   {0: "no ESS", 1: "block ESS", 2: "Chebyshev distance-map ESS", 3: "anisotropic Chebyshev distance-map ESS"}[skip]

@@ -110,14 +110,29 @@ class NativeExchange:
 
     my_ray_count = TileGather.my_ray_count
 
-    def assemble(self, b, root, stream):
-        """enqueue gather + de-interleave of buffer b on `stream` (a torch stream); every rank must pass the same root"""
+    def assemble(self, b, root, stream, scatter_stream=None):
+        """enqueue gather + de-interleave of buffer b on `stream` (a torch stream); every rank must pass the same root.
+        With ``scatter_stream`` the de-interleave runs there, behind an event recorded after the gather (the gather of the next frame
+        then does not queue behind this frame's de-interleave).  Returns the stream whose completion frees buffer b."""
         if root != 0 and not self.any_root:
             raise ValueError("NativeExchange was created for rank 0 as the only frame owner")
         is_root = self.rank == root
-        self.ctx.assemble_frame(self.buffers[b].data_ptr(), self.flat[b].data_ptr() if is_root else None,
-                                self.images[b].data_ptr() if is_root else None, self.frame_size, (self.tile, self.tile), self.world, self.rank,
-                                self.tiles_per_rank, self.bpp, root, self._comm.value, stream.cuda_stream)
+        if scatter_stream is None:
+            self.ctx.assemble_frame(self.buffers[b].data_ptr(), self.flat[b].data_ptr() if is_root else None,
+                                    self.images[b].data_ptr() if is_root else None, self.frame_size, (self.tile, self.tile), self.world, self.rank,
+                                    self.tiles_per_rank, self.bpp, root, self._comm.value, stream.cuda_stream)
+            return stream
+        import torch
+        self.ctx.gather_tiles(self.buffers[b].data_ptr(), self.flat[b].data_ptr() if is_root else None, self.buffers[b].numel(), root,
+                              self._comm.value, stream.cuda_stream)
+        if not is_root:
+            return stream
+        gathered = torch.cuda.Event()
+        gathered.record(stream)
+        scatter_stream.wait_event(gathered)
+        self.ctx.scatter_tiles(self.flat[b].data_ptr(), self.images[b].data_ptr(), self.frame_size, (self.tile, self.tile), self.world,
+                               self.tiles_per_rank, self.bpp, scatter_stream.cuda_stream)
+        return scatter_stream
 
     def close(self):
         if self._comm:
