@@ -1,5 +1,6 @@
 // rm_lab.hip — experimental instantiations of the ray-march kernels (vkvolume_amd/csrc/raymarch_core.hpp), A/B-ed on the GPU by
 // tools/lab/run_lab.py against the product's vkv_render before a variant moves into the product.  Not part of the product.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 
@@ -19,9 +20,19 @@ template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF>
 int launch_lean(const RayMarchArgs &a, hipStream_t s)
 {
 	const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile;
-	const size_t   lds  = (LF & kLeanLut) ? (size_t) a.lut_words * 4 : 0;
+	size_t         lds  = (LF & kLeanLut) ? (size_t) a.lut_words * 4 : 0;
 	if ((LF & kLeanLut) && (!a.addr_lut || lds > 48 * 1024))
 		return -103;
+	if ((LF & kLeanFull) != 0)
+	{
+		const size_t fb = full_lut_bytes(a.W, a.H, a.D);
+		if (kFullLutWord * 4 + fb > 48 * 1024)
+			return -104;
+		if (kFullLutWord * 4 + fb > sizeof(RmLds))
+			lds = std::max(lds, kFullLutWord * 4 + fb - sizeof(RmLds));
+	}
+	if ((LF & kLeanScalar) != 0 && !map_fits_u24((uint32_t) a.mw, (uint32_t) a.mh, (uint32_t) a.md))
+		return -105;
 	hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, LF>), dim3(grid), dim3(256), lds, s, a);
 	return (int) hipGetLastError();
 }
@@ -46,6 +57,7 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 {
 	switch (variant)
 	{
+#ifdef LAB_ALL
 		case 102: return launch_wpb<SKIP, ERT, GRAD, 2>(a, s);
 		case 101: return launch_wpb<SKIP, ERT, GRAD, 1>(a, s);
 		case 104: return launch_wpb<SKIP, ERT, GRAD, 4>(a, s);
@@ -55,12 +67,20 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 			hipLaunchKernelGGL((k_raymarch_tiles<SKIP, ERT, GRAD, true, 4>), dim3(grid), dim3(256), 0, s, a);
 			return (int) hipGetLastError();
 		}
+#endif
+		case 8: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar>(a, s);
+		case 10: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest>(a, s);
+		case 13: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep>(a, s);
+		case 15: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanFull>(a, s);
+		case 16: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull>(a, s);
+		case 17: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanFull>(a, s);
+		case 6: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanLut | kLeanBranch | kLeanCvt>(a, s);
+#ifdef LAB_ALL
 		case 1: return launch_lean<SKIP, ERT, GRAD, true, 0>(a, s);
 		case 2: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform>(a, s);
 		case 3: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanLut>(a, s);
 		case 4: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanBranch>(a, s);
 		case 5: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanCvt>(a, s);
-		case 6: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanLut | kLeanBranch | kLeanCvt>(a, s);
 		case 7: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanLut | kLeanCvt>(a, s);
 		case 11: return launch_er<SKIP, ERT, GRAD, true, 1, 0>(a, s);
 		case 12: return launch_er<SKIP, ERT, GRAD, true, 2, 0>(a, s);
@@ -81,6 +101,7 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 		case 31: return launch_er<SKIP, ERT, GRAD, true, 1, kErStamp>(a, s);
 		case 32: return launch_er<SKIP, ERT, GRAD, true, 2, kErStamp>(a, s);
 		case 34: return launch_er<SKIP, ERT, GRAD, true, 4, kErStamp>(a, s);
+#endif
 		default: return -100;
 	}
 }

@@ -54,6 +54,28 @@ KERNEL(k_ceil, U8("v_ceil_f32"))
 KERNEL(k_fmac, L8("v_fmac_f32"))
 KERNEL(k_sqrt, U8("v_sqrt_f32"))
 KERNEL(k_rcp, U8("v_rcp_f32"))
+#define KERNEL64(NAME, ASM)                                                                                                   \
+	__global__ void __launch_bounds__(256) NAME(float *out, int iters)                                                        \
+	{                                                                                                                         \
+		double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7, b = 1.5; \
+		for (int i = 0; i < iters; ++i)                                                                                       \
+		{                                                                                                                     \
+			_Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile(ASM : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b)); \
+		}                                                                                                                     \
+		out[blockIdx.x * 256 + threadIdx.x] = (float) (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);                                \
+	}
+KERNEL64(k_pk_fma, T8("v_pk_fma_f32"))
+KERNEL64(k_pk_add, L8("v_pk_add_f32"))
+KERNEL64(k_pk_mul, L8("v_pk_mul_f32"))
+KERNEL64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %8\n\tv_lshl_add_u64 %1, %1, 0, %8\n\tv_lshl_add_u64 %2, %2, 0, %8\n\tv_lshl_add_u64 %3, %3, 0, %8\n\tv_lshl_add_u64 %4, %4, 0, %8\n\tv_lshl_add_u64 %5, %5, 0, %8\n\tv_lshl_add_u64 %6, %6, 0, %8\n\tv_lshl_add_u64 %7, %7, 0, %8")
+KERNEL(k_perm, T8("v_perm_b32"))
+KERNEL(k_trunc, U8("v_trunc_f32"))
+KERNEL(k_fract, U8("v_fract_f32"))
+KERNEL(k_rndne, U8("v_rndne_f32"))
+KERNEL(k_min_u32, L8("v_min_u32"))
+KERNEL(k_cvt_u32_f32, U8("v_cvt_u32_f32"))
+KERNEL(k_fmamk, "v_fmamk_f32 %0, %0, 0x41000000, %8\n\tv_fmamk_f32 %1, %1, 0x41000000, %8\n\tv_fmamk_f32 %2, %2, 0x41000000, %8\n\tv_fmamk_f32 %3, %3, 0x41000000, %8\n\tv_fmamk_f32 %4, %4, 0x41000000, %8\n\tv_fmamk_f32 %5, %5, 0x41000000, %8\n\tv_fmamk_f32 %6, %6, 0x41000000, %8\n\tv_fmamk_f32 %7, %7, 0x41000000, %8")
+KERNEL(k_mul_lit, "v_mul_f32 %0, 0x3b808081, %0\n\tv_mul_f32 %1, 0x3b808081, %1\n\tv_mul_f32 %2, 0x3b808081, %2\n\tv_mul_f32 %3, 0x3b808081, %3\n\tv_mul_f32 %4, 0x3b808081, %4\n\tv_mul_f32 %5, 0x3b808081, %5\n\tv_mul_f32 %6, 0x3b808081, %6\n\tv_mul_f32 %7, 0x3b808081, %7")
 int main()
 {
 	float *out;
@@ -68,7 +90,10 @@ int main()
 		{"v_mad_u32_u24", k_mad_u32_u24}, {"v_mul_lo_u32", k_mul_lo_u32}, {"v_bfe_u32", k_bfe}, {"v_lshl_or_b32", k_lshl_or}, {"v_cmp_lt_f32 (vcc)", k_cmp},
 		{"v_sub_u32_sdwa", k_sdwa_sub}, {"v_cndmask_b32 (sgpr mask)", k_cndmask_s}, {"v_cmp_lt_f32 (sgpr dst)", k_cmp_s}, {"v_and_or_b32", k_and_or}, {"v_add3_u32", k_add3},
 		{"v_lshl_add_u32", k_lshl_add}, {"v_min_f32", k_min_f32}, {"v_max_f32", k_max_f32}, {"v_or_b32", k_or_b32}, {"v_xor_b32", k_xor_b32}, {"v_sub_u32", k_sub_u32},
-		{"v_mul_u32_u24", k_mul_u32_u24}, {"v_ceil_f32", k_ceil}, {"v_fmac_f32", k_fmac}, {"v_sqrt_f32", k_sqrt}, {"v_rcp_f32", k_rcp}};
+		{"v_mul_u32_u24", k_mul_u32_u24}, {"v_ceil_f32", k_ceil}, {"v_fmac_f32", k_fmac}, {"v_sqrt_f32", k_sqrt}, {"v_rcp_f32", k_rcp},
+		{"v_pk_fma_f32", k_pk_fma}, {"v_pk_add_f32", k_pk_add}, {"v_pk_mul_f32", k_pk_mul}, {"v_lshl_add_u64", k_lshl_add_u64}, {"v_perm_b32", k_perm},
+		{"v_trunc_f32", k_trunc}, {"v_fract_f32", k_fract}, {"v_rndne_f32", k_rndne}, {"v_min_u32", k_min_u32}, {"v_cvt_u32_f32", k_cvt_u32_f32},
+		{"v_fmamk_f32 (literal)", k_fmamk}, {"v_mul_f32 (literal)", k_mul_lit}};
 	for (auto &c : cases)
 	{
 		c.k<<<blocks, 256>>>(out, 10);

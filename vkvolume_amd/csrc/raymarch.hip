@@ -1,4 +1,5 @@
 // raymarch.hip — launchers of the ray-march integrator (device code: raymarch_core.hpp).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -13,6 +14,29 @@ enum Scheduler
 	kSchedLean       = 0,        // k_raymarch_lean: one lane per ray, predicated loop body (default)
 	kSchedPersistent = 1         // k_raymarch_persistent: resident waves, ballot + mbcnt lane re-fill (bit-identical, slower)
 };
+
+// The three instantiations of the lean kernel a launch chooses from (raymarch_core.hpp explains the flags):
+constexpr uint32_t kLfPlain = kLeanDefault | kLeanNest | kLeanKeep;        // footprint address worked out in registers: any volume, any map
+constexpr uint32_t kLfLut   = kLfPlain | kLeanScalar | kLeanLut;           // two-level address tables in LDS (volumes up to ~2500 voxels per axis)
+constexpr uint32_t kLfFull  = kLfLut | kLeanFull;                          // + one entry per voxel index with the separable transfer function
+
+struct LeanChoice
+{
+	int    kind;        // 0 plain, 1 two-level tables, 2 full tables
+	size_t lds;         // dynamic LDS bytes
+};
+
+static LeanChoice choose_lean(const RayMarchArgs &a)
+{
+	const size_t lut_bytes = (size_t) a.lut_words * sizeof(uint32_t);
+	if (!a.packed || !a.addr_lut || lut_bytes > kMaxLutBytes || !map_fits_u24((uint32_t) a.mw, (uint32_t) a.mh, (uint32_t) a.md))
+		return {0, 0};
+	static const bool no_full = [] { const char *e = std::getenv("VKV_RAYMARCH_LUT"); return e && e[0] == '2'; }();        // A/B switch: two-level only
+	const size_t      full_end = kFullLutWord * 4 + full_lut_bytes(a.W, a.H, a.D);        // from the start of RmLds
+	if (!no_full && full_end <= kFullLdsLimit)
+		return {2, std::max(lut_bytes, full_end > sizeof(RmLds) ? full_end - sizeof(RmLds) : (size_t) 0)};
+	return {1, lut_bytes};
+}
 
 template <int SKIP, bool ERT, int GRAD, bool PACKED>
 static int launch_one(vkv_ctx *ctx, int sched, RayMarchArgs &a, hipStream_t s)
@@ -41,17 +65,18 @@ static int launch_one(vkv_ctx *ctx, int sched, RayMarchArgs &a, hipStream_t s)
 	{
 		// ids are dealt round-robin to the XCDs, each XCD walking its own tiles: pad the tile count to a multiple of 8
 		const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile;
-		// the per-axis address tables go to LDS when they fit (volumes up to ~2500 voxels per axis); otherwise the address is computed
-		const size_t lut_bytes = (size_t) a.lut_words * sizeof(uint32_t);
 		bool launched = false;
 		if constexpr (PACKED && GRAD != 2)
-			if (a.addr_lut && lut_bytes <= kMaxLutBytes)
-			{
-				hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLeanDefault | kLeanLut>), dim3(grid), dim3(256), lut_bytes, s, a);
-				launched = true;
-			}
+		{
+			const LeanChoice c = choose_lean(a);
+			if (c.kind == 2)
+				hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfFull>), dim3(grid), dim3(256), c.lds, s, a);
+			else if (c.kind == 1)
+				hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfLut>), dim3(grid), dim3(256), c.lds, s, a);
+			launched = c.kind != 0;
+		}
 		if (!launched)
-			hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLeanDefault>), dim3(grid), dim3(256), 0, s, a);
+			hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfPlain>), dim3(grid), dim3(256), 0, s, a);
 	}
 	return check_launch(ctx, "render");
 }
@@ -160,29 +185,40 @@ int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut
 }
 
 // ---- several frames in one launch --------------------------------------------------------------------------------
-template <int SKIP, bool ERT>
-static void launch_batch_grad(int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, size_t lut_bytes, hipStream_t s)
+template <int SKIP, bool ERT, int GRAD>
+static void launch_batch_kind(LeanChoice c, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, hipStream_t s)
 {
-	// lut_bytes > 0: every frame of the batch has address tables of that size (same volume extent) and they fit the LDS budget
-	if (grad == 0 && lut_bytes)
-		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 0, kLeanDefault | kLeanLut>), dim3(grid), dim3(256), lut_bytes, s, d_frames, n, gpf);
-	else if (grad == 0)
-		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 0, kLeanDefault>), dim3(grid), dim3(256), 0, s, d_frames, n, gpf);
-	else if (grad == 1 && lut_bytes)
-		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 1, kLeanDefault | kLeanLut>), dim3(grid), dim3(256), lut_bytes, s, d_frames, n, gpf);
+	if constexpr (GRAD != 2)
+	{
+		if (c.kind == 2)
+			hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfFull>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
+		else if (c.kind == 1)
+			hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfLut>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
+		if (c.kind != 0)
+			return;
+	}
+	hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfPlain>), dim3(grid), dim3(256), 0, s, d_frames, n, gpf);
+}
+
+template <int SKIP, bool ERT>
+static void launch_batch_grad(int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, LeanChoice c, hipStream_t s)
+{
+	// c.kind > 0: every frame of the batch has address tables of that size (same volume extent) and they fit the LDS budget
+	if (grad == 0)
+		launch_batch_kind<SKIP, ERT, 0>(c, d_frames, n, grid, gpf, s);
 	else if (grad == 1)
-		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 1, kLeanDefault>), dim3(grid), dim3(256), 0, s, d_frames, n, gpf);
+		launch_batch_kind<SKIP, ERT, 1>(c, d_frames, n, grid, gpf, s);
 	else
-		hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, 2, kLeanDefault>), dim3(grid), dim3(256), 0, s, d_frames, n, gpf);
+		launch_batch_kind<SKIP, ERT, 2>(c, d_frames, n, grid, gpf, s);
 }
 
 template <int SKIP>
-static void launch_batch_ert(bool ert, int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, size_t lut_bytes, hipStream_t s)
+static void launch_batch_ert(bool ert, int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, LeanChoice c, hipStream_t s)
 {
 	if (ert)
-		launch_batch_grad<SKIP, true>(grad, d_frames, n, grid, gpf, lut_bytes, s);
+		launch_batch_grad<SKIP, true>(grad, d_frames, n, grid, gpf, c, s);
 	else
-		launch_batch_grad<SKIP, false>(grad, d_frames, n, grid, gpf, lut_bytes, s);
+		launch_batch_grad<SKIP, false>(grad, d_frames, n, grid, gpf, c, s);
 }
 
 int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, const float *alpha_luts, hipStream_t s)
@@ -219,16 +255,19 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	// switch: measured 0.183 vs 0.169 ms per frame on C3 with 8 frames per launch)
 	static const bool sequential = [] { const char *e = std::getenv("VKV_RAYMARCH_BATCH_ORDER"); return e && e[0] == 's'; }();
 	const uint32_t    gpf        = sequential ? (uint32_t) (grid / n / 8) : 0u;
-	size_t            lut_bytes  = (size_t) host[0].lut_words * sizeof(uint32_t);
-	for (uint32_t i = 0; i < n; ++i)
-		if (!host[i].addr_lut || host[i].lut_words != host[0].lut_words || lut_bytes > kMaxLutBytes)
-			lut_bytes = 0;
+	LeanChoice        choice     = choose_lean(host[0]);
+	for (uint32_t i = 1; i < n; ++i)
+	{        // one kernel for all frames: the most general choice any of them needs
+		const LeanChoice c = choose_lean(host[i]);
+		if (c.kind != choice.kind || c.lds != choice.lds || host[i].lut_words != host[0].lut_words)
+			choice = {0, 0};
+	}
 	switch (P[0].options.skipping_type)
 	{
-		case VKV_SKIP_NONE: launch_batch_ert<VKV_SKIP_NONE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, lut_bytes, s); break;
-		case VKV_SKIP_BLOCK: launch_batch_ert<VKV_SKIP_BLOCK>(ert, grad, d_frames, n, (uint32_t) grid, gpf, lut_bytes, s); break;
-		case VKV_SKIP_DISTANCE: launch_batch_ert<VKV_SKIP_DISTANCE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, lut_bytes, s); break;
-		case VKV_SKIP_ANISOTROPIC_DISTANCE: launch_batch_ert<VKV_SKIP_ANISOTROPIC_DISTANCE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, lut_bytes, s); break;
+		case VKV_SKIP_NONE: launch_batch_ert<VKV_SKIP_NONE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, s); break;
+		case VKV_SKIP_BLOCK: launch_batch_ert<VKV_SKIP_BLOCK>(ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, s); break;
+		case VKV_SKIP_DISTANCE: launch_batch_ert<VKV_SKIP_DISTANCE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, s); break;
+		case VKV_SKIP_ANISOTROPIC_DISTANCE: launch_batch_ert<VKV_SKIP_ANISOTROPIC_DISTANCE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, s); break;
 		default: return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: bad skipping_type %d", P[0].options.skipping_type);
 	}
 	return check_launch(ctx, "render_batch");

@@ -786,9 +786,14 @@ struct RmLds
 	};
 };
 
+__device__ __forceinline__ bool tf_is_separable(const RayMarchArgs &A)
+{
+	return A.tf_bits != nullptr && (A.tf_bits[kTfFlagWord] & kTfFlagSeparable) != 0u;        // wave-uniform (scalar load)
+}
+
 __device__ __forceinline__ bool stage_tables_er(const RayMarchArgs &A, RmLds &L)
 {
-	const bool sep = A.tf_bits != nullptr && (A.tf_bits[kTfFlagWord] & kTfFlagSeparable) != 0u;        // wave-uniform (scalar load)
+	const bool sep = tf_is_separable(A);
 	for (int i = threadIdx.x; i < 256; i += blockDim.x)
 	{
 		const float a = A.alpha_lut[i];
@@ -1312,10 +1317,38 @@ __device__ __forceinline__ int med3_i32(int x, int lo, int hi)
 	return r;
 }
 
+template <typename T>
+__device__ __forceinline__ T undefined_value()
+{        // whatever the register holds (for values that are never read in the lanes that get them): an empty asm "defines" it, so
+	 // the compiler neither zeroes it nor reasons about an undefined value
+	T x;
+	asm volatile("" : "=v"(x));
+	return x;
+}
+
+__device__ __forceinline__ int clamp0_i32(int x, int hi)
+{        // clamp(x, 0, hi) with a wave-uniform hi kept in a scalar register (no per-iteration v_mov of the bound)
+	int r;
+	asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+	return r;
+}
+
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
+{        // a * b + c for a, b < 2^24 and a wave-uniform b: one half-rate instruction (the compiler picks v_mad_u64_u32 + v_mul_u32_u24 + add)
+	uint32_t r;
+	asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+	return r;
+}
+
 constexpr uint32_t kLeanUniform = 1u;        // wave-uniform branches around the probe-only and the sample-only work
 constexpr uint32_t kLeanNt      = 2u;        // non-temporal footprint loads (leave the caches to the distance map)
 constexpr uint32_t kLeanLut     = 4u;        // footprint address = X[bx] + Y[by] + Z[bz] from per-axis tables in LDS instead of ~20 half-rate bit operations
 constexpr uint32_t kLeanBranch  = 8u;        // state update as EXEC-masked branches instead of selects (a select costs the SIMD 4.3 cycles, a move 2.4)
+constexpr uint32_t kLeanNest    = 32u;       // probe / sample arithmetic inside the state update's EXEC-masked blocks (no ballots, no merge values)
+constexpr uint32_t kLeanKeep    = 64u;       // with kLeanNest: keep the loads ahead of both blocks
+constexpr uint32_t kLeanScalar  = 128u;      // clamp bounds from scalar registers, 24-bit multiply-adds for the cell index (the launcher checks
+                                             // map_fits_u24: z * mh + y and mw below 2^24 — every map with block >= 2 that fits the device)
+constexpr uint32_t kLeanFull    = 256u;      // with kLeanLut and the separable transfer function: one table entry per voxel index and axis
 constexpr uint32_t kLeanDefault = 1u | 8u | 16u;        // kLeanUniform | kLeanBranch | kLeanCvt: what the product launches (+ kLeanLut when the tables fit)
 constexpr size_t   kMaxLutBytes = 8 * 1024;           // LDS budget of the address tables (1.2 KB at 1024 voxels per axis, 1.9 KB at 2048)
 constexpr uint32_t kLeanCvt     = 16u;       // cost-aware instruction selection (tools/micro/valu_mix.hip): float subtraction of two converted bytes
@@ -1373,20 +1406,73 @@ __device__ __forceinline__ void stage_addr_lut(const RayMarchArgs &A)
 // straight from the float (fma(fx, 4, 4) is exact: fx is a small integer): 4 * bx & 124 is the byte offset into the in-macro table,
 // (4 * bx >> 5) & ~3 the byte offset into the macro table.  Both terms of an axis and the three axes add up to the offset
 // packed_footprint computes with ~20 half-rate shift / mask / multiply instructions; the LDS pipe is otherwise idle in this loop.
+template <bool SC>
 __device__ __forceinline__ const uint8_t *packed_footprint_lut(const RayMarchArgs &A, float px, float py, float pz, float &wx, float &wy, float &wz)
 {
 	const float cx = __builtin_fmaf(px, (float) A.W, -0.5f), cy = __builtin_fmaf(py, (float) A.H, -0.5f), cz = __builtin_fmaf(pz, (float) A.D, -0.5f);
 	const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy), fz = __builtin_floorf(cz);
 	wx = cx - fx, wy = cy - fy, wz = cz - fz;
-	const uint32_t tx = (uint32_t) med3_i32((int) __builtin_fmaf(fx, 4.0f, 4.0f), 0, 4 * (A.W + 1));
-	const uint32_t ty = (uint32_t) med3_i32((int) __builtin_fmaf(fy, 4.0f, 4.0f), 0, 4 * (A.H + 1));
-	const uint32_t tz = (uint32_t) med3_i32((int) __builtin_fmaf(fz, 4.0f, 4.0f), 0, 4 * (A.D + 1));
+	const uint32_t tx = (uint32_t) (SC ? clamp0_i32((int) __builtin_fmaf(fx, 4.0f, 4.0f), 4 * (A.W + 1)) : med3_i32((int) __builtin_fmaf(fx, 4.0f, 4.0f), 0, 4 * (A.W + 1)));
+	const uint32_t ty = (uint32_t) (SC ? clamp0_i32((int) __builtin_fmaf(fy, 4.0f, 4.0f), 4 * (A.H + 1)) : med3_i32((int) __builtin_fmaf(fy, 4.0f, 4.0f), 0, 4 * (A.H + 1)));
+	const uint32_t tz = (uint32_t) (SC ? clamp0_i32((int) __builtin_fmaf(fz, 4.0f, 4.0f), 4 * (A.D + 1)) : med3_i32((int) __builtin_fmaf(fz, 4.0f, 4.0f), 0, 4 * (A.D + 1)));
 	const char *   lut = reinterpret_cast<const char *>(s_addr_lut);
 	const uint32_t xi = *reinterpret_cast<const uint32_t *>(lut + (tx & 124u)), xm = *reinterpret_cast<const uint32_t *>(lut + 4u * kLutXm + ((tx >> 5) & ~3u));
 	const uint32_t yi = *reinterpret_cast<const uint32_t *>(lut + 128u + (ty & 124u)), ym = *reinterpret_cast<const uint32_t *>(lut + 4u * A.lut_y + ((ty >> 5) & ~3u));
 	const uint32_t zi = *reinterpret_cast<const uint32_t *>(lut + 256u + (tz & 124u));
 	const uint64_t zm = *reinterpret_cast<const uint64_t *>(lut + 4u * A.lut_z + ((tz >> 4) & ~7u));
 	return reinterpret_cast<const uint8_t *>(zm + (((xi + xm) + (yi + ym)) + zi));
+}
+
+// kLeanFull — one table entry per padded voxel index and axis, so an axis costs one LDS read and no shift / mask / add: X[W + 2] and
+// Y[H + 2] 32-bit byte offsets, Z[D + 2] 64-bit addresses inside the packed image.  Built by the workgroup from the two-level tables
+// (each entry = in-macro term + macro term).  14.6 KB at 1024 x 1024 x 795: too much on top of the transfer-function tables, so they
+// are only used with the separable transfer function, whose tables leave the second half of RmLds (the bit table of the general
+// path) free: the full tables start there and run on into the dynamic segment (which begins where the static one ends).
+constexpr uint32_t kFullLutWord  = 1280;         // = (offsetof(RmLds, s) + sizeof(RmLds::s)) / 4, checked below
+__host__ __device__ __forceinline__ bool map_fits_u24(uint32_t mw, uint32_t mh, uint32_t md) { return (uint64_t) mh * md < (1ull << 24) && mw < (1u << 24); }
+constexpr size_t   kFullLdsLimit = 20 * 1024;        // static + dynamic LDS of a workgroup that still lets 8 workgroups share a CU
+
+__host__ __device__ __forceinline__ size_t full_lut_bytes(int W, int H, int D) { return (size_t) (W + 2 + H + 2 + ((W + H) & 1)) * 4 + (size_t) (D + 2) * 8; }
+
+__device__ __forceinline__ uint32_t *full_lut_base(const RmLds &L) { return const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(&L)) + kFullLutWord; }
+
+__device__ __forceinline__ void stage_full_lut(const RayMarchArgs &A, RmLds &L)
+{
+	static_assert(offsetof(RmLds, s) + sizeof(((RmLds *) nullptr)->s) == kFullLutWord * 4, "full tables start behind the separable TF tables");
+	const uint32_t  nx = (uint32_t) A.W + 2u, ny = (uint32_t) A.H + 2u, nz = (uint32_t) A.D + 2u;
+	uint32_t *      fx = full_lut_base(L), *fy = fx + nx;
+	uint64_t *      fz = reinterpret_cast<uint64_t *>(fx + ((nx + ny + 1u) & ~1u));
+	const uint32_t *g  = A.addr_lut;
+	const uint64_t  base = reinterpret_cast<uint64_t>(A.packed);
+	for (uint32_t b = threadIdx.x; b < nx; b += blockDim.x)
+		fx[b] = g[b & 31u] + g[kLutXm + (b >> 5)];
+	for (uint32_t b = threadIdx.x; b < ny; b += blockDim.x)
+		fy[b] = g[32u + (b & 31u)] + g[A.lut_y + (b >> 5)];
+	for (uint32_t b = threadIdx.x; b < nz; b += blockDim.x)
+		fz[b] = base + ((((uint64_t) g[A.lut_z + 2u * (b >> 5) + 1u]) << 32) | g[A.lut_z + 2u * (b >> 5)]) + g[64u + (b & 31u)];
+}
+
+__device__ __forceinline__ float clamp_m1_f32(float x, float hi)
+{        // clamp(x, -1, hi), hi wave-uniform: the bounds cost no register and no move inside the loop
+	float r;
+	asm("v_med3_f32 %0, %1, -1.0, %2" : "=v"(r) : "v"(x), "s"(hi));
+	return r;
+}
+
+// LDS byte address of X[clamp(ix, -1, W) + 1] straight from the float: fma(clamped floor, 4, 4 + table offset) is exact (small integers)
+__device__ __forceinline__ const uint8_t *packed_footprint_full(const RayMarchArgs &A, const RmLds &L, float px, float py, float pz, float &wx, float &wy, float &wz)
+{
+	const float cx = __builtin_fmaf(px, (float) A.W, -0.5f), cy = __builtin_fmaf(py, (float) A.H, -0.5f), cz = __builtin_fmaf(pz, (float) A.D, -0.5f);
+	const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy), fz = __builtin_floorf(cz);
+	wx = cx - fx, wy = cy - fy, wz = cz - fz;
+	const int      oy = 4 * (A.W + 2), oz = 4 * (int) (((uint32_t) A.W + 2u + (uint32_t) A.H + 2u + 1u) & ~1u);
+	const int      tx = (int) __builtin_fmaf(clamp_m1_f32(fx, (float) A.W), 4.0f, 4.0f);
+	const int      ty = (int) __builtin_fmaf(clamp_m1_f32(fy, (float) A.H), 4.0f, (float) (oy + 4));
+	const int      tz = (int) __builtin_fmaf(clamp_m1_f32(fz, (float) A.D), 8.0f, (float) (oz + 8));
+	const char *   lut = reinterpret_cast<const char *>(full_lut_base(L));
+	const uint32_t xo = *reinterpret_cast<const uint32_t *>(lut + tx), yo = *reinterpret_cast<const uint32_t *>(lut + ty);
+	const uint64_t zo = *reinterpret_cast<const uint64_t *>(lut + tz);
+	return reinterpret_cast<const uint8_t *>(zo + (xo + yo));
 }
 
 // A footprint address that comes out of the LDS address tables is an integer: tell the compiler it points to global memory, or it emits
@@ -1406,7 +1492,7 @@ template <int SKIP, bool ERT, int GRAD, bool PACKED, bool SEP, uint32_t LF>
 __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const RmLds &L, uint32_t &iter)
 {
 	constexpr bool kUni = (LF & kLeanUniform) != 0, kNt = (LF & kLeanNt) != 0, kLut = (LF & kLeanLut) != 0, kBranch = (LF & kLeanBranch) != 0,
-	               kCvt = (LF & kLeanCvt) != 0;
+	               kCvt = (LF & kLeanCvt) != 0, kNest = (LF & kLeanNest) != 0 && kBranch, kKeep = (LF & kLeanKeep) != 0, kScalar = (LF & kLeanScalar) != 0, kFull = (LF & kLeanFull) != 0 && SEP;
 	const int   W = A.W, H = A.H, D = A.D;
 	const float kx = SKIP != VKV_SKIP_NONE ? (float) W / A.block_size[0] : 0.0f, ky = SKIP != VKV_SKIP_NONE ? (float) H / A.block_size[1] : 0.0f,
 	            kz = SKIP != VKV_SKIP_NONE ? (float) D / A.block_size[2] : 0.0f;
@@ -1428,19 +1514,33 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		if (SKIP != VKV_SKIP_NONE)
 		{        // frag:192, 220-221
 			ux = kx * posx, uy = ky * posy, uz = kz * posz;
-			uix = med3_i32((int) ux, 0, mw1), uiy = med3_i32((int) uy, 0, mh1), uiz = med3_i32((int) uz, 0, md1);
-			cell = __umul24(__umul24((uint32_t) uiz, (uint32_t) A.mh) + (uint32_t) uiy, (uint32_t) A.mw) + (uint32_t) uix;
+			if (kScalar)
+			{
+				uix = clamp0_i32((int) ux, mw1), uiy = clamp0_i32((int) uy, mh1), uiz = clamp0_i32((int) uz, md1);
+				cell = mad_u24(mad_u24((uint32_t) uiz, (uint32_t) A.mh, (uint32_t) uiy), (uint32_t) A.mw, (uint32_t) uix);
+			}
+			else
+			{
+				uix = med3_i32((int) ux, 0, mw1), uiy = med3_i32((int) uy, 0, mh1), uiz = med3_i32((int) uz, 0, md1);
+				cell = __umul24(__umul24((uint32_t) uiz, (uint32_t) A.mh) + (uint32_t) uiy, (uint32_t) A.mw) + (uint32_t) uix;
+			}
 		}
 		const bool probe = SKIP != VKV_SKIP_NONE && !occ && cell != ul;        // frag:224
 
 		// ---- loads: probe byte first, then the footprint of the sampling lanes ----------------------------------------
 		uint32_t dist = 0, q00 = 0, q10 = 0, q01 = 0, q11 = 0;
 		float    wx = 0, wy = 0, wz = 0;
+		if (kNest)
+		{        // every use sits under the predicate of its load: the values of the other lanes are left undefined (no moves)
+			dist = undefined_value<uint32_t>(), q00 = undefined_value<uint32_t>(), q10 = undefined_value<uint32_t>(), q01 = undefined_value<uint32_t>();
+			q11 = undefined_value<uint32_t>(), wx = undefined_value<float>(), wy = undefined_value<float>(), wz = undefined_value<float>();
+		}
 		if (SKIP != VKV_SKIP_NONE && probe)
 			dist = R.dmap[cell];
 		if (kHoist && !probe)
 		{
-			const uint8_t *ba = kLut ? packed_footprint_lut(A, posx, posy, posz, wx, wy, wz)
+			const uint8_t *ba = kFull ? packed_footprint_full(A, L, posx, posy, posz, wx, wy, wz)
+			                    : kLut ? packed_footprint_lut<kScalar>(A, posx, posy, posz, wx, wy, wz)
 			                         : packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, wx, wy, wz);
 			q00 = load_row<kNt>(ba);
 			q10 = load_row<kNt>(ba + 10);
@@ -1448,12 +1548,11 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			q11 = load_row<kNt>(ba + 60);
 		}
 		// a wave whose live lanes all probe (the empty space in front of the volume) or all sample skips the other kind's arithmetic
-		const bool any_probe = !kUni || __ballot(probe) != 0ull, any_sample = !kUni || SKIP == VKV_SKIP_NONE || __ballot(!probe) != 0ull;
+		const bool any_probe = !kUni || kNest || __builtin_amdgcn_ballot_w64(probe) != 0ull, any_sample = !kUni || kNest || SKIP == VKV_SKIP_NONE || __builtin_amdgcn_ballot_w64(!probe) != 0ull;
 
 		// ---- probe outcome (frag:234-247); needs the probe byte only ---------------------------------------------------
 		int skip = 0;
-		if (SKIP != VKV_SKIP_NONE && any_probe)
-		{
+		auto probe_outcome = [&]() {
 			const float rx = __builtin_amdgcn_fmed3f((float) uix - ux, -1.0f, 0.0f);
 			const float ry = __builtin_amdgcn_fmed3f((float) uiy - uy, -1.0f, 0.0f);
 			const float rz = __builtin_amdgcn_fmed3f((float) uiz - uz, -1.0f, 0.0f);
@@ -1483,14 +1582,15 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			float m = __builtin_fminf(__builtin_fminf(ax, ay), az);
 			m       = (m < 1073741824.0f) ? m : 1073741824.0f;
 			skip    = max(1, (int) __builtin_ceilf(m));
-		}
+		};
+		if (SKIP != VKV_SKIP_NONE && !kNest && any_probe)
+			probe_outcome();
 
 		// ---- sample outcome (frag:272-284) ---------------------------------------------------------------------------
 		float    intensity = 0.0f, gradient = 1.0f;
 		uint32_t ab = 0, texel = 0;
 		float    a = 0.0f, c = 0.0f;
-		if (any_sample)
-		{
+		auto sample_outcome = [&]() {
 		if (kHoist && kCvt)
 		{
 			float unused;
@@ -1568,12 +1668,24 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			ab = texel >> 24;
 			a  = L.alpha[ab];
 		}
-		}
+		};
+		if (!kNest && any_sample)
+			sample_outcome();
 
 		if (kBranch)
 		{        // ---- the frag's state update (frag:224-310) under EXEC: plain moves and adds instead of selects ------------------
-			if (probe)
+			bool probe_now = probe;
+			if (kNest && kKeep)
+			{        // the same predicate through a register the compiler cannot see through: otherwise it merges these blocks with the
+				 // load blocks above and the footprint is only requested after the probe outcome has been worked out
+				int pi = probe ? 1 : 0;
+				asm volatile("" : "+v"(pi));
+				probe_now = pi != 0;
+			}
+			if (probe_now)
 			{
+				if (kNest)
+					probe_outcome();        // an empty side is skipped by the branch the compiler puts around it (s_cbranch_execz)
 				++R.n_dist;
 				if (dist > 0u)
 					R.i = i + skip;        // frag:244-247
@@ -1587,6 +1699,8 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			}
 			else
 			{
+				if (kNest)
+					sample_outcome();
 				++R.n_vol;
 				occ        = ab > 0u;        // frag:276
 				bool ended = false;
@@ -1696,7 +1810,12 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 	if (__syncthreads_or(marched ? 1 : 0))
 	{
 		if ((LF & kLeanLut) != 0 && PACKED && GRAD != 2)
-			stage_addr_lut(A);        // before the barrier of stage_tables_er
+		{        // before the barrier of stage_tables_er
+			if ((LF & kLeanFull) != 0 && tf_is_separable(A))
+				stage_full_lut(A, L);
+			else
+				stage_addr_lut(A);
+		}
 		const bool sep = stage_tables_er(A, L);
 		if (marched)
 		{
