@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: grow the frame with N (weak) or keep it (strong); default per workload")
     ap.add_argument("--submit", default=None, choices=["batch", "streams"], help="N = 1: vkv_render_batch launches (default) or single-frame launches "
                     "on --frames-in-flight streams; N > 1 always uses streams")
+    ap.add_argument("--batch-streams", type=int, default=1, help="batch submission: consecutive vkv_render_batch launches alternate over this many HIP streams "
+                    "(the tail of one launch overlaps the head of the next)")
     ap.add_argument("--frames-per-launch", type=int, default=8, help="batch submission: frames per vkv_render_batch launch (1 = one frame per launch)")
     ap.add_argument("--frames-in-flight", type=int, default=3, help="stream submission: consecutive frames render on this many HIP streams")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the timed block of K steps until this much time has been measured")
@@ -191,6 +193,7 @@ def main():
     fif = max(1, args.frames_in_flight)
     fpl = max(1, min(args.frames_per_launch, abi.MAX_BATCH, args.steps))
     gather, images, rotate = None, [], False
+    nbs = max(1, args.batch_streams) if submit == "batch" and not use_gather else 1
     if use_gather:
         nbuf = fif + 1  # one more buffer than render streams: a render does not wait for the gather of the frame fif steps back
         rotate = args.frame_owner == "rotate" and world > 1
@@ -203,11 +206,11 @@ def main():
                 images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
         bufs, my_rays = gather.buffers, gather.my_ray_count()
     else:
-        nbuf = fpl if submit == "batch" else fif
+        nbuf = fpl * nbs if submit == "batch" else fif
         bufs, my_rays = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)], fw * fh
     torch.cuda.synchronize()
     frame_bytes = [n_vs[i] * 16 + n_ds[i] * 1 + my_rays * B_OUT for i in range(N_VIEWS)]  # algorithmic bytes of one frame (this rank's part)
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(fif - 1)]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(max(fif, nbs) - 1)]
     # the exchange streams get the higher priority: their small kernels (RCCL's gather, the de-interleave) must not queue behind the render
     # workgroups of the next frames (native exchange with a one-rank group: 0.25 -> 0.19 ms per step)
     side = torch.cuda.Stream(priority=-1) if gather else None
@@ -229,11 +232,13 @@ def main():
             batch_params.append(row)
 
     def run_batch(n_steps, timed):
-        st = streams[0]
-        k = 0
+        k, launch = 0, 0
         while k < n_steps:
             n = min(fpl, n_steps - k)
-            plist = [batch_params[(k + j) % N_VIEWS][j] for j in range(n)]
+            slot = launch % nbs  # stream and output buffers of this launch
+            st = streams[slot]
+            launch += 1
+            plist = [batch_params[(k + j) % N_VIEWS][slot * fpl + j] for j in range(n)]
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(st)

@@ -73,6 +73,10 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 		case 13: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep>(a, s);
 		case 15: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanFull>(a, s);
 		case 16: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull>(a, s);
+		case 18: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf>(a, s);
+		case 19: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanGradSkip>(a, s);
+		case 20: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb>(a, s);
+		case 21: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI>(a, s);
 		case 17: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanFull>(a, s);
 		case 6: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanLut | kLeanBranch | kLeanCvt>(a, s);
 #ifdef LAB_ALL

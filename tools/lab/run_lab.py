@@ -36,6 +36,15 @@ L.vkv_debug_trace.argtypes = [C.c_void_p, C.c_void_p]
 v, tf, frame, skip = bench.build_scene(ctx, name)
 fw, fh = frame
 views = bench.cameras(v, fw / fh)
+if "--away" in flags:
+    # every camera turned away from the volume: no ray enters it, the launch is ray set-up + pixel write-out only
+    import math
+    from vkvolume_amd import camera as _cam
+    m = (v.node_transform.astype(np.float64).T @ v.image_transform.astype(np.float64).T)[:3, :3]
+    r = 1.5 * 0.5 * math.sqrt(sum(float(np.linalg.norm(m[:, i])) ** 2 for i in range(3)))
+    eyes = [r * np.array([math.cos(math.radians(20.0)) * math.sin(math.radians(45.0 * i)), math.sin(math.radians(20.0)),
+                          math.cos(math.radians(20.0)) * math.cos(math.radians(45.0 * i))]) for i in range(8)]
+    views = [(_cam.look_at(eyes[i], 3.0 * eyes[i]), views[i][1]) for i in range(8)]
 if dense:
     opts = abi.RenderOptions(skipping_type=abi.SKIP_NONE, clip_distance=1.0, early_ray_termination=False)
 else:

@@ -133,6 +133,29 @@ const uint32_t *tile_start_order(vkv_ctx *ctx, uint32_t img_w, uint32_t img_h, u
 	std::vector<uint32_t> order(count);
 	for (uint32_t r = 0; r < count; ++r)
 		order[r] = key[r].second;
+	// experiment (VKV_RAYMARCH_TILE_MIX=<heavy share>,<spread>): the central <heavy share> of the tiles is spread evenly over the first
+	// <spread> of the start order, the remaining (border) tiles fill the gaps and the end
+	static const char *mix_env = std::getenv("VKV_RAYMARCH_TILE_MIX");
+	double mix_heavy = 0.0, mix_spread = 0.0;
+	if (mix_env && std::sscanf(mix_env, "%lf,%lf", &mix_heavy, &mix_spread) == 2 && mix_heavy > 0.0 && mix_heavy < 1.0 && mix_spread >= mix_heavy && mix_spread <= 1.0)
+	{
+		// in groups of eight ranks: rank r runs on XCD r & 7, so a group gives every XCD one tile of the same kind
+		const uint32_t groups = count / 8, nh = (uint32_t) (mix_heavy * groups), span = (uint32_t) (mix_spread * groups);
+		std::vector<uint32_t> mixed;
+		mixed.reserve(count);
+		uint32_t h = 0, l = nh;
+		for (uint32_t r = 0; r < groups; ++r)
+		{
+			// heavy group number h is due at position h * span / nh
+			const bool     take_heavy = h < nh && ((uint64_t) h * span <= (uint64_t) r * nh || l >= groups);
+			const uint32_t g          = take_heavy ? h++ : l++;
+			for (uint32_t j = 0; j < 8; ++j)
+				mixed.push_back(order[g * 8 + j]);
+		}
+		for (uint32_t r = groups * 8; r < count; ++r)
+			mixed.push_back(order[r]);
+		order.swap(mixed);
+	}
 	uint32_t *d = nullptr;
 	if (hipMalloc((void **) &d, (size_t) count * sizeof(uint32_t)) != hipSuccess)
 		return nullptr;

@@ -16,7 +16,7 @@ enum Scheduler
 };
 
 // The three instantiations of the lean kernel a launch chooses from (raymarch_core.hpp explains the flags):
-constexpr uint32_t kLfPlain = kLeanDefault | kLeanNest | kLeanKeep;        // footprint address worked out in registers: any volume, any map
+constexpr uint32_t kLfPlain = kLeanDefault | kLeanNest | kLeanKeep | kLeanTf | kLeanWb | kLeanFloatI;        // footprint address worked out in registers: any volume, any map
 constexpr uint32_t kLfLut   = kLfPlain | kLeanScalar | kLeanLut;           // two-level address tables in LDS (volumes up to ~2500 voxels per axis)
 constexpr uint32_t kLfFull  = kLfLut | kLeanFull;                          // + one entry per voxel index with the separable transfer function
 
@@ -99,6 +99,51 @@ static int launch_ert(vkv_ctx *ctx, int sched, bool ert, int grad, RayMarchArgs 
 	return ert ? launch_grad<SKIP, true, false>(ctx, sched, grad, a, s) : launch_grad<SKIP, false, false>(ctx, sched, grad, a, s);
 }
 
+// Conservative pixel bound of the unit box [0,1]^3 (texture space) as seen through the ray generator of the kernel: pixel (px, py) looks
+// along dir00 + (px + 0.5) ddx + (py + 0.5) ddy from cam, so a corner c is seen at the (fx, fy) with c - cam = g (dir00 + fx ddx + fy ddy),
+// g > 0.  The bound is the min / max over the eight corners, widened by two pixels (the device evaluates the direction in fp32: it can
+// disagree with this double-precision solve by a tiny fraction of a pixel); a corner at or behind the camera plane, or a degenerate
+// generator, disables it.  Pixels outside cannot hit the box, whatever the clip plane or the depth test do afterwards.
+static void screen_bound_of_box(RayMarchArgs &a)
+{
+	a.cull_x0 = 0u, a.cull_x1 = ~0u, a.cull_y0 = 0u, a.cull_y1 = ~0u;
+	static const bool off = [] { const char *e = std::getenv("VKV_RAYMARCH_CULL"); return e && e[0] == '0'; }();        // A/B switch
+	if (off)
+		return;
+	// inverse of M = [ddx ddy dir00] (columns) by the adjugate
+	const double M[3][3] = {{a.ddx[0], a.ddy[0], a.dir00[0]}, {a.ddx[1], a.ddy[1], a.dir00[1]}, {a.ddx[2], a.ddy[2], a.dir00[2]}};
+	double       inv[3][3], scale = 0.0;
+	for (int i = 0; i < 3; ++i)
+		for (int j = 0; j < 3; ++j)
+		{
+			const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+			inv[j][i]    = M[i1][j1] * M[i2][j2] - M[i1][j2] * M[i2][j1];        // cofactor (i, j) -> adjugate (j, i)
+			scale        = std::max(scale, std::fabs(M[i][j]));
+		}
+	const double det = M[0][0] * inv[0][0] + M[0][1] * inv[1][0] + M[0][2] * inv[2][0];
+	if (!std::isfinite(det) || !(std::fabs(det) > 1e-12 * scale * scale * scale))
+		return;
+	double lo_x = 1e300, hi_x = -1e300, lo_y = 1e300, hi_y = -1e300;
+	for (int c = 0; c < 8; ++c)
+	{
+		const double v[3] = {(double) (c & 1) - a.cam[0], (double) ((c >> 1) & 1) - a.cam[1], (double) ((c >> 2) & 1) - a.cam[2]};
+		const double fa = (inv[0][0] * v[0] + inv[0][1] * v[1] + inv[0][2] * v[2]) / det, fb = (inv[1][0] * v[0] + inv[1][1] * v[1] + inv[1][2] * v[2]) / det;
+		const double g  = (inv[2][0] * v[0] + inv[2][1] * v[1] + inv[2][2] * v[2]) / det;
+		if (!(g > 1e-6) || !std::isfinite(fa) || !std::isfinite(fb))
+			return;        // a corner beside or behind the camera: its projection says nothing
+		lo_x = std::min(lo_x, fa / g), hi_x = std::max(hi_x, fa / g), lo_y = std::min(lo_y, fb / g), hi_y = std::max(hi_y, fb / g);
+	}
+	// pixel p is sampled at p + 0.5
+	const double x0 = std::floor(lo_x - 0.5) - 2.0, x1 = std::ceil(hi_x - 0.5) + 2.0, y0 = std::floor(lo_y - 0.5) - 2.0, y1 = std::ceil(hi_y - 0.5) + 2.0;
+	if (x1 < 0.0 || y1 < 0.0 || x0 > 4.0e9 || y0 > 4.0e9)
+	{        // the box is off screen: an empty bound
+		a.cull_x0 = 1u, a.cull_x1 = 0u;
+		return;
+	}
+	a.cull_x0 = x0 <= 0.0 ? 0u : (uint32_t) x0, a.cull_y0 = y0 <= 0.0 ? 0u : (uint32_t) y0;
+	a.cull_x1 = x1 >= 4.0e9 ? ~0u : (uint32_t) x1, a.cull_y1 = y1 >= 4.0e9 ? ~0u : (uint32_t) y1;
+}
+
 // VkvRenderParams -> kernel arguments.  Returns VKV_OK with a.nblocks == 0 when the schedule is empty.
 int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, RayMarchArgs &a)
 {
@@ -154,6 +199,7 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 	static const bool no_lut = [] { const char *e = std::getenv("VKV_RAYMARCH_LUT"); return e && e[0] == '0'; }();        // A/B switch
 	if (a.packed && !no_lut)
 		a.addr_lut = packed_addr_lut(ctx, a.W, a.H, a.D, &a.lut_y, &a.lut_z, &a.lut_words);
+	screen_bound_of_box(a);
 	a.tile_order  = in_order ? nullptr : tile_start_order(ctx, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count);
 	for (int i = 0; i < 256; ++i)
 		a.alpha_lut[i] = alpha_lut[i];

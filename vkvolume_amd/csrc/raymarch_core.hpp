@@ -19,6 +19,8 @@
 //                          (ballot + mbcnt compaction); bit-identical, slower (the re-fill breaks the coherence of a wave)
 #pragma once
 
+#include <type_traits>
+
 #include "vkv_device.hpp"
 
 using namespace vkv;
@@ -57,6 +59,8 @@ struct RayMarchArgs
 	int             back;           // ceil(sampling_factor): the step back after a probe that found an occupied cell (frag:253)
 	const uint32_t *addr_lut;       // k_raymarch_lean: per-axis byte offsets of the packed image (see addr_lut_words), or null
 	uint32_t        lut_y, lut_z, lut_words;        // word offsets of the y and z tables inside addr_lut and its total length
+	uint32_t        cull_x0, cull_x1, cull_y0, cull_y1;        // k_raymarch_lean: pixels outside [x0, x1] x [y0, y1] cannot see the volume's box
+	                                                           // (conservative screen bound from the launcher); 0, ~0, 0, ~0 = no bound
 	const uint32_t *tile_order;     // k_raymarch_lean: the r-th tile to be started is schedule entry tile_order[r] (centre of the image first), or null
 	uint32_t *      queue_heads;        // persistent scheduler: 8 tile-queue heads (one per XCD label), zeroed per launch
 	float           alpha_lut[256];     // opacity correction keyed by the TF alpha byte (frag:283)
@@ -327,6 +331,16 @@ __device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, ui
 	return true;
 }
 
+// the state ray_setup leaves behind for a pixel the volume's box does not cover
+__device__ __forceinline__ void ray_clear(Ray &R)
+{
+	R.r = R.g = R.b = R.a = 0.0f;
+	R.depth = 0.0f;
+	R.n_vol = R.n_dist = R.n_empty = 0;
+	R.n_steps = 0, R.i = 0, R.i_min = 0, R.first_hit = 0, R.ul = 0;
+	R.fragment = false;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // One iteration of the frag's loop (frag:215-312): either one distance-map probe or one volume sample.
 // Returns true when the ray has ended (ran past n_steps, or early ray termination).
@@ -550,6 +564,16 @@ __device__ __forceinline__ void ray_finish(const RayMarchArgs &A, Ray &R, bool m
 		}
 		if (A.depth_attachment)
 			R.depth = A.in_depth[o];
+		// a fresh target gets the clear values (out_color = 0, counters 0: nothing was added to them since ray_setup / ray_clear)
+		if (A.out_color)
+			reinterpret_cast<float4 *>(A.out_color)[o] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (A.out_rgba8)
+			reinterpret_cast<uint32_t *>(A.out_rgba8)[o] = 0u;
+		if (A.out_counts)
+			A.out_counts[o * 3 + 0] = A.out_counts[o * 3 + 1] = A.out_counts[o * 3 + 2] = 0;
+		if (A.out_depth)
+			A.out_depth[o] = R.depth;
+		return;
 	}
 	else if (A.blend)
 	{        // blend state of the subpass (src/volume_render_subpass.cpp:176-190): rgb = src + (1 - src.a) * dst, a = src.a * (1 - src.a)
@@ -780,8 +804,8 @@ struct RmLds
 		} g;
 		struct
 		{
-			float  ai[256], ag[256];
-			float2 pair[256];        // {alpha_lut[b], (b / 255) * alpha_lut[b]}: corrected opacity and premultiplied grey of alpha byte b
+			float  ai[258], ag[258];        // entry 256 repeats entry 255: int(u * 256) of u = 1.0 needs no clamp (kLeanTf)
+			float2 pair[256];               // {alpha_lut[b], (b / 255) * alpha_lut[b]}: corrected opacity and premultiplied grey of alpha byte b
 		} s;
 	};
 };
@@ -802,6 +826,8 @@ __device__ __forceinline__ bool stage_tables_er(const RayMarchArgs &A, RmLds &L)
 		{
 			L.s.ai[i]   = __uint_as_float(A.tf_bits[kTfAiWord + i]);
 			L.s.ag[i]   = __uint_as_float(A.tf_bits[kTfAgWord + i]);
+			if (i == 255)
+				L.s.ai[256] = L.s.ai[255], L.s.ag[256] = L.s.ag[255];
 			L.s.pair[i] = make_float2(a, unorm8(i) * a);
 		}
 		else
@@ -1326,6 +1352,13 @@ __device__ __forceinline__ T undefined_value()
 	return x;
 }
 
+__device__ __forceinline__ float max_f32_raw(float a, float b)
+{        // v_max_f32 without the canonicalisation fmaxf puts in front of it (both operands are ordinary numbers here)
+	float r;
+	asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+
 __device__ __forceinline__ int clamp0_i32(int x, int hi)
 {        // clamp(x, 0, hi) with a wave-uniform hi kept in a scalar register (no per-iteration v_mov of the bound)
 	int r;
@@ -1349,6 +1382,13 @@ constexpr uint32_t kLeanKeep    = 64u;       // with kLeanNest: keep the loads a
 constexpr uint32_t kLeanScalar  = 128u;      // clamp bounds from scalar registers, 24-bit multiply-adds for the cell index (the launcher checks
                                              // map_fits_u24: z * mh + y and mw below 2^24 — every map with block >= 2 that fits the device)
 constexpr uint32_t kLeanFull    = 256u;      // with kLeanLut and the separable transfer function: one table entry per voxel index and axis
+constexpr uint32_t kLeanTf      = 512u;      // separable transfer function: table index int(u * 1024) & ~3 without a clamp (u <= 1: a filter of bytes / 255;
+                                             // the tables have a 257th entry), alpha byte without a clamp (ai, ag <= 1 by construction of the tables)
+constexpr uint32_t kLeanGradSkip = 1024u;    // separable transfer function: the gradient channel is only filtered when some lane's intensity alpha is > 0
+constexpr uint32_t kLeanFloatI  = 2048u;     // the loop position, its bounds and the first hit are kept as floats (exact: n_steps <= 2^24): no int -> float
+                                             // conversion at the head of every iteration, a float max / add for the skip
+constexpr uint32_t kLeanWb      = 4096u;     // kLeanKeep through a wave barrier (a convergent no-op the compiler cannot thread a jump through) instead of
+                                             // a predicate laundered through a register (v_cndmask + v_cmp per iteration)
 constexpr uint32_t kLeanDefault = 1u | 8u | 16u;        // kLeanUniform | kLeanBranch | kLeanCvt: what the product launches (+ kLeanLut when the tables fit)
 constexpr size_t   kMaxLutBytes = 8 * 1024;           // LDS budget of the address tables (1.2 KB at 1024 voxels per axis, 1.9 KB at 2048)
 constexpr uint32_t kLeanCvt     = 16u;       // cost-aware instruction selection (tools/micro/valu_mix.hip): float subtraction of two converted bytes
@@ -1382,6 +1422,17 @@ __device__ __forceinline__ void packed_filter_cvt(uint32_t q00, uint32_t q10, ui
 		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
 		out_g = __builtin_fmaf(wz, c1 - c0, c0) * kInv255;
 	}
+}
+
+// the gradient channel alone (bytes 1 and 3 of the x-pair dwords)
+__device__ __forceinline__ void packed_filter_g(uint32_t q00, uint32_t q10, uint32_t q01, uint32_t q11, float wx, float wy, float wz, float &out_g)
+{
+	const float b000 = cvt_ubyte1(q00), b100 = cvt_ubyte3(q00), b010 = cvt_ubyte1(q10), b110 = cvt_ubyte3(q10);
+	const float b001 = cvt_ubyte1(q01), b101 = cvt_ubyte3(q01), b011 = cvt_ubyte1(q11), b111 = cvt_ubyte3(q11);
+	const float c00 = __builtin_fmaf(wx, b100 - b000, b000), c10 = __builtin_fmaf(wx, b110 - b010, b010);
+	const float c01 = __builtin_fmaf(wx, b101 - b001, b001), c11 = __builtin_fmaf(wx, b111 - b011, b011);
+	const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
+	out_g = __builtin_fmaf(wz, c1 - c0, c0) * kInv255;
 }
 
 // LDS copy of the two-level per-axis address tables (dynamic shared memory of the kernels that use kLeanLut; ~1.5 KB):
@@ -1428,7 +1479,7 @@ __device__ __forceinline__ const uint8_t *packed_footprint_lut(const RayMarchArg
 // (each entry = in-macro term + macro term).  14.6 KB at 1024 x 1024 x 795: too much on top of the transfer-function tables, so they
 // are only used with the separable transfer function, whose tables leave the second half of RmLds (the bit table of the general
 // path) free: the full tables start there and run on into the dynamic segment (which begins where the static one ends).
-constexpr uint32_t kFullLutWord  = 1280;         // = (offsetof(RmLds, s) + sizeof(RmLds::s)) / 4, checked below
+constexpr uint32_t kFullLutWord  = 1284;         // = (offsetof(RmLds, s) + sizeof(RmLds::s)) / 4, checked below
 __host__ __device__ __forceinline__ bool map_fits_u24(uint32_t mw, uint32_t mh, uint32_t md) { return (uint64_t) mh * md < (1ull << 24) && mw < (1u << 24); }
 constexpr size_t   kFullLdsLimit = 20 * 1024;        // static + dynamic LDS of a workgroup that still lets 8 workgroups share a CU
 
@@ -1479,6 +1530,14 @@ __device__ __forceinline__ const uint8_t *packed_footprint_full(const RayMarchAr
 // flat_load (which also counts on lgkmcnt, so every wait for an LDS read would wait for the footprint as well).
 typedef const __attribute__((address_space(1))) u32_align2 *global_row_ptr;
 
+// The distance-map pointer reaches the batch kernel through its argument block in memory, which hides its address space from the
+// compiler: a flat load, which counts on lgkmcnt, so every wait for an address-table read would also wait for the probe byte.
+__device__ __forceinline__ uint32_t load_u8_global(const uint8_t *base, uint32_t index)
+{
+	typedef const __attribute__((address_space(1))) uint8_t *global_u8_ptr;
+	return ((global_u8_ptr) (uintptr_t) base)[index];
+}
+
 template <bool NT>
 __device__ __forceinline__ uint32_t load_row(const uint8_t *p)
 {
@@ -1491,21 +1550,25 @@ __device__ __forceinline__ uint32_t load_row(const uint8_t *p)
 template <int SKIP, bool ERT, int GRAD, bool PACKED, bool SEP, uint32_t LF>
 __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const RmLds &L, uint32_t &iter)
 {
+	constexpr bool kHoist = PACKED && GRAD != 2;
 	constexpr bool kUni = (LF & kLeanUniform) != 0, kNt = (LF & kLeanNt) != 0, kLut = (LF & kLeanLut) != 0, kBranch = (LF & kLeanBranch) != 0,
-	               kCvt = (LF & kLeanCvt) != 0, kNest = (LF & kLeanNest) != 0 && kBranch, kKeep = (LF & kLeanKeep) != 0, kScalar = (LF & kLeanScalar) != 0, kFull = (LF & kLeanFull) != 0 && SEP;
+	               kCvt = (LF & kLeanCvt) != 0, kNest = (LF & kLeanNest) != 0 && kBranch, kKeep = (LF & kLeanKeep) != 0, kScalar = (LF & kLeanScalar) != 0, kFull = (LF & kLeanFull) != 0 && SEP, kTf = (LF & kLeanTf) != 0 && SEP && kHoist && kCvt,
+	               kGradSkip = (LF & kLeanGradSkip) != 0 && kTf && GRAD == 1, kFloatI = (LF & kLeanFloatI) != 0 && kBranch, kWb = (LF & kLeanWb) != 0;
+	using idx_t = std::conditional_t<kFloatI, float, int>;
 	const int   W = A.W, H = A.H, D = A.D;
 	const float kx = SKIP != VKV_SKIP_NONE ? (float) W / A.block_size[0] : 0.0f, ky = SKIP != VKV_SKIP_NONE ? (float) H / A.block_size[1] : 0.0f,
 	            kz = SKIP != VKV_SKIP_NONE ? (float) D / A.block_size[2] : 0.0f;
 	const int   mw1 = A.mw - 1, mh1 = A.mh - 1, md1 = A.md - 1;
-	constexpr bool kHoist = PACKED && GRAD != 2;
 	float    grey = 0.0f;
 	uint32_t ul   = 0;
 	bool     occ  = true, done = false;
 	const float sgx = R.six > 0.0f ? 1.0f : -1.0f, sgy = R.siy > 0.0f ? 1.0f : -1.0f, sgz = R.siz > 0.0f ? 1.0f : -1.0f;
 	const float ofx = R.six > 0.0f ? 0.0f : 1.0f, ofy = R.siy > 0.0f ? 0.0f : 1.0f, ofz = R.siz > 0.0f ? 0.0f : 1.0f;
+	idx_t       li = (idx_t) R.i, li_min = (idx_t) R.i_min, lfirst = (idx_t) R.first_hit;
+	const idx_t ln = (idx_t) R.n_steps, lback = (idx_t) A.back;
 	while (!done)
 	{
-		const int   i  = R.i;
+		const idx_t i  = li;
 		const float fi = (float) i;
 		const float posx = __builtin_fmaf(fi, R.sx, R.ex), posy = __builtin_fmaf(fi, R.sy, R.ey), posz = __builtin_fmaf(fi, R.sz, R.ez);
 		int         uix = 0, uiy = 0, uiz = 0;
@@ -1536,7 +1599,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			q11 = undefined_value<uint32_t>(), wx = undefined_value<float>(), wy = undefined_value<float>(), wz = undefined_value<float>();
 		}
 		if (SKIP != VKV_SKIP_NONE && probe)
-			dist = R.dmap[cell];
+			dist = load_u8_global(R.dmap, cell);
 		if (kHoist && !probe)
 		{
 			const uint8_t *ba = kFull ? packed_footprint_full(A, L, posx, posy, posz, wx, wy, wz)
@@ -1551,8 +1614,8 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		const bool any_probe = !kUni || kNest || __builtin_amdgcn_ballot_w64(probe) != 0ull, any_sample = !kUni || kNest || SKIP == VKV_SKIP_NONE || __builtin_amdgcn_ballot_w64(!probe) != 0ull;
 
 		// ---- probe outcome (frag:234-247); needs the probe byte only ---------------------------------------------------
-		int skip = 0;
-		auto probe_outcome = [&]() {
+		idx_t skip = 0;
+		auto  probe_outcome = [&]() {
 			const float rx = __builtin_amdgcn_fmed3f((float) uix - ux, -1.0f, 0.0f);
 			const float ry = __builtin_amdgcn_fmed3f((float) uiy - uy, -1.0f, 0.0f);
 			const float rz = __builtin_amdgcn_fmed3f((float) uiz - uz, -1.0f, 0.0f);
@@ -1581,7 +1644,10 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			// they were the comparison caps the result exactly as the select chain of the oracle does
 			float m = __builtin_fminf(__builtin_fminf(ax, ay), az);
 			m       = (m < 1073741824.0f) ? m : 1073741824.0f;
-			skip    = max(1, (int) __builtin_ceilf(m));
+			if (kFloatI)
+				skip = (idx_t) __builtin_fmaxf(1.0f, __builtin_ceilf(m));        // a NaN m gives 1 here as (int) NaN = 0 does below
+			else
+				skip = (idx_t) max(1, (int) __builtin_ceilf(m));
 		};
 		if (SKIP != VKV_SKIP_NONE && !kNest && any_probe)
 			probe_outcome();
@@ -1591,6 +1657,29 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		uint32_t ab = 0, texel = 0;
 		float    a = 0.0f, c = 0.0f;
 		auto sample_outcome = [&]() {
+		if (kTf)
+		{        // separable transfer function, table addresses straight from the filtered values
+			const char *ai_tab = reinterpret_cast<const char *>(L.s.ai), *ag_tab = reinterpret_cast<const char *>(L.s.ag);
+			float       g_unused;
+			if (GRAD == 1 && !kGradSkip)
+				packed_filter_cvt<true>(q00, q10, q01, q11, wx, wy, wz, intensity, gradient);
+			else
+				packed_filter_cvt<false>(q00, q10, q01, q11, wx, wy, wz, intensity, g_unused);
+			const float ai = *reinterpret_cast<const float *>(ai_tab + ((uint32_t) (int) (intensity * 1024.0f) & ~3u));
+			float       ag = GRAD == 0 ? L.s.ag[255] : 0.0f;
+			// most samples behind a probe are still empty voxels (intensity below the window): when that holds for every sampling lane of
+			// the wave the gradient channel is not needed (ai == 0 makes the alpha byte 0 whatever ag is)
+			if (GRAD == 1 && (!kGradSkip || __builtin_amdgcn_ballot_w64(ai > 0.0f) != 0ull))
+			{
+				if (kGradSkip)
+					packed_filter_g(q00, q10, q01, q11, wx, wy, wz, gradient);
+				ag = *reinterpret_cast<const float *>(ag_tab + ((uint32_t) (int) (gradient * 1024.0f) & ~3u));
+			}
+			ab              = (uint32_t) ((ai * ag) * 255.0f);        // <= 255: ai, ag <= 1 (k_tf_tables_init)
+			const float2 pr = L.s.pair[ab];
+			a = pr.x, c = pr.y;
+			return;
+		}
 		if (kHoist && kCvt)
 		{
 			float unused;
@@ -1675,7 +1764,9 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		if (kBranch)
 		{        // ---- the frag's state update (frag:224-310) under EXEC: plain moves and adds instead of selects ------------------
 			bool probe_now = probe;
-			if (kNest && kKeep)
+			if (kNest && kKeep && kWb)
+				__builtin_amdgcn_wave_barrier();        // emits nothing; keeps the load blocks above apart from the blocks below
+			else if (kNest && kKeep)
 			{        // the same predicate through a register the compiler cannot see through: otherwise it merges these blocks with the
 				 // load blocks above and the footprint is only requested after the probe outcome has been worked out
 				int pi = probe ? 1 : 0;
@@ -1688,14 +1779,14 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 					probe_outcome();        // an empty side is skipped by the branch the compiler puts around it (s_cbranch_execz)
 				++R.n_dist;
 				if (dist > 0u)
-					R.i = i + skip;        // frag:244-247
+					li = i + skip;        // frag:244-247
 				else
 				{        // frag:253-261
 					occ = true;
 					ul  = cell;
-					R.i = max(i - A.back, R.i_min);
+					li  = kFloatI ? (idx_t) max_f32_raw((float) (i - lback), (float) li_min) : (idx_t) max((int) (i - lback), (int) li_min);
 				}
-				done = R.i >= R.n_steps;
+				done = li >= ln;
 			}
 			else
 			{
@@ -1718,7 +1809,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 					}
 					R.a = __builtin_fmaf(om, a, R.a);
 					if (a > 0.0f)
-						R.first_hit = i;
+						lfirst = i;
 					if (ERT && R.a > 0.99f)
 					{        // frag:293-299
 						R.a   = 1.0f;
@@ -1729,10 +1820,10 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 					++R.n_empty;
 				if (!ended)
 				{
-					R.i     = i + 1;
-					R.i_min = R.i;
+					li     = i + (idx_t) 1;
+					li_min = li;
 				}
-				done = ended || R.i >= R.n_steps;
+				done = ended || li >= ln;
 			}
 			if (__builtin_amdgcn_readfirstlane(++iter) == 48u)
 				__builtin_amdgcn_s_setprio(3);
@@ -1759,20 +1850,21 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		}
 		const bool ended = ERT && hit && na > 0.99f;        // frag:293-299
 		R.a              = hit ? (ended ? 1.0f : na) : R.a;
-		R.first_hit      = (hit && a > 0.0f) ? i : R.first_hit;
+		lfirst           = (hit && a > 0.0f) ? i : lfirst;
 		occ              = smp ? occ_s : (p_occ || occ);
 		if (SKIP != VKV_SKIP_NONE)
 			ul = (hit || p_occ) ? cell : ul;
-		const int jb = max(i - A.back, R.i_min);
-		const int ni = p_skip ? i + skip : (p_occ ? jb : i + 1);
-		R.i_min      = smp ? i + 1 : R.i_min;
-		R.i          = ni;
+		const int jb = max((int) i - A.back, (int) li_min);
+		const int ni = p_skip ? (int) i + (int) skip : (p_occ ? jb : (int) i + 1);
+		li_min       = smp ? (idx_t) ((int) i + 1) : li_min;
+		li           = (idx_t) ni;
 		done         = ended || ni >= R.n_steps;
 		// the frame time is the critical path of the wave with the longest ray: once a wave has run 48 iterations it is one of
 		// those, so let it win instruction arbitration against the younger waves on its SIMD
 		if (__builtin_amdgcn_readfirstlane(++iter) == 48u)
 			__builtin_amdgcn_s_setprio(3);
 	}
+	R.i = (int) li, R.i_min = (int) li_min, R.first_hit = (int) lfirst;
 	if (SEP)
 		R.r = grey, R.g = grey, R.b = grey;
 }
@@ -1804,7 +1896,12 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 	const unsigned long long t_start = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	bool marched = false;
 	if (inside)
-		marched = ray_setup<SKIP>(A, px, py, R);
+	{        // pixels outside the screen bound of the volume's box skip the ray set-up (a third of a C3 frame)
+		if (px >= A.cull_x0 && px <= A.cull_x1 && py >= A.cull_y0 && py <= A.cull_y1)
+			marched = ray_setup<SKIP>(A, px, py, R);
+		else
+			ray_clear(R);
+	}
 	uint32_t iter = 0;
 	// 60 % of the workgroups of a frame hold no ray that enters the volume: they skip the LDS tables (and their barrier) altogether
 	if (__syncthreads_or(marched ? 1 : 0))
