@@ -1510,16 +1510,32 @@ __device__ __forceinline__ float clamp_m1_f32(float x, float hi)
 	return r;
 }
 
-// LDS byte address of X[clamp(ix, -1, W) + 1] straight from the float: fma(clamped floor, 4, 4 + table offset) is exact (small integers)
-__device__ __forceinline__ const uint8_t *packed_footprint_full(const RayMarchArgs &A, const RmLds &L, float px, float py, float pz, float &wx, float &wy, float &wz)
+// Loop-invariant operands of packed_footprint_full, worked out once per ray.  They pass through an empty asm so that the compiler keeps
+// them in registers: in the batch kernel (arguments in memory) it otherwise re-loads W, H, D and converts them again in every iteration.
+struct FullLutConsts
 {
-	const float cx = __builtin_fmaf(px, (float) A.W, -0.5f), cy = __builtin_fmaf(py, (float) A.H, -0.5f), cz = __builtin_fmaf(pz, (float) A.D, -0.5f);
+	float w, h, d, oy, oz;
+};
+
+__device__ __forceinline__ FullLutConsts full_lut_consts(const RayMarchArgs &A)
+{
+	FullLutConsts c;
+	c.w = (float) A.W, c.h = (float) A.H, c.d = (float) A.D;
+	c.oy = (float) (4 * (A.W + 2) + 4);
+	c.oz = (float) (4 * (int) (((uint32_t) A.W + 2u + (uint32_t) A.H + 2u + 1u) & ~1u) + 8);
+	asm volatile("" : "+v"(c.w), "+v"(c.h), "+v"(c.d), "+v"(c.oy), "+v"(c.oz));
+	return c;
+}
+
+// LDS byte address of X[clamp(ix, -1, W) + 1] straight from the float: fma(clamped floor, 4, 4 + table offset) is exact (small integers)
+__device__ __forceinline__ const uint8_t *packed_footprint_full(const FullLutConsts &C, const RmLds &L, float px, float py, float pz, float &wx, float &wy, float &wz)
+{
+	const float cx = __builtin_fmaf(px, C.w, -0.5f), cy = __builtin_fmaf(py, C.h, -0.5f), cz = __builtin_fmaf(pz, C.d, -0.5f);
 	const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy), fz = __builtin_floorf(cz);
 	wx = cx - fx, wy = cy - fy, wz = cz - fz;
-	const int      oy = 4 * (A.W + 2), oz = 4 * (int) (((uint32_t) A.W + 2u + (uint32_t) A.H + 2u + 1u) & ~1u);
-	const int      tx = (int) __builtin_fmaf(clamp_m1_f32(fx, (float) A.W), 4.0f, 4.0f);
-	const int      ty = (int) __builtin_fmaf(clamp_m1_f32(fy, (float) A.H), 4.0f, (float) (oy + 4));
-	const int      tz = (int) __builtin_fmaf(clamp_m1_f32(fz, (float) A.D), 8.0f, (float) (oz + 8));
+	const int      tx = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fx, -1.0f, C.w), 4.0f, 4.0f);
+	const int      ty = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fy, -1.0f, C.h), 4.0f, C.oy);
+	const int      tz = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fz, -1.0f, C.d), 8.0f, C.oz);
 	const char *   lut = reinterpret_cast<const char *>(full_lut_base(L));
 	const uint32_t xo = *reinterpret_cast<const uint32_t *>(lut + tx), yo = *reinterpret_cast<const uint32_t *>(lut + ty);
 	const uint64_t zo = *reinterpret_cast<const uint64_t *>(lut + tz);
@@ -1564,6 +1580,9 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	bool     occ  = true, done = false;
 	const float sgx = R.six > 0.0f ? 1.0f : -1.0f, sgy = R.siy > 0.0f ? 1.0f : -1.0f, sgz = R.siz > 0.0f ? 1.0f : -1.0f;
 	const float ofx = R.six > 0.0f ? 0.0f : 1.0f, ofy = R.siy > 0.0f ? 0.0f : 1.0f, ofz = R.siz > 0.0f ? 0.0f : 1.0f;
+	FullLutConsts fullc = {};
+	if (kFull)
+		fullc = full_lut_consts(A);
 	idx_t       li = (idx_t) R.i, li_min = (idx_t) R.i_min, lfirst = (idx_t) R.first_hit;
 	const idx_t ln = (idx_t) R.n_steps, lback = (idx_t) A.back;
 	while (!done)
@@ -1602,7 +1621,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			dist = load_u8_global(R.dmap, cell);
 		if (kHoist && !probe)
 		{
-			const uint8_t *ba = kFull ? packed_footprint_full(A, L, posx, posy, posz, wx, wy, wz)
+			const uint8_t *ba = kFull ? packed_footprint_full(fullc, L, posx, posy, posz, wx, wy, wz)
 			                    : kLut ? packed_footprint_lut<kScalar>(A, posx, posy, posz, wx, wy, wz)
 			                         : packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, wx, wy, wz);
 			q00 = load_row<kNt>(ba);
@@ -1957,16 +1976,9 @@ __global__ void __launch_bounds__(256) k_raymarch_lean_batch(const RayMarchArgs 
 {
 	__shared__ RmLds L;
 	const uint32_t   g = blockIdx.x >> 3;
-	if (groups_per_frame == 0)
-	{        // interleaved
-		const uint32_t f = g % n;
-		lean_block<SKIP, ERT, GRAD, true, LF>(frames[f], ((g / n) << 3) | (blockIdx.x & 7u), L);
-	}
-	else
-	{        // one frame after the other
-		const uint32_t f = g / groups_per_frame;
-		lean_block<SKIP, ERT, GRAD, true, LF>(frames[f], ((g % groups_per_frame) << 3) | (blockIdx.x & 7u), L);
-	}
+	// groups_per_frame == 0: frames interleaved in groups of eight workgroups; otherwise one frame after the other (A/B switch of the launcher)
+	const uint32_t f = groups_per_frame == 0 ? g % n : g / groups_per_frame, gi = groups_per_frame == 0 ? g / n : g % groups_per_frame;
+	lean_block<SKIP, ERT, GRAD, true, LF>(frames[f], (gi << 3) | (blockIdx.x & 7u), L);
 }
 
 namespace vkv
