@@ -64,13 +64,13 @@ def test_gradient_map_parity(ctx, shape, use_gradient):
 
 def test_gradient_kernel_shortcuts_are_exact(ctx):
     """The tiled gradient kernel's two short-cuts, checked exhaustively on the device: (0) its short sqrt (v_sqrt_f32 + one-ulp
-    fix-up, no range rescaling) equals the compiler's correctly rounded sqrt for every float a sum of squares can be - 0 and all
-    of [2^-90, 4); (1) its one-instruction clamped R8_UNORM store equals rint(clamp(g, 0, 1) * 255) for every non-NaN float."""
+    fix-up, no range rescaling) equals the compiler's correctly rounded sqrt for every float its argument can be - 0 and all of
+    [2^-90, 16): the sum of the squares of three tap sums in [-2, 2] (the 0.25 factors are applied after the root); (1) its one-instruction clamped R8_UNORM store equals rint(clamp(g, 0, 1) * 255) for every non-NaN float."""
     import ctypes as C
     L = ctx._lib
     L.vkv_debug_check.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
     bad = torch.zeros(2, dtype=torch.int64, device="cuda")
-    lo, hi = int(np.float32(2.0 ** -90).view(np.uint32)), int(np.float32(4.0).view(np.uint32))
+    lo, hi = int(np.float32(2.0 ** -90).view(np.uint32)), int(np.float32(16.0).view(np.uint32))
     ctx.check(L.vkv_debug_check(ctx.handle, 0, lo, hi - lo, bad.data_ptr(), None))
     ctx.check(L.vkv_debug_check(ctx.handle, 0, 0, 1, bad.data_ptr(), None))  # x = 0
     inf = 0x7f800000

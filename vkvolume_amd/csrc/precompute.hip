@@ -3,6 +3,7 @@
 // Replaces ComputeGradientMap / ComputeDistanceMap (src/compute_gradient_map.cpp, src/compute_distance_map.cpp)
 // and their shaders (gradient_map.comp, occupancy_map.comp, distance_map.comp, distance_map_anisotropic.comp).
 // All kernels are integer/byte streaming work bound by HBM / LDS bandwidth; no MFMA.
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -41,7 +42,7 @@ __global__ void __launch_bounds__(256) k_gradient_map(const uint8_t *__restrict_
 // -fhip-fp32-correctly-rounded-divide-sqrt, without the rescaling of tiny inputs and the inf / nan pass-through around it (7 of its
 // 16 instructions).  The gradient's sum of squares is 0 or >= ~1e-17 (squares of rounding residues of byte / 255 values), far above
 // 2^-96 where the rescaling starts.  vkv_debug_check (what = 0) compares it with __builtin_sqrtf for every float of a range; the GPU
-// tests run it over 0 and all of [2^-90, 4).
+// tests run it over 0 and all of [2^-90, 16).
 __device__ __forceinline__ float sqrt_rn_normal(float x)
 {
 	const float r  = __builtin_amdgcn_sqrtf(x);
@@ -85,6 +86,7 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
 	const int      y0 = (int) ((t / tiles_x) % tiles_y) * kGradTileY;
 	const int      z0 = (int) (t / (tiles_x * tiles_y)) * kGradTileZ;
 	const int      wd = W >> 2;        // dwords per row
+	const float    quarter_modifier = 0.25f * modifier;
 	// ---- stage: 100 rows x 18 dwords; rows clamp in y and z, dword columns clamp in x (the two x-border bytes are patched below)
 	constexpr int kRows = (kGradTileZ + 2) * (kGradTileY + 2), kCols = kGradPitch / 4;
 	{
@@ -137,12 +139,15 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
 			const float    v2 = s_unorm[c[-1 - sy + sz]];        // k.yyx = (-1,-1, 1)
 			const float    v3 = s_unorm[c[-1 + sy - sz]];        // k.yxy = (-1, 1,-1)
 			const float    v4 = s_unorm[c[+1 + sy + sz]];        // k.xxx = ( 1, 1, 1)
-			// get_gradient_compute.glsl:12-20, the operations of gradient_from_taps with the short exact sqrt
-			const float gx  = 0.25f * (((v1 - v2) - v3) + v4);
-			const float gy  = 0.25f * (((-v1 - v2) + v3) + v4);
-			const float gz  = 0.25f * (((-v1 + v2) - v3) + v4);
-			const float len = sqrt_rn_normal((gx * gx + gy * gy) + gz * gz);
-			grad[vidx(x, y, z, W, H)] = store_unorm8_clamped(len * modifier);
+			// get_gradient_compute.glsl:12-20, the operations of gradient_from_taps with the short exact sqrt.  The three factors 0.25 are
+			// taken out: scaling by a power of two commutes with every rounding on the way (squares x 2^-4, their sums, the root x 2^-2;
+			// nothing comes near the denormal range: the sum is 0 or >= ~1e-17), so sqrt(sum of (0.25 s)^2) * m == sqrt(sum of s^2) * (0.25 m)
+			// bit for bit (quarter_modifier = 0.25 * modifier is exact as well)
+			const float sx  = ((v1 - v2) - v3) + v4;
+			const float sy_ = ((-v1 - v2) + v3) + v4;
+			const float sz_ = ((-v1 + v2) - v3) + v4;
+			const float len = sqrt_rn_normal((sx * sx + sy_ * sy_) + sz_ * sz_);
+			grad[vidx(x, y, z, W, H)] = store_unorm8_clamped(len * quarter_modifier);
 		}
 	}
 }
@@ -789,50 +794,62 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 	}
 }
 
-// LDS-staged version for dword-aligned rows (W % 4 == 0): a workgroup packs 8 x 2 x 2 bricks from a 33 x 9 x 9 texel tile that it
-// stages with coalesced dword loads (volume and gradient once each), then writes the 32 bricks as whole 256-byte lines.
+// LDS-staged version for dword-aligned rows (W % 4 == 0): a workgroup packs 8 x BY x BZ bricks from a 33 x (4 BY + 1) x (4 BZ + 1) texel
+// tile that it stages with coalesced dword loads (volume and gradient once each), then writes the bricks as whole 256-byte lines.
+// 8 x 4 x 4 (the launcher's choice for volumes of at least 16 bricks in y and z): every lane has 2 x 11 dwords in flight before the
+// barrier (8 x 2 x 2: 2 x 3 - not enough outstanding bytes per CU to cover the HBM latency) and the apron re-read drops from 1.42 to 1.27.
+template <int BY, int BZ, int PITCH>
 __global__ void __launch_bounds__(256) k_pack_volume_tiled(const uint8_t *__restrict__ vol, const uint8_t *__restrict__ grad, uint8_t *__restrict__ packed,
                                                            int W, int H, int D, PackedDims pd, uint32_t groups_x)
 {
-	// tile: [9][9] rows of (v | g << 8) texels; staged dword column c (voxels 4 * (bx0 - 1 + c) ..) sits at texels 4c .. 4c + 3, so the
+	// tile: rows (jz, jy) of (v | g << 8) texels; staged dword column c (voxels 4 * (bx0 - 1 + c) ..) sits at texels 4c .. 4c + 3, so the
 	// padded tile column jx (voxel x = 4 * bx0 - 1 + jx) is texel jx + 3; 36 texels staged, 33 used
-	constexpr int kTX = 40, kRows = 81;
+	constexpr int kTX = PITCH, kRY = 4 * BY + 1, kRZ = 4 * BZ + 1, kRows = kRY * kRZ;
 	__shared__ __align__(8) uint16_t s_tile[kRows * kTX];
 	// x-neighbouring workgroups stage parts of the same 128-byte lines: consecutive groups go to one XCD (own L2)
 	const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-	const int      bx0 = (int) (bid % groups_x) * 8, by0 = (int) (bid / groups_x) * 2, bz0 = (int) blockIdx.y * 2;
+	const int      bx0 = (int) (bid % groups_x) * 8, by0 = (int) (bid / groups_x) * BY, bz0 = (int) blockIdx.y * BZ;
 	const int wd  = W >> 2;
 	// ---- stage: row = (jz, jy) of the padded tile, 9 dwords per row starting one dword left of the tile; a lane's (row, column) advance by
-	// constants from one of its three loads to the next (256 = 28 * 9 + 4), so the divisions are done once
+	// constants from one of its loads to the next (256 = 28 * 9 + 4), so the divisions are done once
 	{
-		constexpr int kIter = (kRows * 9 + 255) / 256;        // 3 x 2 dwords per thread, all in flight before the first LDS store
+		constexpr int kIter = (kRows * 9 + 255) / 256;        // all loads of a lane are in flight before its first LDS store
 		uint32_t      v4[kIter], g4[kIter];
 		const int     row0 = (int) threadIdx.x / 9, c0 = (int) threadIdx.x - row0 * 9;
+		int           row = row0, c = c0;
 #pragma unroll
 		for (int j = 0; j < kIter; ++j)
 		{
-			int row = row0 + 28 * j, c = c0 + 4 * j;
-			if (c >= 9)
-				c -= 9, ++row;
-			row           = min(row, kRows - 1);
-			const int ry = row % 9, rz = row / 9;
+			const int r  = min(row, kRows - 1);
+			const int ry = r % kRY, rz = r / kRY;
 			const int y = min(max(by0 * 4 + ry - 1, 0), H - 1), z = min(max(bz0 * 4 + rz - 1, 0), D - 1);
 			const int dc = min(max(bx0 - 1 + c, 0), wd - 1);
 			const size_t o = ((size_t) z * H + y) * (size_t) W;
 			v4[j]          = reinterpret_cast<const uint32_t *>(vol + o)[dc];
 			g4[j]          = grad ? reinterpret_cast<const uint32_t *>(grad + o)[dc] : 0u;
+			row += 28, c += 4;
+			if (c >= 9)
+				c -= 9, ++row;
 		}
+		row = row0, c = c0;
 #pragma unroll
 		for (int j = 0; j < kIter; ++j)
 		{
-			int row = row0 + 28 * j, c = c0 + 4 * j;
+			if (row < kRows)
+			{
+				// bytes (v0 v1 v2 v3), (g0 g1 g2 g3) -> texel pairs (v0 g0 v1 g1), (v2 g2 v3 g3): one byte permute each, one 8-byte LDS store
+				const uint32_t lo = __builtin_amdgcn_perm(g4[j], v4[j], 0x05010400u), hi = __builtin_amdgcn_perm(g4[j], v4[j], 0x07030602u);
+				if (kTX % 4 == 0)
+					*reinterpret_cast<uint2 *>(&s_tile[row * kTX + 4 * c]) = make_uint2(lo, hi);
+				else
+				{
+					*reinterpret_cast<uint32_t *>(&s_tile[row * kTX + 4 * c])     = lo;
+					*reinterpret_cast<uint32_t *>(&s_tile[row * kTX + 4 * c + 2]) = hi;
+				}
+			}
+			row += 28, c += 4;
 			if (c >= 9)
 				c -= 9, ++row;
-			if (row >= kRows)
-				break;
-			// bytes (v0 v1 v2 v3), (g0 g1 g2 g3) -> texel pairs (v0 g0 v1 g1), (v2 g2 v3 g3): one byte permute each, one 8-byte LDS store
-			const uint32_t lo = __builtin_amdgcn_perm(g4[j], v4[j], 0x05010400u), hi = __builtin_amdgcn_perm(g4[j], v4[j], 0x07030602u);
-			*reinterpret_cast<uint2 *>(&s_tile[row * kTX + 4 * c]) = make_uint2(lo, hi);
 		}
 	}
 	__syncthreads();
@@ -850,8 +867,8 @@ __global__ void __launch_bounds__(256) k_pack_volume_tiled(const uint8_t *__rest
 		}
 		__syncthreads();
 	}
-	// ---- write: 32 bricks x 16 pieces of 16 bytes (a store instruction costs the same per lane whatever its width).  A lane keeps its piece
-	// q of every brick it writes (bricks b, b + 16), so the positions of its eight texels inside a brick's 5^3 block are computed once
+	// ---- write: 8 BY BZ bricks x 16 pieces of 16 bytes (a store instruction costs the same per lane whatever its width).  A lane keeps its
+	// piece q of every brick it writes (bricks b, b + 16, ...), so the positions of its eight texels inside a brick's 5^3 block are computed once
 	const int q = (int) threadIdx.x & 15;
 	int       off[8];
 #pragma unroll
@@ -859,16 +876,17 @@ __global__ void __launch_bounds__(256) k_pack_volume_tiled(const uint8_t *__rest
 	{
 		const int t = 8 * q + k;        // texel of the 5^3 brick, x fastest; 125..127 are padding
 		const int lx = t % 5, ly = (t / 5) % 5, lz = t / 25;
-		off[k]       = t < 125 ? (lz * 9 + ly) * kTX + lx + 3 : -1;
+		off[k]       = t < 125 ? (lz * kRY + ly) * kTX + lx + 3 : -1;
 	}
 #pragma unroll
-	for (int j = 0; j < 2; ++j)
+	for (int j = 0; j < (8 * BY * BZ) / 16; ++j)
 	{
-		const int b = ((int) threadIdx.x >> 4) + 16 * j;
-		const int bx = bx0 + (b & 7), by = by0 + ((b >> 3) & 1), bz = bz0 + (b >> 4);
+		const int b  = ((int) threadIdx.x >> 4) + 16 * j;
+		const int lbx = b & 7, lby = (b >> 3) % BY, lbz = (b >> 3) / BY;
+		const int bx = bx0 + lbx, by = by0 + lby, bz = bz0 + lbz;
 		if (bx >= pd.bx || by >= pd.by || bz >= pd.bz)
 			continue;
-		const int base = (((b >> 4) * 4) * 9 + ((b >> 3) & 1) * 4) * kTX + (b & 7) * 4;
+		const int base = ((lbz * 4) * kRY + lby * 4) * kTX + lbx * 4;
 		uint32_t  w[4] = {0, 0, 0, 0};
 #pragma unroll
 		for (int k = 0; k < 8; ++k)
@@ -1018,7 +1036,10 @@ int launch_gradient_map(vkv_ctx *ctx, const uint8_t *d_vol, uint8_t *d_grad, Vkv
 	const uint32_t blocks_x = (e.width + 63) / 64;
 	if (e.depth > 65535u || (uint64_t) blocks_x * ((e.height + 3) / 4) > 0xffffffull)
 		return set_error(ctx, VKV_E_UNSUPPORTED, "gradient_map: volume too large for one launch");
-	if (tf->use_gradient && (e.width & 3u) == 0 && (((uintptr_t) d_vol) & 3u) == 0)
+	// the tiled kernel folds the three factors 0.25 into the modifier: exact unless 0.25 * modifier is denormal (or the modifier no number)
+	const float m_abs    = std::fabs(tf->grad_magnitude_modifier);
+	const bool  m_normal = m_abs == 0.0f || (m_abs >= 1e-30f && m_abs <= 1e30f);
+	if (tf->use_gradient && m_normal && (e.width & 3u) == 0 && (((uintptr_t) d_vol) & 3u) == 0)
 	{
 		const uint64_t tx = (e.width + kGradTileX - 1) / kGradTileX, ty = (e.height + kGradTileY - 1) / kGradTileY,
 		               tz = (e.depth + kGradTileZ - 1) / kGradTileZ;
@@ -1278,11 +1299,20 @@ int launch_pack_volume(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_grad
 	const PackedDims pd = packed_dims((int) e.width, (int) e.height, (int) e.depth);
 	if ((e.width & 3u) == 0 && ((((uintptr_t) d_vol) | ((uintptr_t) d_grad)) & 3u) == 0)
 	{
-		const uint32_t gx = (uint32_t) (pd.bx + 7) / 8, gy = (uint32_t) (pd.by + 1) / 2, gz = (uint32_t) (pd.bz + 1) / 2;
+		static const int tile_env = [] { const char *v = std::getenv("VKV_PACK_TILE"); return v ? std::atoi(v) : 0; }();        // A/B switch: 2 or 4
+		const bool     big = tile_env ? tile_env == 4 : (pd.by >= 16 && pd.bz >= 16);
+		const uint32_t t   = big ? 4u : 2u;
+		const uint32_t gx = (uint32_t) (pd.bx + 7) / 8, gy = ((uint32_t) pd.by + t - 1) / t, gz = ((uint32_t) pd.bz + t - 1) / t;
 		if ((uint64_t) gx * gy <= 0xffffffull && gz <= 65535u && (uint64_t) pd.mx * pd.my * pd.mz * 512 <= 0xffffffffull)
 		{
-			hipLaunchKernelGGL(k_pack_volume_tiled, dim3(gx * gy, gz), dim3(256), 0, s, d_vol, d_grad, (uint8_t *) d_packed, (int) e.width, (int) e.height,
-			                   (int) e.depth, pd, gx);
+			// row pitch 40 texels; 38 (19 banks, odd: no bank conflicts, 70 % of the LDS cycles otherwise) measured the same 1.34 ms: the
+			// kernel follows its 5.3 GB of traffic, not the LDS or the VALU (50 % busy)
+			if (big)
+				hipLaunchKernelGGL((k_pack_volume_tiled<4, 4, 40>), dim3(gx * gy, gz), dim3(256), 0, s, d_vol, d_grad, (uint8_t *) d_packed, (int) e.width,
+				                   (int) e.height, (int) e.depth, pd, gx);
+			else
+				hipLaunchKernelGGL((k_pack_volume_tiled<2, 2, 40>), dim3(gx * gy, gz), dim3(256), 0, s, d_vol, d_grad, (uint8_t *) d_packed, (int) e.width,
+				                   (int) e.height, (int) e.depth, pd, gx);
 			return check_launch(ctx, "pack_volume");
 		}
 	}
