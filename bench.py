@@ -233,8 +233,10 @@ def main():
 
     def run_batch(n_steps, timed):
         k, launch = 0, 0
+        n_launches = -(-n_steps // fpl)
         while k < n_steps:
-            n = min(fpl, n_steps - k)
+            # the frames of a block are spread evenly over its launches (20 steps with 8 per launch: 7 + 7 + 6, not 8 + 8 + 4)
+            n = (n_steps - k + (n_launches - launch) - 1) // (n_launches - launch)
             slot = launch % nbs  # stream and output buffers of this launch
             st = streams[slot]
             launch += 1
