@@ -264,3 +264,47 @@ def test_native_rccl_gather_and_assemble(ctx):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("skipping_type", [abi.SKIP_NONE, abi.SKIP_DISTANCE, abi.SKIP_ANISOTROPIC_DISTANCE])
+def test_render_batch_pull_kernel_equals_single_launches(ctx, skipping_type, monkeypatch):
+    """VKV_RAYMARCH_BATCH=pull (resident workgroups, waves pull 8x8 units from per-XCD ticket counters): same frames, bit for bit."""
+    opt = abi.VolumeOptions(**T.APP_TF)
+    scene = T.OracleScene(O.synth_volume((96, 80, 72), 1, 91), opt, 4)
+    v, tf = make_gpu_volume(ctx, scene)
+    V.ComputeDistanceMap(ctx).compute(v, tf, skipping_type)
+    size = (208, 112)
+    ro = abi.RenderOptions(skipping_type=skipping_type, clip_distance=1.0)
+    st = torch.cuda.current_stream().cuda_stream
+    params = []
+    for az in (0.0, 40.0, 95.0, 170.0, 230.0, 300.0, 345.0):
+        view, proj = T.orbit(az, image_size=size)
+        params.append(V.VolumeRenderSubpass(ctx, v, ro, size).bind(scene.params(view, proj, size, ro)))
+
+    def outputs():
+        return [dict(color=torch.full((size[1], size[0], 4), -1.0, dtype=torch.float32, device="cuda"),
+                     counts=torch.full((size[1], size[0], 3), 9, dtype=torch.int32, device="cuda"),
+                     depth=torch.full((size[1], size[0]), -1.0, dtype=torch.float32, device="cuda"),
+                     rgba8=torch.full((size[1], size[0], 4), 7, dtype=torch.uint8, device="cuda")) for _ in params]
+
+    def point(p, o):
+        p.d_out_color, p.d_out_counts, p.d_out_depth, p.d_out_rgba8 = (o[k].data_ptr() for k in ("color", "counts", "depth", "rgba8"))
+
+    single, pulled = outputs(), outputs()
+    for p, o in zip(params, single):
+        point(p, o)
+        ctx.render(p, st)
+    plist = []
+    for p, o in zip(params, pulled):
+        q = abi.RenderParams.from_buffer_copy(p)
+        point(q, o)
+        plist.append(q)
+    monkeypatch.setenv("VKV_RAYMARCH_BATCH", "pull")
+    for _ in range(2):  # twice: the ticket counters are re-armed by every launch
+        ctx.render_batch(plist, st)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("VKV_RAYMARCH_BATCH")
+    for i, (a, b) in enumerate(zip(single, pulled)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), "frame %d: %s differs between the pull kernel and the single launch" % (i, k)

@@ -1952,7 +1952,7 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
 		if (lane == (uint32_t) __builtin_ctzll(__ballot(1)))
 		{
-			unsigned long long *rec = A.trace + ((size_t) bid * WPB + wave) * kTraceWords;
+			unsigned long long *rec = A.trace + ((size_t) blockIdx.x * WPB + wave) * kTraceWords;        // per launch (a batch: all its frames)
 			rec[0] = t_start, rec[1] = t_end, rec[2] = it, rec[3] = ((unsigned long long) __builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (k * A.blocks_per_tile + sb);
 			for (int w = 4; w < kTraceWords; ++w)
 				rec[w] = 0;
@@ -1979,6 +1979,105 @@ __global__ void __launch_bounds__(256) k_raymarch_lean_batch(const RayMarchArgs 
 	// groups_per_frame == 0: frames interleaved in groups of eight workgroups; otherwise one frame after the other (A/B switch of the launcher)
 	const uint32_t f = groups_per_frame == 0 ? g % n : g / groups_per_frame, gi = groups_per_frame == 0 ? g / n : g % groups_per_frame;
 	lean_block<SKIP, ERT, GRAD, true, LF>(frames[f], (gi << 3) | (blockIdx.x & 7u), L);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_raymarch_lean_pull — the batch launch with resident workgroups whose WAVES pull 8x8 units from per-XCD ticket counters.
+//   * A workgroup of the tile-per-workgroup kernels keeps its 20 KB of LDS tables until its longest wave is done, so a CU that could hold 32
+//     waves holds 20 on average (wave trace of an 8-frame launch) and a launch ends with 150 us of declining occupancy.  Here a wave that
+//     has finished its unit takes the next one: the workgroups stay, every wave slot stays busy until the tickets run out, the tables are
+//     staged once per workgroup (2048 times per launch instead of 26 000), and workgroups without a marching ray cost nothing.
+//   * Requires every frame of the launch to share the tables (same packed image, TF tables, opacity table: the launcher compares them).
+//   * Ticket v of queue q (one queue per XCD, as the static kernels deal the tiles): unit w = v % upt of frame (v / upt) % n of the
+//     queue's (v / (upt n))-th tile, i.e. the frames advance side by side through the centre-first start order.  A wave takes from its own
+//     XCD's queue first and from the others once that is empty.  The eight counters sit in front of the argument blocks in the stream's
+//     scratch buffer and are zeroed by the same upload.
+// No lane compaction: a wave marches one 8x8 unit at a time with the loop of the tile kernels (lean_march).
+// ---------------------------------------------------------------------------------------------------------------
+// the pull loop of one wave, one copy per transfer-function path (each copy holds one march loop: half the register pressure)
+template <int SKIP, bool ERT, int GRAD, uint32_t LF, bool SEP>
+__device__ __forceinline__ void pull_units(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t *__restrict__ heads, const RmLds &L)
+{
+	const RayMarchArgs &A0   = frames[0];
+	const uint32_t      lane = threadIdx.x & 63u;
+	const uint32_t      upt  = A0.blocks_per_tile * 4u;        // 8x8 units per tile
+	uint32_t            q = blockIdx.x & 7u, open_queues = 0xffu;
+	while (open_queues != 0u)
+	{
+		if (((open_queues >> q) & 1u) == 0u)
+		{
+			q = (q + 1u) & 7u;
+			continue;
+		}
+		uint32_t v = 0;
+		if (lane == 0)
+			v = atomicAdd(&heads[q * vkv::kPullHeadStride], 1u);
+		v = __builtin_amdgcn_readfirstlane(v);
+		const uint32_t tiles_q = A0.tile_count > q ? (A0.tile_count - q + 7u) >> 3 : 0u;
+		if (v >= tiles_q * upt * n)
+		{
+			open_queues &= ~(1u << q);
+			q = (q + 1u) & 7u;
+			continue;
+		}
+		const uint32_t      w = v % upt, f = (v / upt) % n, rank = (v / (upt * n)) * 8u + q;
+		const RayMarchArgs &A = frames[f];
+		const uint32_t      k = A.tile_order ? A.tile_order[rank] : rank;
+		uint32_t            px, py, o;
+		const bool          inside = block_pixel<1>(A, k * A.blocks_per_tile + (w >> 2), (w & 3u) * 64u + lane, px, py, o);
+		Ray                 R = {};        // every field defined per unit: nothing of the previous unit's ray is carried round the loop
+		R.o = o;
+		const unsigned long long t_start = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+		bool                     marched = false;
+		if (inside)
+		{
+			if (px >= A.cull_x0 && px <= A.cull_x1 && py >= A.cull_y0 && py <= A.cull_y1)
+				marched = ray_setup<SKIP>(A, px, py, R);
+			else
+				ray_clear(R);
+		}
+		uint32_t                 iter    = 0;
+		const unsigned long long t_setup = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+		if (marched)
+			lean_march<SKIP, ERT, GRAD, true, SEP, LF>(A, R, L, iter);
+		const unsigned long long t_march = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+		__builtin_amdgcn_s_setprio(0);        // lean_march raises the priority of a long wave: back to normal for the next unit
+		if (inside)
+			ray_finish(A, R, marched);
+		if (A.trace)
+		{        // diagnostic only: one record per unit
+			uint32_t it = iter;
+			for (int o2 = 32; o2 > 0; o2 >>= 1)
+				it = max(it, (uint32_t) __shfl_xor((int) it, o2));
+			const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+			if (lane == 0)
+			{
+				unsigned long long *rec = A.trace + ((size_t) ((v / upt) * 8u + q) * upt + w) * kTraceWords;
+				rec[0] = t_start, rec[1] = t_end, rec[2] = it, rec[3] = ((unsigned long long) __builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (rank * upt + w);
+				rec[4] = t_setup, rec[5] = t_march;
+				for (int x = 6; x < kTraceWords; ++x)
+					rec[x] = 0;
+			}
+		}
+	}
+}
+
+template <int SKIP, bool ERT, int GRAD, uint32_t LF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_raymarch_lean_pull(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t *__restrict__ heads)
+{
+	__shared__ RmLds    L;
+	const RayMarchArgs &A0 = frames[0];
+	if ((LF & kLeanLut) != 0 && GRAD != 2)
+	{        // before the barrier of stage_tables_er
+		if ((LF & kLeanFull) != 0 && tf_is_separable(A0))
+			stage_full_lut(A0, L);
+		else
+			stage_addr_lut(A0);
+	}
+	if (stage_tables_er(A0, L))
+		pull_units<SKIP, ERT, GRAD, LF, true>(frames, n, heads, L);
+	else
+		pull_units<SKIP, ERT, GRAD, LF, false>(frames, n, heads, L);
 }
 
 namespace vkv
