@@ -14,7 +14,10 @@ The timed block is EXACTLY K steps between two fences (barrier + synchronize); t
 --min-seconds have been measured and the MEDIAN block is reported (`repeats`, `ms_per_step_min_max`).
 
 N = 1 submits the frames `--frames-per-launch` at a time through vkv_render_batch (default 8: the eight views of one orbit in one
-launch, the frames advance side by side inside one grid); `--frames-per-launch 1` renders strictly one frame per launch, and
+launch, the frames advance side by side inside one grid; a block's frames are spread evenly over its launches) and alternates
+consecutive launches over `--batch-streams` HIP streams (default 3: the launches of a block overlap, the tail of one is covered by
+the others; streams that happen to share a hardware queue simply serialise, which is the one-stream behaviour);
+`--batch-streams 1` keeps one launch at a time; `--frames-per-launch 1` renders strictly one frame per launch, and
 `--submit streams` keeps `--frames-in-flight` single-frame launches in flight on as many HIP streams (the round 1 scheme).
 The one-frame-at-a-time launch duration is always measured too (`single_frame`, outside the timed region).
 
@@ -118,7 +121,7 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: grow the frame with N (weak) or keep it (strong); default per workload")
     ap.add_argument("--submit", default=None, choices=["batch", "streams"], help="N = 1: vkv_render_batch launches (default) or single-frame launches "
                     "on --frames-in-flight streams; N > 1 always uses streams")
-    ap.add_argument("--batch-streams", type=int, default=1, help="batch submission: consecutive vkv_render_batch launches alternate over this many HIP streams "
+    ap.add_argument("--batch-streams", type=int, default=3, help="batch submission: consecutive vkv_render_batch launches alternate over this many HIP streams "
                     "(the tail of one launch overlaps the head of the next)")
     ap.add_argument("--frames-per-launch", type=int, default=8, help="batch submission: frames per vkv_render_batch launch (1 = one frame per launch)")
     ap.add_argument("--frames-in-flight", type=int, default=3, help="stream submission: consecutive frames render on this many HIP streams")
@@ -231,6 +234,8 @@ def main():
                 row.append(q)
             batch_params.append(row)
 
+    last_slot = [0]
+
     def run_batch(n_steps, timed):
         k, launch = 0, 0
         n_launches = -(-n_steps // fpl)
@@ -241,6 +246,7 @@ def main():
             st = streams[slot]
             launch += 1
             plist = [batch_params[(k + j) % N_VIEWS][slot * fpl + j] for j in range(n)]
+            last_slot[0] = slot * fpl + n - 1  # output buffer of the block's last step (--verify)
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(st)
@@ -364,7 +370,7 @@ def main():
     vs_total, ds_total, cov_total = float(tot[0].item()), float(tot[1].item()), float(tot[2].item())
 
     if args.verify:
-        verify(ctx, sp, v, views, params, args.steps, nbuf, fpl if submit == "batch" else 0, (fw, fh), bufs, images, gather, rank,
+        verify(ctx, sp, v, views, params, args.steps, nbuf, (last_slot[0] + 1) if submit == "batch" else 0, (fw, fh), bufs, images, gather, rank,
                (args.steps - 1) % world if rotate else 0)
     if rank != 0:
         if native:
@@ -387,7 +393,7 @@ def main():
                        world, "rank k mod N for frame k" if rotate else "rank 0") + (" (vkv_assemble_frame: ncclGather + de-interleave)" if native else " (torch.distributed.gather)")
                    if world > 1 else "1 GPU",
                    "output": "RGBA8",
-                   "submission": ("vkv_render_batch, %d frames per launch" % fpl) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams" % (fif, fif)),
+                   "submission": ("vkv_render_batch, up to %d frames per launch, consecutive launches on %d HIP stream(s)" % (fpl, nbs)) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams" % (fif, fif)),
                    "occupied_voxel_percent": round(occupied_voxel_percent(ctx, v, tf), 4)},
         "covered_Mray_per_s": round(cov_total / elapsed / 1e6, 3), "covered_fraction": round(cov_total / (rays_per_frame_all * args.steps), 4),
         "volume_samples_per_s": round(vs_total / elapsed, 1), "distance_probes_per_s": round(ds_total / elapsed, 1),
@@ -397,9 +403,14 @@ def main():
                      "frames_per_launch": round(sum(kernel_frames) / len(kernel_frames), 3),
                      "algorithmic_bytes_per_launch": int(alg_avg),
                      "achieved_aggregate": round(sum(frame_bytes[k % N_VIEWS] for k in range(args.steps)) / elapsed / 1e9, 2),
+                     "frac_aggregate": round(sum(frame_bytes[k % N_VIEWS] for k in range(args.steps)) / elapsed / 1e9 / HBM_PEAK_GBS, 5),
+                     "concurrent_launches": (nbs if submit == "batch" else fif),
                      "note": "algorithmic (requested) bytes: 16 B/volume sample + 1 B/distance probe + 4 B/ray, summed over the frames of a launch; NOT "
                              "DRAM traffic. achieved = bytes of a launch / HIP-event duration of that launch, averaged over the timed launches; "
-                             "achieved_aggregate = this rank's bytes of one timed block / its wall time; HIP events bracket every launch at N = 1 "
+                             "achieved_aggregate / frac_aggregate = this rank's bytes of one timed block / its wall time (with concurrent_launches > 1 "
+                             "the launches of a block overlap, so one launch's duration covers work of the others: per-launch achieved is then a "
+                             "share of the device, the aggregate is the device; single_frame is the same kernel with nothing else running); "
+                             "HIP events bracket every launch at N = 1 "
                              "and every 7th launch on the gather path (where launches of consecutive frames overlap)"},
     }
     if single is not None:
@@ -411,7 +422,8 @@ def main():
         with open(TRAFFIC_FILE) as f:
             tr = json.load(f)
         if tr.get("workload") == args.workload and world == 1 and tr.get("kernel") == out["roofline"]["kernel"]:
-            out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+            # measured with 8 frames per launch: scaled to this run's average launch
+            out["roofline"]["traffic"] = int(tr["traffic_bytes_per_launch"] * out["roofline"]["frames_per_launch"] / tr.get("frames_per_launch", 8))
             out["roofline"]["traffic_source"] = tr["source"]
     except (OSError, ValueError, KeyError):
         pass
@@ -435,7 +447,7 @@ def verify(ctx, sp, v, views, params, steps, nbuf, fpl, frame, bufs, images, gat
     direct = torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda")
     sp.draw(sp.make_params(*views[k % N_VIEWS], abi.full_frame_tiles(fw, fh, TILE, TILE)), rgba8=direct)
     torch.cuda.synchronize()
-    slot = (k % fpl) if fpl else (k % nbuf)  # batch submission: step k is slot k mod fpl of its launch
+    slot = (fpl - 1) if fpl else (k % nbuf)  # batch submission: `fpl` carries the last step's output buffer index + 1
     got = images[k % nbuf] if gather else bufs[slot].view(fh, fw, 4)
     if not torch.equal(got, direct):
         raise SystemExit("verify failed: assembled frame differs from the direct render in %d bytes" % int((got != direct).sum().item()))

@@ -288,7 +288,7 @@ int vkv_render(vkv_ctx *ctx, const VkvRenderParams *params, void *stream);
  * may differ (stereo pairs, orbit sweeps, the per-rank tile sets of a multi-GPU frame, the reference's frames in flight).  The
  * frames advance side by side inside one grid, so the long tail of each is covered by the bulk of the others without relying on
  * several hardware queues.  Output buffers of different frames must not overlap.  Results are bit-identical to `count` vkv_render calls. */
-#define VKV_MAX_BATCH 12
+#define VKV_MAX_BATCH 32
 int vkv_render_batch(vkv_ctx *ctx, const VkvRenderParams *params, uint32_t count, void *stream);
 
 /* Root-rank de-interleave of gathered compact tile buffers into the W×H image (multi-GPU):

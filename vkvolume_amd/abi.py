@@ -10,7 +10,7 @@ VKV_E_UNSUPPORTED = -2
 VKV_E_NO_DEVICE = -3
 VKV_E_IO = -4
 TF_BITS_WORDS = 2564  # VKV_TF_BITS_WORDS
-MAX_BATCH = 12  # VKV_MAX_BATCH
+MAX_BATCH = 32  # VKV_MAX_BATCH
 
 # VolumeRenderSubpass::SkippingType / Test (src/volume_render_subpass.h:58-72)
 SKIP_NONE, SKIP_BLOCK, SKIP_DISTANCE, SKIP_ANISOTROPIC_DISTANCE = 0, 1, 2, 3

@@ -162,7 +162,7 @@ uint8_t *stream_scratch(vkv_ctx *ctx, hipStream_t stream);
 // at 0, 32, 64; macro terms of x at 96, of y at *lut_y, of z as 64-bit values at *lut_z (even); nullptr if it cannot be allocated.
 const uint32_t *packed_addr_lut(vkv_ctx *ctx, int W, int H, int D, uint32_t *lut_y, uint32_t *lut_z, uint32_t *words);
 const uint32_t *tile_start_order(vkv_ctx *ctx, uint32_t img_w, uint32_t img_h, uint32_t tile_w, uint32_t tile_h, uint32_t first, uint32_t stride, uint32_t count);
-constexpr size_t kScratchBytes     = 64 * 1024;
+constexpr size_t kScratchBytes     = 128 * 1024;
 constexpr size_t kTfBitsOffset     = 0;           // 256*256 bits = 8 KiB: TF bit table of the map update / the voxel count
 constexpr size_t kQueueHeadsOffset = 8192;        // 8 x u32 tile-queue heads of the persistent ray-march scheduler
 constexpr size_t kPullHeadsBytes   = 2048;        // 8 ticket counters of k_raymarch_lean_pull, 256 bytes apart (one memory channel each), directly in
