@@ -13,9 +13,9 @@ run_stats() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --stats --out
 run_pmc() { name=$1; ctr=$2; shift; shift; timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_${name}_$ctr -- $B --steps 16 --warmup 2 --min-seconds 0.1 "$@" > /dev/null 2> $O/pmc_${name}_$ctr.err; }
 run_stats default
 run_stats batch8 --batch-streams 1
-run_stats single --frames-per-launch 1
+run_stats single --frames-per-launch 1 --batch-streams 1
 run_stats streams3 --submit streams
-run_stats dense_single --skip none --no-ert --frames-per-launch 1 --steps 16 --warmup 4
+run_stats dense_single --skip none --no-ert --frames-per-launch 1 --batch-streams 1 --steps 16 --warmup 4
 run_pmc batch8 FETCH_SIZE --batch-streams 1
 run_pmc batch8 WRITE_SIZE --batch-streams 1
 run_pmc single FETCH_SIZE --frames-per-launch 1
