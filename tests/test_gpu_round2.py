@@ -308,3 +308,42 @@ def test_render_batch_pull_kernel_equals_single_launches(ctx, skipping_type, mon
     for i, (a, b) in enumerate(zip(single, pulled)):
         for k in a:
             assert torch.equal(a[k], b[k]), "frame %d: %s differs between the pull kernel and the single launch" % (i, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["inside", "off_centre", "zoomed", "away", "grazing_corner", "compact_rank"])
+def test_render_parity_screen_bound_cases(ctx, case):
+    """The launcher's screen bound of the volume's box (pixels outside skip the ray set-up) must never cut a pixel the oracle shades:
+    camera inside the box (bound disabled), box partly off screen, box larger than the screen, box behind the camera, a box corner
+    beside the camera plane, and a compact multi-GPU tile schedule."""
+    opt = abi.VolumeOptions(**T.APP_TF)
+    scene = T.OracleScene(O.synth_volume((88, 72, 64), 1, 0xB0B0), opt, 4)
+    v, tf = make_gpu_volume(ctx, scene)
+    skipping_type = abi.SKIP_DISTANCE
+    V.ComputeDistanceMap(ctx).compute(v, tf, skipping_type)
+    size = (176, 96)
+    from vkvolume_amd import camera
+    fov, tiles = 60.0, None
+    if case == "inside":
+        view = camera.look_at((12.0, 5.0, 8.0), (-30.0, 0.0, -20.0))
+    elif case == "off_centre":
+        view = camera.look_at((150.0, 40.0, 20.0), (70.0, 10.0, -60.0))
+    elif case == "zoomed":
+        view, fov = camera.look_at((130.0, 30.0, 40.0), (0.0, 0.0, 0.0)), 14.0
+    elif case == "away":
+        view = camera.look_at((150.0, 40.0, 20.0), (400.0, 90.0, 60.0))
+    elif case == "grazing_corner":
+        view = camera.look_at((62.0, 10.0, 58.0), (62.0, 10.0, -100.0))  # looks along -z past the box: corners beside the camera plane
+    else:
+        view = camera.look_at((140.0, 50.0, -60.0), (20.0, 0.0, 10.0))
+        tiles = abi.full_frame_tiles(size[0], size[1], 16, 16, 1, 3, compact=True)
+    proj = camera.perspective_vulkan(fov, size[0] / size[1])
+    ro = abi.RenderOptions(skipping_type=skipping_type, clip_distance=1.0)
+    p = scene.params(view, proj, size, ro, tiles=tiles)
+    ref = scene.render(p)
+    got = gpu_render(ctx, v, p)
+    compare_render(got, ref, "screen bound case %s" % case)
+    if case == "away":
+        assert int(ref.counts.sum()) == 0
+    elif case != "grazing_corner":
+        assert int(ref.counts.sum()) > 0
