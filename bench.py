@@ -75,10 +75,13 @@ N_VIEWS = 8
 B_OUT = 4  # bytes per ray of the RGBA8 frame
 
 
-def build_scene(ctx, name):
+def build_scene(ctx, name, tf_preset="app"):
     extent, seed, voxel, axis_angle, frame, skip = WORKLOADS[name][:6]
     v = V.Volume(ctx)
-    v.options = abi.VolumeOptions(intensity_min=0.1, intensity_max=1.0, gradient_min=0.0, gradient_max=0.2)  # volume_render.cpp:67-70
+    if tf_preset == "intensity":  # the reference CSVs' intensity-only rows (gmin = gmax = 0: no gradient term, 8 B per volume sample)
+        v.options = abi.VolumeOptions(intensity_min=0.1, intensity_max=1.0, gradient_min=0.0, gradient_max=0.0)
+    else:
+        v.options = abi.VolumeOptions(intensity_min=0.1, intensity_max=1.0, gradient_min=0.0, gradient_max=0.2)  # volume_render.cpp:67-70
     v.load_synthetic(extent, kind=1, seed=seed, distance_map_block_size=4)
     V.default_scene(v, voxel, axis_angle)
     tf = v.get_transfer_function_uniform()
@@ -117,6 +120,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--skip", default=None, choices=["none", "block", "distance", "anisotropic"], help="override the workload's empty-space-skipping mode")
+    ap.add_argument("--tf", default="app", choices=["app", "intensity"], help="transfer function: the application's default (intensity 0.1..1, gradient "
+                    "0..0.2) or the intensity-only rows of the reference CSVs (gmin = gmax = 0)")
     ap.add_argument("--no-ert", action="store_true", help="early ray termination off (with --skip none: dense sampling of every step of every ray)")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: grow the frame with N (weak) or keep it (strong); default per workload")
     ap.add_argument("--submit", default=None, choices=["batch", "streams"], help="N = 1: vkv_render_batch launches (default) or single-frame launches "
@@ -163,7 +168,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     ctx = lib.Context(local_rank)  # raises if the HIP library is missing: there is no fallback path
-    v, tf, frame, skip = build_scene(ctx, args.workload)
+    v, tf, frame, skip = build_scene(ctx, args.workload, args.tf)
     if args.skip is not None:
         skip = {"none": abi.SKIP_NONE, "block": abi.SKIP_BLOCK, "distance": abi.SKIP_DISTANCE, "anisotropic": abi.SKIP_ANISOTROPIC_DISTANCE}[args.skip]
         V.ComputeDistanceMap(ctx).compute(v, tf, skip)
@@ -212,7 +217,10 @@ def main():
         nbuf = fpl * nbs if submit == "batch" else fif
         bufs, my_rays = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)], fw * fh
     torch.cuda.synchronize()
-    frame_bytes = [n_vs[i] * 16 + n_ds[i] * 1 + my_rays * B_OUT for i in range(N_VIEWS)]  # algorithmic bytes of one frame (this rank's part)
+    # algorithmic bytes of one frame (this rank's part): 8 B per trilinear footprint of the volume, 8 more for the gradient map's when the
+    # transfer function has a gradient term, 1 B per distance probe
+    b_sample = 16 if tf.use_gradient else 8
+    frame_bytes = [n_vs[i] * b_sample + n_ds[i] * 1 + my_rays * B_OUT for i in range(N_VIEWS)]
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(max(fif, nbs) - 1)]
     # the exchange streams get the higher priority: their small kernels (RCCL's gather, the de-interleave) must not queue behind the render
     # workgroups of the next frames (native exchange with a one-rank group: 0.25 -> 0.19 ms per step)
@@ -385,10 +393,11 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "repeats": len(blocks), "host_enqueue_ms_per_step": round(float(np.median(enqueue_times)) / args.steps * 1e3, 4), "ms_per_step_min_max": [round(min(blocks) / args.steps * 1e3, 4), round(max(blocks) / args.steps * 1e3, 4)],
-        "config": {"workload": "%s (%s): %dx%dx%d uint8 synthetic shells, %dx%d frame, %s, block 4, TF imin 0.1 imax 1 gmin 0 gmax 0.2, "
+        "config": {"workload": "%s (%s): %dx%dx%d uint8 synthetic shells, %dx%d frame, %s, block 4, TF %s, "
                                "8 orbit views" % (args.workload, WORKLOAD_NOTE[args.workload], *extent, fw, fh,
                                                   {0: "no ESS", 1: "block ESS", 2: "Chebyshev distance-map ESS", 3: "anisotropic Chebyshev distance-map ESS"}[skip]
-                                                  + (" + ERT" if not args.no_ert else ", no ERT")),
+                                                  + (" + ERT" if not args.no_ert else ", no ERT"),
+                                                  "imin 0.1 imax 1 gmin 0 gmax 0.2" if args.tf == "app" else "imin 0.1 imax 1 gmin 0 gmax 0 (intensity only)"),
                    "parallelism": "screen tiles 16x16 round-robin over %d GPU(s), RCCL gather to %s" % (
                        world, "rank k mod N for frame k" if rotate else "rank 0") + (" (vkv_assemble_frame: ncclGather + de-interleave)" if native else " (torch.distributed.gather)")
                    if world > 1 else "1 GPU",
@@ -405,7 +414,7 @@ def main():
                      "achieved_aggregate": round(sum(frame_bytes[k % N_VIEWS] for k in range(args.steps)) / elapsed / 1e9, 2),
                      "frac_aggregate": round(sum(frame_bytes[k % N_VIEWS] for k in range(args.steps)) / elapsed / 1e9 / HBM_PEAK_GBS, 5),
                      "concurrent_launches": (nbs if submit == "batch" else fif),
-                     "note": "algorithmic (requested) bytes: 16 B/volume sample + 1 B/distance probe + 4 B/ray, summed over the frames of a launch; NOT "
+                     "note": "algorithmic (requested) bytes: 16 B/volume sample (8 with the intensity-only TF) + 1 B/distance probe + 4 B/ray, summed over the frames of a launch; NOT "
                              "DRAM traffic. achieved = bytes of a launch / HIP-event duration of that launch, averaged over the timed launches; "
                              "achieved_aggregate / frac_aggregate = this rank's bytes of one timed block / its wall time (with concurrent_launches > 1 "
                              "the launches of a block overlap, so one launch's duration covers work of the others: per-launch achieved is then a "
@@ -421,7 +430,8 @@ def main():
     try:
         with open(TRAFFIC_FILE) as f:
             tr = json.load(f)
-        if tr.get("workload") == args.workload and world == 1 and tr.get("kernel") == out["roofline"]["kernel"]:
+        if (tr.get("workload") == args.workload and world == 1 and tr.get("kernel") == out["roofline"]["kernel"] and args.tf == "app"
+                and args.skip is None and not args.no_ert):
             # measured with 8 frames per launch: scaled to this run's average launch
             out["roofline"]["traffic"] = int(tr["traffic_bytes_per_launch"] * out["roofline"]["frames_per_launch"] / tr.get("frames_per_launch", 8))
             out["roofline"]["traffic_source"] = tr["source"]
