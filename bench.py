@@ -155,7 +155,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     use_gather = world > 1 or args.force_gather
-    submit = "streams" if use_gather else (args.submit or "batch")
+    # N > 1 (and the one-rank --force-gather proxy): batch launches with ONE gather per launch (torch exchange), or round 1's single-frame
+    # launches with one exchange per frame (--submit streams; always with the native exchange)
+    submit = "streams" if (use_gather and args.exchange == "native") else (args.submit or "batch")
     if submit == "streams":
         # several single-frame launches in flight prefer the plain tile order (their heavy image centres then do not coincide: 0.134 vs
         # 0.141 ms per frame on C3); the library reads the switch once, before its first launch
@@ -201,8 +203,16 @@ def main():
     fif = max(1, args.frames_in_flight)
     fpl = max(1, min(args.frames_per_launch, abi.MAX_BATCH, args.steps))
     gather, images, rotate = None, [], False
-    nbs = max(1, args.batch_streams) if submit == "batch" and not use_gather else 1
-    if use_gather:
+    nbs = max(1, args.batch_streams) if submit == "batch" else 1
+    nsets = nbs + 1  # gather path: one more buffer set than render streams, so a launch does not wait for the exchange nbs launches back
+    if use_gather and submit == "batch":
+        rotate = args.frame_owner == "rotate" and world > 1
+        gather = multigpu.BatchTileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda", frames=fpl, n_sets=nsets, any_root=rotate)
+        if rank == 0 or rotate:
+            images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nsets * fpl)]
+        nbuf = nsets * fpl
+        bufs, my_rays = gather.buffers, gather.my_ray_count()
+    elif use_gather:
         nbuf = fif + 1  # one more buffer than render streams: a render does not wait for the gather of the frame fif steps back
         rotate = args.frame_owner == "rotate" and world > 1
         if args.exchange == "native":
@@ -226,7 +236,7 @@ def main():
     # workgroups of the next frames (native exchange with a one-rank group: 0.25 -> 0.19 ms per step)
     side = torch.cuda.Stream(priority=-1) if gather else None
     xchg = torch.cuda.Stream(priority=-1) if gather else None  # native exchange: RCCL's gather here, the de-interleave on `side`
-    freed = [None] * nbuf
+    freed = [None] * (nsets if (use_gather and submit == "batch") else nbuf)
     launches = []  # (start event, stop event, algorithmic bytes) of the timed launches of the last block
 
     # per-launch parameter blocks of the batch path: slot j of a launch renders into bufs[j]
@@ -242,7 +252,7 @@ def main():
                 row.append(q)
             batch_params.append(row)
 
-    last_slot = [0]
+    last_slot, last_owner = [0], [0]
 
     def run_batch(n_steps, timed):
         k, launch = 0, 0
@@ -250,21 +260,38 @@ def main():
         while k < n_steps:
             # the frames of a block are spread evenly over its launches (20 steps with 8 per launch: 7 + 7 + 6, not 8 + 8 + 4)
             n = (n_steps - k + (n_launches - launch) - 1) // (n_launches - launch)
-            slot = launch % nbs  # stream and output buffers of this launch
-            st = streams[slot]
+            st = streams[launch % nbs]  # stream of this launch
+            slot = (launch % nsets) if gather else (launch % nbs)  # its set of output buffers
+            owner = (launch % world) if rotate else 0  # gather path: the rank that assembles this launch's frames
             launch += 1
             plist = [batch_params[(k + j) % N_VIEWS][slot * fpl + j] for j in range(n)]
             last_slot[0] = slot * fpl + n - 1  # output buffer of the block's last step (--verify)
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(st)
-            if n == 1:
-                ctx.render(plist[0], st.cuda_stream)
-            else:
-                ctx.render_batch(plist, st.cuda_stream)
-            if timed:
-                e1.record(st)
-                launches.append((e0, e1, sum(frame_bytes[(k + j) % N_VIEWS] for j in range(n)), n))
+            with torch.cuda.stream(st):
+                if gather and freed[slot] is not None:
+                    st.wait_event(freed[slot])  # the exchange that last used this buffer set has read it
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                if n == 1:
+                    ctx.render(plist[0], st.cuda_stream)
+                else:
+                    ctx.render_batch(plist, st.cuda_stream)
+                if timed:
+                    e1.record(st)
+                    launches.append((e0, e1, sum(frame_bytes[(k + j) % N_VIEWS] for j in range(n)), n))
+                if gather:
+                    gather.start(slot, owner, n)  # ONE collective for the launch's n frames, ordered after the render
+            if gather:
+                with torch.cuda.stream(side):
+                    got = gather.finish(slot)
+                    if got is not None:
+                        flat, nf = got
+                        for j in range(nf):
+                            src, stride = gather.frame_source(flat, j)
+                            ctx.scatter_tiles(src, images[slot * fpl + j].data_ptr(), (fw, fh), (TILE, TILE), world, stride, 4, side.cuda_stream)
+                    freed[slot] = torch.cuda.Event()
+                    freed[slot].record(side)
+                last_owner[0] = owner
             k += n
 
     # HIP events bracket every launch at N = 1; on the gather path every 7th (a timing event per launch costs ~25 us per step
@@ -379,7 +406,7 @@ def main():
 
     if args.verify:
         verify(ctx, sp, v, views, params, args.steps, nbuf, (last_slot[0] + 1) if submit == "batch" else 0, (fw, fh), bufs, images, gather, rank,
-               (args.steps - 1) % world if rotate else 0)
+               last_owner[0] if submit == "batch" else ((args.steps - 1) % world if rotate else 0))
     if rank != 0:
         if native:
             gather.close()
@@ -399,7 +426,8 @@ def main():
                                                   + (" + ERT" if not args.no_ert else ", no ERT"),
                                                   "imin 0.1 imax 1 gmin 0 gmax 0.2" if args.tf == "app" else "imin 0.1 imax 1 gmin 0 gmax 0 (intensity only)"),
                    "parallelism": "screen tiles 16x16 round-robin over %d GPU(s), RCCL gather to %s" % (
-                       world, "rank k mod N for frame k" if rotate else "rank 0") + (" (vkv_assemble_frame: ncclGather + de-interleave)" if native else " (torch.distributed.gather)")
+                       world, ("rank l mod N for launch l (one gather per launch)" if submit == "batch" else "rank k mod N for frame k") if rotate else "rank 0")
+                   + (" (vkv_assemble_frame: ncclGather + de-interleave)" if native else " (torch.distributed.gather)")
                    if world > 1 else "1 GPU",
                    "output": "RGBA8",
                    "submission": ("vkv_render_batch, up to %d frames per launch, consecutive launches on %d HIP stream(s)" % (fpl, nbs)) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams" % (fif, fif)),
@@ -458,7 +486,7 @@ def verify(ctx, sp, v, views, params, steps, nbuf, fpl, frame, bufs, images, gat
     sp.draw(sp.make_params(*views[k % N_VIEWS], abi.full_frame_tiles(fw, fh, TILE, TILE)), rgba8=direct)
     torch.cuda.synchronize()
     slot = (fpl - 1) if fpl else (k % nbuf)  # batch submission: `fpl` carries the last step's output buffer index + 1
-    got = images[k % nbuf] if gather else bufs[slot].view(fh, fw, 4)
+    got = (images[slot] if fpl else images[k % nbuf]) if gather else bufs[slot].view(fh, fw, 4)
     if not torch.equal(got, direct):
         raise SystemExit("verify failed: assembled frame differs from the direct render in %d bytes" % int((got != direct).sum().item()))
     print("verify ok (rank %d): frame of step %d matches the direct render (%d non-zero bytes)" % (rank, k, int((direct != 0).sum().item())),

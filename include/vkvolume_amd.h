@@ -292,7 +292,10 @@ int vkv_render(vkv_ctx *ctx, const VkvRenderParams *params, void *stream);
 int vkv_render_batch(vkv_ctx *ctx, const VkvRenderParams *params, uint32_t count, void *stream);
 
 /* Root-rank de-interleave of gathered compact tile buffers into the W×H image (multi-GPU):
- * d_gathered holds n_ranks buffers of tiles_per_rank tiles each, bytes_per_pixel per pixel. */
+ * d_gathered holds n_ranks buffers of tiles_per_rank tiles each, bytes_per_pixel per pixel.  tiles_per_rank is only the distance
+ * (in tiles) between the buffers of consecutive ranks: when the frames of a whole vkv_render_batch launch were gathered in one
+ * collective as [rank][frame][tiles], frame f is read with d_gathered + f * (one rank's bytes of a frame) and
+ * tiles_per_rank = frames * (tiles of a rank per frame). */
 int vkv_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, uint32_t image_width,
                       uint32_t image_height, uint32_t tile_width, uint32_t tile_height,
                       uint32_t n_ranks, uint32_t tiles_per_rank, uint32_t bytes_per_pixel, void *stream);

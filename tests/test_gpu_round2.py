@@ -10,7 +10,7 @@ import torch
 from oracle import vkv_oracle as O
 from tests import helpers as T
 from tests.test_gpu_parity import compare_render, gpu_render, make_gpu_volume
-from vkvolume_amd import abi, lib, volume as V
+from vkvolume_amd import abi, lib, multigpu, volume as V
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -347,3 +347,20 @@ def test_render_parity_screen_bound_cases(ctx, case):
         assert int(ref.counts.sum()) == 0
     elif case != "grazing_corner":
         assert int(ref.counts.sum()) > 0
+
+
+@pytest.mark.gpu
+def test_scatter_tiles_reads_one_frame_of_a_gathered_batch(ctx):
+    """The exchange of a whole vkv_render_batch launch (multigpu.BatchTileGather): the owner receives [rank][frame][tiles] and
+    de-interleaves frame f with vkv_scatter_tiles on the block's f-th slice, the rank stride being frames x tiles_per_rank."""
+    world, frames, size, tile = 3, 4, (208, 112), 16
+    g = multigpu.BatchTileGather(None, 1, world, size, tile, 4, device="cuda", frames=frames, n_sets=1, any_root=True)
+    rng = np.random.default_rng(5)
+    flat = torch.from_numpy(rng.integers(0, 256, size=tuple(g.flat[0].shape), dtype=np.uint8)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    for f in range(frames):
+        img = torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda")
+        src, stride = g.frame_source(flat, f)
+        ctx.scatter_tiles(src, img.data_ptr(), size, (tile, tile), world, stride, 4, st)
+        want = multigpu.deinterleave_reference(flat[:, f].cpu().numpy(), size, tile, world)
+        assert np.array_equal(img.cpu().numpy(), want), "frame %d of the batch" % f

@@ -64,6 +64,47 @@ class TileGather:
         return self.flat[b] if self.rank == self.roots[b] else None
 
 
+class BatchTileGather(TileGather):
+    """The exchange of a whole vkv_render_batch launch in ONE collective: every rank sends the compact tile buffers of the launch's
+    frames as one block [frames][tiles_per_rank x tile pixels]; the owner of the launch receives [world][frames][...] and
+    de-interleaves frame f with vkv_scatter_tiles on the block's f-th slice (rank stride = frames x tiles_per_rank tiles).  One
+    gather and one host call per launch instead of one per frame."""
+
+    def __init__(self, dist, rank, world, frame_size, tile=16, bytes_per_pixel=4, device="cuda", frames=8, n_sets=2, any_root=False):
+        import torch
+        super().__init__(dist, rank, world, frame_size, tile, bytes_per_pixel, device, n_buffers=0, any_root=any_root)
+        n = self.tiles_per_rank * tile * tile
+        self.frames = frames
+        self.sets = [torch.zeros((frames, n, bytes_per_pixel), dtype=torch.uint8, device=device) for _ in range(n_sets)]
+        self.buffers = [s[j] for s in self.sets for j in range(frames)]  # buffer of frame j of set b: buffers[b * frames + j]
+        self.flat = None
+        if rank == 0 or any_root:
+            self.flat = [torch.zeros((world, frames, n, bytes_per_pixel), dtype=torch.uint8, device=device) for _ in range(n_sets)]
+        self.works, self.roots, self.counts = [None] * n_sets, [0] * n_sets, [0] * n_sets
+
+    def start(self, b, root=0, n_frames=None):
+        """gather the first n_frames frames of set b to `root` (asynchronous); every rank passes the same root and count"""
+        if root != 0 and not self.any_root:
+            raise ValueError("BatchTileGather was created for rank 0 as the only frame owner")
+        n = self.frames if n_frames is None else n_frames
+        gl = [self.flat[b][r, :n] for r in range(self.world)] if self.rank == root else None
+        self.roots[b], self.counts[b] = root, n
+        self.works[b] = self.dist.gather(self.sets[b][:n], gl, dst=root, async_op=True)
+
+    def finish(self, b):
+        """wait for set b's gather; on its owner returns (flat [world, frames, n, bpp], number of frames), elsewhere None"""
+        if self.works[b] is None:
+            return None
+        self.works[b].wait()
+        self.works[b] = None
+        return (self.flat[b], self.counts[b]) if self.rank == self.roots[b] else None
+
+    def frame_source(self, flat, f):
+        """(device pointer, rank stride in tiles) that make vkv_scatter_tiles read frame f of a gathered launch"""
+        per_rank_bytes = self.tiles_per_rank * self.tile * self.tile * self.bpp
+        return flat.data_ptr() + f * per_rank_bytes, self.frames * self.tiles_per_rank
+
+
 class NativeExchange:
     """The exchange step through the product's C ABI: ``vkv_assemble_frame`` = ``ncclGather`` (RCCL over xGMI) of the compact tile
     buffers to the frame's owner + de-interleave there, enqueued on a HIP stream — no torch.distributed on the data path.
