@@ -2,6 +2,7 @@
 stream re-entrancy of one context, several volumes in one subpass, a reloaded Volume object."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -364,3 +365,18 @@ def test_scatter_tiles_reads_one_frame_of_a_gathered_batch(ctx):
         ctx.scatter_tiles(src, img.data_ptr(), size, (tile, tile), world, stride, 4, st)
         want = multigpu.deinterleave_reference(flat[:, f].cpu().numpy(), size, tile, world)
         assert np.array_equal(img.cpu().numpy(), want), "frame %d of the batch" % f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["VKV_RAYMARCH_LUT=0", "VKV_RAYMARCH_LUT=2", "VKV_RAYMARCH_CULL=0", "VKV_RAYMARCH_TILE_ORDER=linear"])
+def test_render_parity_under_each_kernel_selection_switch(switch):
+    """The launcher picks one of three instantiations of the integrator (footprint address in registers / two-level LDS tables / one
+    entry per voxel index), a tile start order and the screen bound by itself; small test volumes always get the same choice.  The
+    library reads these A/B switches once per process, so the render parity tests are re-run in a child process under each of them."""
+    name, value = switch.split("=")
+    env = dict(os.environ, **{name: value})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-x", "-q", "-k", "render", "-p", "no:cacheprovider"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "%s:\n%s\n%s" % (switch, r.stdout[-3000:], r.stderr[-1000:])
+    assert " passed" in r.stdout
