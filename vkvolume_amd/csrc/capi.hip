@@ -213,6 +213,7 @@ int vkv_create(int device_ordinal, vkv_ctx **out_ctx)
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
 	ctx->device   = device_ordinal;
+	ctx->cu_count = prop.multiProcessorCount;
 	ctx->error[0] = 0;
 	ctx->d_trace  = nullptr;
 	*out_ctx      = ctx;        // the caller's current device is left as it is: every entry point switches to ctx->device itself

@@ -274,23 +274,9 @@ static void launch_batch_ert(bool ert, int grad, const RayMarchArgs *d_frames, u
 template <int SKIP, bool ERT, int GRAD, uint32_t LF>
 static uint32_t launch_pull_one(vkv_ctx *ctx, const RayMarchArgs *d_frames, uint32_t n, uint32_t *d_heads, size_t lds, uint64_t units, hipStream_t s)
 {
-	static int    per_cu = 0, cus = 0;        // per instantiation and LDS size; the device of a context does not change
-	static size_t per_cu_lds = 0;
-	if (per_cu == 0 || per_cu_lds != lds)
-	{
-		hipDeviceProp_t prop;
-		int             blocks = 0;
-		if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess ||
-		    hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_raymarch_lean_pull<SKIP, ERT, GRAD, LF>, 256, lds) != hipSuccess || blocks < 1)
-			return 0;
-		per_cu = blocks, cus = prop.multiProcessorCount, per_cu_lds = lds;
-	}
-	// eight workgroups of four waves fill a CU's 32 wave slots; should the occupancy be lower than that, the surplus workgroups start
-	// when others have finished and take what tickets are left
-	static const bool debug = std::getenv("VKV_DEBUG") != nullptr;
-	if (debug)
-		std::fprintf(stderr, "[vkv] k_raymarch_lean_pull: occupancy API %d workgroups per CU, %d CUs, lds %zu\n", per_cu, cus, lds);
-	const uint64_t resident = (uint64_t) 8 * (uint64_t) cus;
+	// eight workgroups of four waves fill a CU's 32 wave slots (this instantiation is held to 64 VGPRs); should fewer fit, the surplus
+	// workgroups start when others have finished and take what tickets are left
+	const uint64_t resident = (uint64_t) 8 * (uint64_t) std::max(1, ctx->cu_count);
 	const uint32_t grid     = (uint32_t) std::max<uint64_t>(8, std::min<uint64_t>(resident, (units + 3) / 4));
 	hipLaunchKernelGGL((k_raymarch_lean_pull<SKIP, ERT, GRAD, LF>), dim3(grid), dim3(256), lds, s, d_frames, n, d_heads);
 	return grid;

@@ -127,6 +127,7 @@ __host__ __device__ __forceinline__ size_t packed_brick_offset(int bx, int by, i
 struct vkv_ctx
 {
 	int   device;
+	int   cu_count;        // compute units of the device (grid of the resident-workgroup kernels)
 	char  error[512];
 	void *d_trace;        // diagnostic wave timeline buffer (vkv_debug_trace), normally null
 	std::mutex                                 mutex;
