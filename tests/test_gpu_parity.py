@@ -430,7 +430,7 @@ def test_render_depth_attachment_and_blending(ctx, shell_scene, skipping_type, b
 # ------------------------------------------------------------------------------------------------------
 # randomised configurations: every knob of the path drawn at random, HIP vs oracle
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(36))
 def test_render_fuzz(ctx, seed):
     """Random volume shape / content, voxel size and rotation, TF window, sampling and alpha factors, block size, skipping mode, ERT,
     gradient variant, clip distance, camera (sometimes inside the box) and frame size: counters bit-exact, colour and depth within the
@@ -462,6 +462,12 @@ def test_render_fuzz(ctx, seed):
     size = (int(rng.integers(3, 9)) * 16 - int(rng.integers(0, 16)), int(rng.integers(2, 6)) * 16 - int(rng.integers(0, 16)))
     radius = float(rng.choice([30.0, 60.0, 110.0, 150.0, 260.0]))  # the node is scaled to 100 units: 30 / 60 put the camera inside or at the box
     view, proj = T.orbit(float(rng.uniform(0, 360)), elevation=float(rng.uniform(-80, 80)), radius=radius, fov=float(rng.uniform(25, 100)), image_size=size)
+    if seed >= 24:
+        # the camera orbits (and looks at) a point beside the volume: the box is off-centre, partly or wholly outside the frame - what
+        # the launcher's screen bound of the box has to get right
+        from vkvolume_amd import camera as _camera
+        centre = tuple(float(x) for x in rng.uniform(-75.0, 75.0, size=3))
+        view = _camera.orbit_camera(float(rng.uniform(0, 360)), float(rng.uniform(-80, 80)), radius, centre)
     opts = abi.RenderOptions(skipping_type=st, clip_distance=float(rng.choice([0.1, 1.0, 1.0, 20.0, 70.0])), early_ray_termination=bool(rng.integers(0, 2)))
     params = scene.params(view, proj, size, opts)
     ref = scene.render(params)
