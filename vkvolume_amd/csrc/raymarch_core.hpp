@@ -1389,6 +1389,9 @@ constexpr uint32_t kLeanFloatI  = 2048u;     // the loop position, its bounds an
                                              // conversion at the head of every iteration, a float max / add for the skip
 constexpr uint32_t kLeanWb      = 4096u;     // kLeanKeep through a wave barrier (a convergent no-op the compiler cannot thread a jump through) instead of
                                              // a predicate laundered through a register (v_cndmask + v_cmp per iteration)
+constexpr uint32_t kLeanFloatCell = 8192u;   // cell coordinates clamped in float (floor + med3) and the linear cell index from two fmas + one conversion:
+                                             // the probe's (float) ui - u needs no int -> float conversions.  Exact while the map has
+                                             // fewer than 2^24 cells (the launcher checks)
 constexpr uint32_t kLeanDefault = 1u | 8u | 16u;        // kLeanUniform | kLeanBranch | kLeanCvt: what the product launches (+ kLeanLut when the tables fit)
 constexpr size_t   kMaxLutBytes = 8 * 1024;           // LDS budget of the address tables (1.2 KB at 1024 voxels per axis, 1.9 KB at 2048)
 constexpr uint32_t kLeanCvt     = 16u;       // cost-aware instruction selection (tools/micro/valu_mix.hip): float subtraction of two converted bytes
@@ -1569,12 +1572,14 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	constexpr bool kHoist = PACKED && GRAD != 2;
 	constexpr bool kUni = (LF & kLeanUniform) != 0, kNt = (LF & kLeanNt) != 0, kLut = (LF & kLeanLut) != 0, kBranch = (LF & kLeanBranch) != 0,
 	               kCvt = (LF & kLeanCvt) != 0, kNest = (LF & kLeanNest) != 0 && kBranch, kKeep = (LF & kLeanKeep) != 0, kScalar = (LF & kLeanScalar) != 0, kFull = (LF & kLeanFull) != 0 && SEP, kTf = (LF & kLeanTf) != 0 && SEP && kHoist && kCvt,
-	               kGradSkip = (LF & kLeanGradSkip) != 0 && kTf && GRAD == 1, kFloatI = (LF & kLeanFloatI) != 0 && kBranch, kWb = (LF & kLeanWb) != 0;
+	               kGradSkip = (LF & kLeanGradSkip) != 0 && kTf && GRAD == 1, kFloatI = (LF & kLeanFloatI) != 0 && kBranch, kWb = (LF & kLeanWb) != 0,
+	               kFloatCell = (LF & kLeanFloatCell) != 0 && SKIP != VKV_SKIP_NONE;
 	using idx_t = std::conditional_t<kFloatI, float, int>;
 	const int   W = A.W, H = A.H, D = A.D;
 	const float kx = SKIP != VKV_SKIP_NONE ? (float) W / A.block_size[0] : 0.0f, ky = SKIP != VKV_SKIP_NONE ? (float) H / A.block_size[1] : 0.0f,
 	            kz = SKIP != VKV_SKIP_NONE ? (float) D / A.block_size[2] : 0.0f;
 	const int   mw1 = A.mw - 1, mh1 = A.mh - 1, md1 = A.md - 1;
+	const float fmw1 = (float) mw1, fmh1 = (float) mh1, fmd1 = (float) md1, fmw = (float) A.mw, fmh = (float) A.mh;
 	float    grey = 0.0f;
 	uint32_t ul   = 0;
 	bool     occ  = true, done = false;
@@ -1591,12 +1596,18 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		const float fi = (float) i;
 		const float posx = __builtin_fmaf(fi, R.sx, R.ex), posy = __builtin_fmaf(fi, R.sy, R.ey), posz = __builtin_fmaf(fi, R.sz, R.ez);
 		int         uix = 0, uiy = 0, uiz = 0;
-		float       ux = 0, uy = 0, uz = 0;
+		float       ux = 0, uy = 0, uz = 0, fuix = 0, fuiy = 0, fuiz = 0;
 		uint32_t    cell = 0;
 		if (SKIP != VKV_SKIP_NONE)
 		{        // frag:192, 220-221
 			ux = kx * posx, uy = ky * posy, uz = kz * posz;
-			if (kScalar)
+			if (kFloatCell)
+			{        // clamp(trunc(u), 0, m - 1) == clamp(floor(u), 0, m - 1): they differ only for u in (-1, 0), where both clamp to 0
+				fuix = __builtin_amdgcn_fmed3f(__builtin_floorf(ux), 0.0f, fmw1), fuiy = __builtin_amdgcn_fmed3f(__builtin_floorf(uy), 0.0f, fmh1);
+				fuiz = __builtin_amdgcn_fmed3f(__builtin_floorf(uz), 0.0f, fmd1);
+				cell = (uint32_t) __builtin_fmaf(__builtin_fmaf(fuiz, fmh, fuiy), fmw, fuix);        // integers below 2^24: exact
+			}
+			else if (kScalar)
 			{
 				uix = clamp0_i32((int) ux, mw1), uiy = clamp0_i32((int) uy, mh1), uiz = clamp0_i32((int) uz, md1);
 				cell = mad_u24(mad_u24((uint32_t) uiz, (uint32_t) A.mh, (uint32_t) uiy), (uint32_t) A.mw, (uint32_t) uix);
@@ -1635,9 +1646,9 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		// ---- probe outcome (frag:234-247); needs the probe byte only ---------------------------------------------------
 		idx_t skip = 0;
 		auto  probe_outcome = [&]() {
-			const float rx = __builtin_amdgcn_fmed3f((float) uix - ux, -1.0f, 0.0f);
-			const float ry = __builtin_amdgcn_fmed3f((float) uiy - uy, -1.0f, 0.0f);
-			const float rz = __builtin_amdgcn_fmed3f((float) uiz - uz, -1.0f, 0.0f);
+			const float rx = __builtin_amdgcn_fmed3f((kFloatCell ? fuix : (float) uix) - ux, -1.0f, 0.0f);
+			const float ry = __builtin_amdgcn_fmed3f((kFloatCell ? fuiy : (float) uiy) - uy, -1.0f, 0.0f);
+			const float rz = __builtin_amdgcn_fmed3f((kFloatCell ? fuiz : (float) uiz) - uz, -1.0f, 0.0f);
 			float       ax, ay, az;
 			if (SKIP == VKV_SKIP_BLOCK)
 			{
