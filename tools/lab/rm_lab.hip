@@ -78,6 +78,7 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 		case 20: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb>(a, s);
 		case 21: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI>(a, s);
 		case 22: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanFloatCell>(a, s);
+		case 23: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanPrefetch>(a, s);
 		case 17: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanFull>(a, s);
 		case 6: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanLut | kLeanBranch | kLeanCvt>(a, s);
 #ifdef LAB_ALL

@@ -1392,6 +1392,9 @@ constexpr uint32_t kLeanWb      = 4096u;     // kLeanKeep through a wave barrier
 constexpr uint32_t kLeanFloatCell = 8192u;   // cell coordinates clamped in float (floor + med3) and the linear cell index from two fmas + one conversion:
                                              // the probe's (float) ui - u needs no int -> float conversions.  Exact while the map has
                                              // fewer than 2^24 cells (the launcher checks)
+constexpr uint32_t kLeanPrefetch = 16384u;   // a lane that samples position i while its previous sample was occupied also requests the footprint of i + 1 (the
+                                             // next event if this sample is occupied too); used an iteration later if the prediction held, dropped otherwise.
+                                             // Shortens the dependent chain of one wave, costs address arithmetic for every wrong prediction
 constexpr uint32_t kLeanDefault = 1u | 8u | 16u;        // kLeanUniform | kLeanBranch | kLeanCvt: what the product launches (+ kLeanLut when the tables fit)
 constexpr size_t   kMaxLutBytes = 8 * 1024;           // LDS budget of the address tables (1.2 KB at 1024 voxels per axis, 1.9 KB at 2048)
 constexpr uint32_t kLeanCvt     = 16u;       // cost-aware instruction selection (tools/micro/valu_mix.hip): float subtraction of two converted bytes
@@ -1573,7 +1576,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	constexpr bool kUni = (LF & kLeanUniform) != 0, kNt = (LF & kLeanNt) != 0, kLut = (LF & kLeanLut) != 0, kBranch = (LF & kLeanBranch) != 0,
 	               kCvt = (LF & kLeanCvt) != 0, kNest = (LF & kLeanNest) != 0 && kBranch, kKeep = (LF & kLeanKeep) != 0, kScalar = (LF & kLeanScalar) != 0, kFull = (LF & kLeanFull) != 0 && SEP, kTf = (LF & kLeanTf) != 0 && SEP && kHoist && kCvt,
 	               kGradSkip = (LF & kLeanGradSkip) != 0 && kTf && GRAD == 1, kFloatI = (LF & kLeanFloatI) != 0 && kBranch, kWb = (LF & kLeanWb) != 0,
-	               kFloatCell = (LF & kLeanFloatCell) != 0 && SKIP != VKV_SKIP_NONE;
+	               kFloatCell = (LF & kLeanFloatCell) != 0 && SKIP != VKV_SKIP_NONE, kPrefetch = (LF & kLeanPrefetch) != 0 && kHoist && kNest;
 	using idx_t = std::conditional_t<kFloatI, float, int>;
 	const int   W = A.W, H = A.H, D = A.D;
 	const float kx = SKIP != VKV_SKIP_NONE ? (float) W / A.block_size[0] : 0.0f, ky = SKIP != VKV_SKIP_NONE ? (float) H / A.block_size[1] : 0.0f,
@@ -1590,6 +1593,9 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		fullc = full_lut_consts(A);
 	idx_t       li = (idx_t) R.i, li_min = (idx_t) R.i_min, lfirst = (idx_t) R.first_hit;
 	const idx_t ln = (idx_t) R.n_steps, lback = (idx_t) A.back;
+	uint32_t pq00 = 0, pq10 = 0, pq01 = 0, pq11 = 0;        // kPrefetch: the footprint of position pf_i, requested one iteration ahead
+	float    pwx = 0, pwy = 0, pwz = 0;
+	idx_t    pf_i = (idx_t) -1;
 	while (!done)
 	{
 		const idx_t i  = li;
@@ -1630,15 +1636,35 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		}
 		if (SKIP != VKV_SKIP_NONE && probe)
 			dist = load_u8_global(R.dmap, cell);
+		auto footprint_of = [&](float px_, float py_, float pz_, float &ox, float &oy, float &oz) {
+			return kFull ? packed_footprint_full(fullc, L, px_, py_, pz_, ox, oy, oz)
+			       : kLut ? packed_footprint_lut<kScalar>(A, px_, py_, pz_, ox, oy, oz)
+			              : packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, px_, py_, pz_, ox, oy, oz);
+		};
 		if (kHoist && !probe)
 		{
-			const uint8_t *ba = kFull ? packed_footprint_full(fullc, L, posx, posy, posz, wx, wy, wz)
-			                    : kLut ? packed_footprint_lut<kScalar>(A, posx, posy, posz, wx, wy, wz)
-			                         : packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, wx, wy, wz);
-			q00 = load_row<kNt>(ba);
-			q10 = load_row<kNt>(ba + 10);
-			q01 = load_row<kNt>(ba + 50);
-			q11 = load_row<kNt>(ba + 60);
+			if (kPrefetch && pf_i == i)
+				q00 = pq00, q10 = pq10, q01 = pq01, q11 = pq11, wx = pwx, wy = pwy, wz = pwz;        // requested an iteration ago
+			else
+			{
+				const uint8_t *ba = footprint_of(posx, posy, posz, wx, wy, wz);
+				q00 = load_row<kNt>(ba);
+				q10 = load_row<kNt>(ba + 10);
+				q01 = load_row<kNt>(ba + 50);
+				q11 = load_row<kNt>(ba + 60);
+			}
+		}
+		if (kPrefetch)
+		{
+			if (!probe && occ && i + (idx_t) 1 < ln)
+			{
+				const float    fn = (float) (i + (idx_t) 1);
+				const uint8_t *bn = footprint_of(__builtin_fmaf(fn, R.sx, R.ex), __builtin_fmaf(fn, R.sy, R.ey), __builtin_fmaf(fn, R.sz, R.ez), pwx, pwy, pwz);
+				pq00 = load_row<kNt>(bn), pq10 = load_row<kNt>(bn + 10), pq01 = load_row<kNt>(bn + 50), pq11 = load_row<kNt>(bn + 60);
+				pf_i = i + (idx_t) 1;
+			}
+			else
+				pf_i = (idx_t) -1;
 		}
 		// a wave whose live lanes all probe (the empty space in front of the volume) or all sample skips the other kind's arithmetic
 		const bool any_probe = !kUni || kNest || __builtin_amdgcn_ballot_w64(probe) != 0ull, any_sample = !kUni || kNest || SKIP == VKV_SKIP_NONE || __builtin_amdgcn_ballot_w64(!probe) != 0ull;
