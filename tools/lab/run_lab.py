@@ -23,7 +23,7 @@ from vkvolume_amd import abi, lib, volume as V  # noqa: E402
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 flags = [a for a in sys.argv[1:] if a.startswith("--")]
 name = args[0] if args else "c3"
-variants = [int(x) for x in args[1].split(",")] if len(args) > 1 else [0, 11, 12, 14, 21, 22, 24]
+variants = [int(x) for x in args[1].split(",")] if len(args) > 1 else [0, 13, 16, 21, 23]  # older ids need -DLAB_ALL (tools/lab/Makefile)
 dense = "--dense" in flags
 
 torch.cuda.set_device(0)
