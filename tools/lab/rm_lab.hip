@@ -88,32 +88,33 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 		case 4: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanBranch>(a, s);
 		case 5: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanCvt>(a, s);
 		case 7: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanLut | kLeanCvt>(a, s);
-		case 11: return launch_er<SKIP, ERT, GRAD, true, 1, 0>(a, s);
-		case 12: return launch_er<SKIP, ERT, GRAD, true, 2, 0>(a, s);
-		case 14: return launch_er<SKIP, ERT, GRAD, true, 4, 0>(a, s);
-		case 18: return launch_er<SKIP, ERT, GRAD, true, 8, 0>(a, s);
-		case 21: return launch_er<SKIP, ERT, GRAD, true, 1, kErFull>(a, s);
-		case 22: return launch_er<SKIP, ERT, GRAD, true, 2, kErFull>(a, s);
-		case 24: return launch_er<SKIP, ERT, GRAD, true, 4, kErFull>(a, s);
-		case 41: return launch_er<SKIP, ERT, GRAD, true, 1, kErMasked>(a, s);
-		case 42: return launch_er<SKIP, ERT, GRAD, true, 2, kErMasked>(a, s);
-		case 51: return launch_er<SKIP, ERT, GRAD, true, 1, kErMasked | kErStamp>(a, s);
-		case 52: return launch_er<SKIP, ERT, GRAD, true, 2, kErMasked | kErStamp>(a, s);
-		case 61: return launch_er<SKIP, ERT, GRAD, true, 1, kErCache16>(a, s);
-		case 62: return launch_er<SKIP, ERT, GRAD, true, 2, kErCache16>(a, s);
-		case 71: return launch_er<SKIP, ERT, GRAD, true, 1, kErCache32>(a, s);
-		case 72: return launch_er<SKIP, ERT, GRAD, true, 2, kErCache32>(a, s);
-		case 81: return launch_er<SKIP, ERT, GRAD, true, 1, kErCache32 | kErStamp>(a, s);
-		case 31: return launch_er<SKIP, ERT, GRAD, true, 1, kErStamp>(a, s);
-		case 32: return launch_er<SKIP, ERT, GRAD, true, 2, kErStamp>(a, s);
-		case 34: return launch_er<SKIP, ERT, GRAD, true, 4, kErStamp>(a, s);
+		case 211: return launch_er<SKIP, ERT, GRAD, true, 1, 0>(a, s);
+		case 212: return launch_er<SKIP, ERT, GRAD, true, 2, 0>(a, s);
+		case 214: return launch_er<SKIP, ERT, GRAD, true, 4, 0>(a, s);
+		case 218: return launch_er<SKIP, ERT, GRAD, true, 8, 0>(a, s);
+		case 221: return launch_er<SKIP, ERT, GRAD, true, 1, kErFull>(a, s);
+		case 222: return launch_er<SKIP, ERT, GRAD, true, 2, kErFull>(a, s);
+		case 224: return launch_er<SKIP, ERT, GRAD, true, 4, kErFull>(a, s);
+		case 241: return launch_er<SKIP, ERT, GRAD, true, 1, kErMasked>(a, s);
+		case 242: return launch_er<SKIP, ERT, GRAD, true, 2, kErMasked>(a, s);
+		case 251: return launch_er<SKIP, ERT, GRAD, true, 1, kErMasked | kErStamp>(a, s);
+		case 252: return launch_er<SKIP, ERT, GRAD, true, 2, kErMasked | kErStamp>(a, s);
+		case 261: return launch_er<SKIP, ERT, GRAD, true, 1, kErCache16>(a, s);
+		case 262: return launch_er<SKIP, ERT, GRAD, true, 2, kErCache16>(a, s);
+		case 271: return launch_er<SKIP, ERT, GRAD, true, 1, kErCache32>(a, s);
+		case 272: return launch_er<SKIP, ERT, GRAD, true, 2, kErCache32>(a, s);
+		case 281: return launch_er<SKIP, ERT, GRAD, true, 1, kErCache32 | kErStamp>(a, s);
+		case 231: return launch_er<SKIP, ERT, GRAD, true, 1, kErStamp>(a, s);
+		case 232: return launch_er<SKIP, ERT, GRAD, true, 2, kErStamp>(a, s);
+		case 234: return launch_er<SKIP, ERT, GRAD, true, 4, kErStamp>(a, s);
 #endif
 		default: return -100;
 	}
 }
 }        // namespace
 
-// variant = 10 + W: evaluate+replay, W lanes per ray; 20 + W: every lane loads both kinds; 30 + W: stamped diagnostic build.
+// LAB_ALL variants = 200 + the ids of the first half of profiles/r2_lab_variants.txt: 210 + W evaluate+replay with W lanes per ray;
+// 220 + W: every lane loads both kinds; 230 + W: stamped diagnostic build; 24x masked loads; 26x / 27x brick cache.
 // Only the bench configurations are instantiated: (distance ESS, ERT, precomputed gradient, packed) and (no ESS, no ERT, ...).
 extern "C" int vkv_lab_render(vkv_ctx *ctx, const VkvRenderParams *P, int variant, void *stream)
 {

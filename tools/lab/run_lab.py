@@ -147,7 +147,7 @@ for var in variants:
     del bb, b
 
 if "--stamps" in flags:
-    for var in [int(x) for x in os.environ.get("LAB_STAMP_VARIANTS", "31,32,34").split(",")]:
+    for var in [int(x) for x in os.environ.get("LAB_STAMP_VARIANTS", "231,232,234").split(",")]:
         p = params[0]
         b = bufs()
         set_outputs(p, b, only_rgba8=True)
