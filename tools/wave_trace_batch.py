@@ -58,3 +58,8 @@ if t[:, 4].max() > 0:
         (su - start)[big].mean(), (ma - su)[big].mean(), ((ma - su)[big] / it[big]).mean(), (end - ma)[big].mean()))
     for i in order[:6]:
         print("   tail unit: set-up %.1f march %.1f write-out %.1f" % (su[i] - start[i], ma[i] - su[i], end[i] - ma[i]))
+if t.shape[1] > 7 and t[:, 7].max() > 0:
+    long = (end - start) > 50.0
+    if long.any():
+        mhz = (t[long, 7] - t[long, 6]) / (end[long] - start[long])  # shader-clock ticks per microsecond
+        print("shader clock seen by waves that ran > 50 us: median %.0f MHz (p10 %.0f, p90 %.0f)" % tuple(np.percentile(mhz, [50, 10, 90])))

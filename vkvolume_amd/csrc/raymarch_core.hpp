@@ -1950,6 +1950,7 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 	Ray R;
 	R.o = o;
 	const unsigned long long t_start = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+	const unsigned long long c_start = A.trace ? __builtin_amdgcn_s_memtime() : 0ull;        // shader clock (with t_start: the clock rate under load)
 	bool marched = false;
 	if (inside)
 	{        // pixels outside the screen bound of the volume's box skip the ray set-up (a third of a C3 frame)
@@ -1991,7 +1992,8 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 		{
 			unsigned long long *rec = A.trace + ((size_t) blockIdx.x * WPB + wave) * kTraceWords;        // per launch (a batch: all its frames)
 			rec[0] = t_start, rec[1] = t_end, rec[2] = it, rec[3] = ((unsigned long long) __builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (k * A.blocks_per_tile + sb);
-			for (int w = 4; w < kTraceWords; ++w)
+			rec[4] = 0, rec[5] = 0, rec[6] = c_start, rec[7] = __builtin_amdgcn_s_memtime();
+			for (int w = 8; w < kTraceWords; ++w)
 				rec[w] = 0;
 		}
 	}
