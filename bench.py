@@ -92,6 +92,17 @@ def build_scene(ctx, name, tf_preset="app"):
     return v, tf, frame, skip
 
 
+def split_frames(n_steps, frames_per_launch):
+    """Frames of a block of n_steps spread evenly over ceil(n_steps / frames_per_launch) launches (20 steps, 8 per launch: 7 + 7 + 6)."""
+    n_launches = -(-n_steps // frames_per_launch)
+    out, k = [], 0
+    for launch in range(n_launches):
+        n = (n_steps - k + (n_launches - launch) - 1) // (n_launches - launch)
+        out.append(n)
+        k += n
+    return out
+
+
 def occupied_voxel_percent(ctx, v, tf):
     """the reference's benchmark-mode statistic (src/volume_render.cpp:399-414): % voxels with analytic TF alpha > 0"""
     count = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -256,10 +267,7 @@ def main():
 
     def run_batch(n_steps, timed):
         k, launch = 0, 0
-        n_launches = -(-n_steps // fpl)
-        while k < n_steps:
-            # the frames of a block are spread evenly over its launches (20 steps with 8 per launch: 7 + 7 + 6, not 8 + 8 + 4)
-            n = (n_steps - k + (n_launches - launch) - 1) // (n_launches - launch)
+        for n in split_frames(n_steps, fpl):  # 20 steps with 8 per launch: 7 + 7 + 6, not 8 + 8 + 4
             st = streams[launch % nbs]  # stream of this launch
             slot = (launch % nsets) if gather else (launch % nbs)  # its set of output buffers
             owner = (launch % world) if rotate else 0  # gather path: the rank that assembles this launch's frames

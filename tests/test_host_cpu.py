@@ -163,3 +163,15 @@ def test_loader_c_abi_matches_oracle_loader(tmp_path):
     (tmp_path / "f32.raw").write_bytes(b"\0" * 4)
     with pytest.raises(RuntimeError):
         lib.load_data(str(tmp_path / "f32.raw"), lib.load_header(str(tmp_path / "f32.raw.header")))  # unsupported type
+
+
+def test_bench_spreads_the_frames_of_a_block_evenly_over_its_launches():
+    import bench
+    assert bench.split_frames(20, 8) == [7, 7, 6]
+    assert bench.split_frames(256, 8) == [8] * 32
+    assert bench.split_frames(5, 8) == [5]
+    assert bench.split_frames(17, 8) == [6, 6, 5]
+    for steps in range(1, 70):
+        for fpl in (1, 3, 8, 12, 32):
+            parts = bench.split_frames(steps, fpl)
+            assert sum(parts) == steps and max(parts) <= fpl and max(parts) - min(parts) <= 1 and len(parts) == -(-steps // fpl)
