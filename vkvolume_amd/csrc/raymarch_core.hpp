@@ -794,11 +794,11 @@ __global__ void __launch_bounds__(256) k_raymarch_persistent(const RayMarchArgs 
 // alpha byte comes from ai[] x ag[], its colour contribution from pair[]; otherwise the alpha > 0 bit table gates the RGBA fetch.
 struct RmLds
 {
-	float alpha[256];        // opacity correction keyed by the alpha byte (frag:283)
 	union
 	{
 		struct
 		{
+			float    alpha[256];        // opacity correction keyed by the alpha byte (frag:283)
 			uint32_t bits[2048];
 			float    unorm[256];        // byte / 255 (exact IEEE division)
 		} g;
@@ -806,7 +806,7 @@ struct RmLds
 		{
 			float  ai[258], ag[258];        // entry 256 repeats entry 255: int(u * 256) of u = 1.0 needs no clamp (kLeanTf)
 			float2 pair[256];               // {alpha_lut[b], (b / 255) * alpha_lut[b]}: corrected opacity and premultiplied grey of alpha byte b
-		} s;
+		} s;        // 4 112 bytes: the rest of the block (and the dynamic segment behind it) holds the full address tables (kLeanFull)
 	};
 };
 
@@ -821,7 +821,8 @@ __device__ __forceinline__ bool stage_tables_er(const RayMarchArgs &A, RmLds &L)
 	for (int i = threadIdx.x; i < 256; i += blockDim.x)
 	{
 		const float a = A.alpha_lut[i];
-		L.alpha[i]    = a;
+		if (!sep)
+			L.g.alpha[i] = a;
 		if (sep)
 		{
 			L.s.ai[i]   = __uint_as_float(A.tf_bits[kTfAiWord + i]);
@@ -1131,7 +1132,7 @@ __device__ __forceinline__ void er_evaluate(const RayMarchArgs &A, const Ray &R,
 		else if (want_sample)
 			texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
 		texel = (texel >> 24) ? texel : 0u;
-		E.tx = texel, E.a = L.alpha[texel >> 24], E.c = 0.0f;
+		E.tx = texel, E.a = L.g.alpha[texel >> 24], E.c = 0.0f;
 	}
 }
 
@@ -1480,55 +1481,49 @@ __device__ __forceinline__ const uint8_t *packed_footprint_lut(const RayMarchArg
 	return reinterpret_cast<const uint8_t *>(zm + (((xi + xm) + (yi + ym)) + zi));
 }
 
-// kLeanFull — one table entry per padded voxel index and axis, so an axis costs one LDS read and no shift / mask / add: X[W + 2] and
-// Y[H + 2] 32-bit byte offsets, Z[D + 2] 64-bit addresses inside the packed image.  Built by the workgroup from the two-level tables
-// (each entry = in-macro term + macro term).  14.6 KB at 1024 x 1024 x 795: too much on top of the transfer-function tables, so they
-// are only used with the separable transfer function, whose tables leave the second half of RmLds (the bit table of the general
-// path) free: the full tables start there and run on into the dynamic segment (which begins where the static one ends).
-constexpr uint32_t kFullLutWord  = 1284;         // = (offsetof(RmLds, s) + sizeof(RmLds::s)) / 4, checked below
+// kLeanFull — one table entry per padded voxel index and axis, so an axis costs one LDS read and no shift / mask / add: X[W + 2],
+// Y[H + 2], Z[D + 2], 32-bit offsets in units of TWO bytes (every term is even; a packed image of up to 8 GiB).  Built by the workgroup
+// from the two-level tables (each entry = in-macro term + macro term).  11.4 KB at 1024 x 1024 x 795: too much on top of the general
+// transfer-function tables, so they are only used with the separable transfer function, whose tables end 4 112 bytes into RmLds: the
+// full tables start there and run on into the dynamic segment (which begins where the static one ends).  Small on purpose: a workgroup
+// keeps its LDS until its longest wave is done, so the LDS per workgroup decides how many waves a CU holds on average.
+constexpr uint32_t kFullLutWord  = 1028;         // = sizeof(RmLds::s) / 4, checked below
 __host__ __device__ __forceinline__ bool map_fits_u24(uint32_t mw, uint32_t mh, uint32_t md) { return (uint64_t) mh * md < (1ull << 24) && mw < (1u << 24); }
-constexpr size_t   kFullLdsLimit = 20 * 1024;        // static + dynamic LDS of a workgroup that still lets 8 workgroups share a CU
+constexpr size_t   kFullLdsLimit = 17920;        // static + dynamic LDS of a workgroup that still lets 9 workgroups share a CU
 
-__host__ __device__ __forceinline__ size_t full_lut_bytes(int W, int H, int D) { return (size_t) (W + 2 + H + 2 + ((W + H) & 1)) * 4 + (size_t) (D + 2) * 8; }
+__host__ __device__ __forceinline__ size_t full_lut_bytes(int W, int H, int D) { return (size_t) (W + 2 + H + 2 + D + 2) * 4; }
 
 __device__ __forceinline__ uint32_t *full_lut_base(const RmLds &L) { return const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(&L)) + kFullLutWord; }
 
 __device__ __forceinline__ void stage_full_lut(const RayMarchArgs &A, RmLds &L)
 {
-	static_assert(offsetof(RmLds, s) + sizeof(((RmLds *) nullptr)->s) == kFullLutWord * 4, "full tables start behind the separable TF tables");
+	static_assert(sizeof(((RmLds *) nullptr)->s) == kFullLutWord * 4, "full tables start behind the separable TF tables");
 	const uint32_t  nx = (uint32_t) A.W + 2u, ny = (uint32_t) A.H + 2u, nz = (uint32_t) A.D + 2u;
-	uint32_t *      fx = full_lut_base(L), *fy = fx + nx;
-	uint64_t *      fz = reinterpret_cast<uint64_t *>(fx + ((nx + ny + 1u) & ~1u));
+	uint32_t *      fx = full_lut_base(L), *fy = fx + nx, *fz = fy + ny;
 	const uint32_t *g  = A.addr_lut;
-	const uint64_t  base = reinterpret_cast<uint64_t>(A.packed);
 	for (uint32_t b = threadIdx.x; b < nx; b += blockDim.x)
-		fx[b] = g[b & 31u] + g[kLutXm + (b >> 5)];
+		fx[b] = (g[b & 31u] + g[kLutXm + (b >> 5)]) >> 1;
 	for (uint32_t b = threadIdx.x; b < ny; b += blockDim.x)
-		fy[b] = g[32u + (b & 31u)] + g[A.lut_y + (b >> 5)];
+		fy[b] = (g[32u + (b & 31u)] + g[A.lut_y + (b >> 5)]) >> 1;
 	for (uint32_t b = threadIdx.x; b < nz; b += blockDim.x)
-		fz[b] = base + ((((uint64_t) g[A.lut_z + 2u * (b >> 5) + 1u]) << 32) | g[A.lut_z + 2u * (b >> 5)]) + g[64u + (b & 31u)];
-}
-
-__device__ __forceinline__ float clamp_m1_f32(float x, float hi)
-{        // clamp(x, -1, hi), hi wave-uniform: the bounds cost no register and no move inside the loop
-	float r;
-	asm("v_med3_f32 %0, %1, -1.0, %2" : "=v"(r) : "v"(x), "s"(hi));
-	return r;
+		fz[b] = (uint32_t) ((((((uint64_t) g[A.lut_z + 2u * (b >> 5) + 1u]) << 32) | g[A.lut_z + 2u * (b >> 5)]) + g[64u + (b & 31u)]) >> 1);
 }
 
 // Loop-invariant operands of packed_footprint_full, worked out once per ray.  They pass through an empty asm so that the compiler keeps
 // them in registers: in the batch kernel (arguments in memory) it otherwise re-loads W, H, D and converts them again in every iteration.
 struct FullLutConsts
 {
-	float w, h, d, oy, oz;
+	float          w, h, d, oy, oz;
+	const uint8_t *base;        // the packed image
 };
 
 __device__ __forceinline__ FullLutConsts full_lut_consts(const RayMarchArgs &A)
 {
 	FullLutConsts c;
 	c.w = (float) A.W, c.h = (float) A.H, c.d = (float) A.D;
+	c.base = A.packed;
 	c.oy = (float) (4 * (A.W + 2) + 4);
-	c.oz = (float) (4 * (int) (((uint32_t) A.W + 2u + (uint32_t) A.H + 2u + 1u) & ~1u) + 8);
+	c.oz = (float) (4 * (A.W + 2 + A.H + 2) + 4);
 	asm volatile("" : "+v"(c.w), "+v"(c.h), "+v"(c.d), "+v"(c.oy), "+v"(c.oz));
 	return c;
 }
@@ -1541,11 +1536,11 @@ __device__ __forceinline__ const uint8_t *packed_footprint_full(const FullLutCon
 	wx = cx - fx, wy = cy - fy, wz = cz - fz;
 	const int      tx = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fx, -1.0f, C.w), 4.0f, 4.0f);
 	const int      ty = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fy, -1.0f, C.h), 4.0f, C.oy);
-	const int      tz = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fz, -1.0f, C.d), 8.0f, C.oz);
+	const int      tz = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fz, -1.0f, C.d), 4.0f, C.oz);
 	const char *   lut = reinterpret_cast<const char *>(full_lut_base(L));
 	const uint32_t xo = *reinterpret_cast<const uint32_t *>(lut + tx), yo = *reinterpret_cast<const uint32_t *>(lut + ty);
-	const uint64_t zo = *reinterpret_cast<const uint64_t *>(lut + tz);
-	return reinterpret_cast<const uint8_t *>(zo + (xo + yo));
+	const uint32_t zo = *reinterpret_cast<const uint32_t *>(lut + tz);
+	return C.base + ((uint64_t) ((xo + yo) + zo) << 1);        // the terms are in units of two bytes
 }
 
 // A footprint address that comes out of the LDS address tables is an integer: tell the compiler it points to global memory, or it emits
@@ -1811,7 +1806,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 					texel = reinterpret_cast<const uint32_t *>(A.tf)[tidx];
 			}
 			ab = texel >> 24;
-			a  = L.alpha[ab];
+			a  = L.g.alpha[ab];
 		}
 		};
 		if (!kNest && any_sample)
