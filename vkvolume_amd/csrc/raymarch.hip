@@ -37,7 +37,8 @@ static LeanChoice choose_lean(const RayMarchArgs &a)
 	const size_t      full_end = kFullLutWord * 4 + full_lut_bytes(a.W, a.H, a.D);        // from the start of RmLds
 	// the full tables hold offsets in units of two bytes in 32 bits: a packed image of up to 8 GiB
 	const bool        fits_u32 = packed_bytes(packed_dims(a.W, a.H, a.D)) <= (1ull << 33);
-	if (!no_full && fits_u32 && full_end <= kFullLdsLimit)
+	static const size_t full_limit = [] { const char *e = std::getenv("VKV_RAYMARCH_FULL_LIMIT"); return e ? (size_t) std::atol(e) : kFullLdsLimit; }();        // A/B switch
+	if (!no_full && fits_u32 && full_end <= full_limit)
 		return {2, std::max(lut_bytes, full_end > sizeof(RmLds) ? full_end - sizeof(RmLds) : (size_t) 0)};
 	return {1, lut_bytes};
 }
