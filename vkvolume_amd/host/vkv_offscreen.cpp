@@ -301,11 +301,31 @@ int main(int argc, char **argv)
 					targets[i].rgba8 = device_alloc<uint8_t>(n_pixels * 4);
 				}
 			}
+			// the frames in flight share one launch; consecutive launches alternate over three streams (each with its own set of targets),
+			// so the tail of one launch is covered by the next (bench.py --batch-streams)
+			const bool                             batched = benchmark && volumes.size() == 1 && fif > 1 && fif <= VKV_MAX_BATCH;
+			constexpr int                          kLaunchStreams = 3;
+			std::vector<hipStream_t>               lstreams(kLaunchStreams, stream);
+			std::vector<std::vector<RenderTarget>> ltargets(kLaunchStreams, targets);
+			for (int s = 1; batched && s < kLaunchStreams; ++s)
+			{
+				if (hipStreamCreate(&lstreams[s]) != hipSuccess)
+					throw std::runtime_error("hipStreamCreate failed");
+				for (int i = 0; i < fif; ++i)
+					ltargets[s][i].rgba8 = device_alloc<uint8_t>(n_pixels * 4);
+			}
 			const auto t0 = std::chrono::steady_clock::now();
-			if (benchmark && volumes.size() == 1 && fif > 1 && fif <= VKV_MAX_BATCH)
-			{        // the frames in flight share one launch
-				for (int f = 0; f < frames; f += fif)
-					subpass.draw_batch(std::vector<RenderTarget>(targets.begin(), targets.begin() + std::min(fif, frames - f)));
+			if (batched)
+			{
+				int launch = 0;
+				for (int f = 0; f < frames; f += fif, ++launch)
+				{
+					const int s = launch % kLaunchStreams;
+					dc.stream   = lstreams[s];
+					subpass.draw_batch(std::vector<RenderTarget>(ltargets[s].begin(), ltargets[s].begin() + std::min(fif, frames - f)));
+				}
+				for (int s = 1; s < kLaunchStreams; ++s)
+					(void) hipStreamSynchronize(lstreams[s]);
 			}
 			else
 				for (int f = 0; f < frames; ++f)
@@ -322,6 +342,12 @@ int main(int argc, char **argv)
 			{
 				(void) hipFree(targets[i].rgba8);
 				(void) hipStreamDestroy(streams[i]);
+			}
+			for (int s = 1; batched && s < kLaunchStreams; ++s)
+			{
+				for (int i = 0; i < fif; ++i)
+					(void) hipFree(ltargets[s][i].rgba8);
+				(void) hipStreamDestroy(lstreams[s]);
 			}
 		}
 
