@@ -63,3 +63,6 @@ if t.shape[1] > 7 and t[:, 7].max() > 0:
     if long.any():
         mhz = (t[long, 7] - t[long, 6]) / (end[long] - start[long])  # shader-clock ticks per microsecond
         print("shader clock seen by waves that ran > 50 us: median %.0f MHz (p10 %.0f, p90 %.0f)" % tuple(np.percentile(mhz, [50, 10, 90])))
+if len(sys.argv) > 2:
+    # per-wave records for offline scheduling experiments: start, end (us), wave iterations, launch-wide wave index
+    np.save(sys.argv[2], np.column_stack([start, end, it, np.nonzero(trace.cpu().numpy()[:, 1] > 0)[0]]))

@@ -216,6 +216,7 @@ int vkv_create(int device_ordinal, vkv_ctx **out_ctx)
 	ctx->cu_count = prop.multiProcessorCount;
 	ctx->error[0] = 0;
 	ctx->d_trace  = nullptr;
+	ctx->d_debug_orders = nullptr, ctx->debug_order_frames = ctx->debug_order_count = 0;
 	*out_ctx      = ctx;        // the caller's current device is left as it is: every entry point switches to ctx->device itself
 	return VKV_OK;
 }
@@ -232,6 +233,12 @@ void vkv_destroy(vkv_ctx *ctx)
 			(void) hipFree(t.d_order);
 		for (auto &t : ctx->addr_luts)
 			(void) hipFree(t.d_lut);
+		for (auto *f : ctx->feedback)
+		{
+			(void) hipFree(f->d_cost);
+			(void) hipFree(f->d_order);
+			delete f;
+		}
 	}
 	delete ctx;
 }
@@ -243,6 +250,17 @@ int vkv_debug_trace(vkv_ctx *ctx, void *d_buffer)
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
 	ctx->d_trace = d_buffer;
+	return VKV_OK;
+}
+
+// Diagnostic hook (not part of the public header): the next vkv_render_batch launches take frame i's tile start order from
+// d_orders + i * count (device array of schedule-entry indices, a permutation of 0 .. count - 1) instead of the centre-first order, when
+// count equals the schedule's tile count; nullptr switches it off.  For start-order experiments (tools/tile_order_feedback.py).
+int vkv_debug_tile_orders(vkv_ctx *ctx, const uint32_t *d_orders, uint32_t frames, uint32_t count)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	ctx->d_debug_orders = d_orders, ctx->debug_order_frames = d_orders ? frames : 0u, ctx->debug_order_count = count;
 	return VKV_OK;
 }
 

@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <new>
 #include <vector>
 
 #include "raymarch_core.hpp"
@@ -197,6 +199,7 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 	a.nblocks     = (uint32_t) nb;
 	a.test        = P->options.test;
 	a.queue_heads = nullptr;        // persistent scheduler: set at launch (per-stream scratch)
+	a.tile_cost = nullptr, a.order_out = nullptr;        // start-order feedback: attached by the launchers
 	a.trace       = reinterpret_cast<unsigned long long *>(ctx->d_trace);
 	a.back        = (int) std::ceil(P->transfer_function.sampling_factor);
 	static const bool in_order = [] { const char *e = std::getenv("VKV_RAYMARCH_TILE_ORDER"); return e && e[0] == 'l'; }();        // "linear": A/B switch
@@ -209,6 +212,63 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 	for (int i = 0; i < 256; ++i)
 		a.alpha_lut[i] = alpha_lut[i];
 	return VKV_OK;
+}
+
+// Start-order feedback.  A renderer draws into the same target again and again with a camera that moves little from frame to frame,
+// so the tiles that were expensive last time are expensive now: every marching wave leaves its iteration count in a per-target cost
+// buffer (atomicMax per tile), and a small sort kernel behind the render (k_tile_orders_from_cost, one workgroup per frame, same stream)
+// turns them into the longest-first order the next frame into that target starts its tiles in.  The first frame into a target, and every frame when
+// VKV_RAYMARCH_FEEDBACK=0, uses the centre-of-image-first order.  Any order renders the same frame.
+// Returns true when `a` now asks for a sort (order_out set).
+static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a)
+{
+	static const bool off = [] { const char *e = std::getenv("VKV_RAYMARCH_FEEDBACK"); return e && e[0] == '0'; }();
+	const void *      target = a.out_rgba8 ? (const void *) a.out_rgba8 : (const void *) a.out_color;
+	if (off || !target || a.tile_count < 64 || ctx->d_debug_orders)
+		return false;
+	vkv_ctx::TileFeedback *     f = nullptr;
+	std::lock_guard<std::mutex> lock(ctx->mutex);
+	for (auto *e : ctx->feedback)
+		if (e->target == target && e->img_w == a.img_w && e->img_h == a.img_h && e->tile_w == a.tile_w && e->tile_h == a.tile_h && e->first == a.tile_first &&
+		    e->stride == a.tile_stride && e->count == a.tile_count)
+		{
+			f = e;
+			break;
+		}
+	if (!f)
+	{
+		if (ctx->feedback.size() >= 256)
+		{        // a renderer has a handful of targets: drop the oldest entry rather than grow without bound (its buffers may still be in use)
+			(void) hipDeviceSynchronize();
+			(void) hipFree(ctx->feedback.front()->d_cost);
+			(void) hipFree(ctx->feedback.front()->d_order);
+			delete ctx->feedback.front();
+			ctx->feedback.erase(ctx->feedback.begin());
+		}
+		uint32_t *cost = nullptr, *order = nullptr;
+		if (hipMalloc((void **) &cost, (size_t) a.tile_count * sizeof(uint32_t)) != hipSuccess)
+			return false;
+		if (hipMalloc((void **) &order, (size_t) a.tile_count * sizeof(uint32_t)) != hipSuccess || hipMemset(cost, 0, (size_t) a.tile_count * sizeof(uint32_t)) != hipSuccess)
+		{
+			(void) hipFree(cost);
+			(void) hipFree(order);
+			return false;
+		}
+		f = new (std::nothrow) vkv_ctx::TileFeedback{target, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count, cost, order, false};
+		if (!f)
+		{
+			(void) hipFree(cost);
+			(void) hipFree(order);
+			return false;
+		}
+		ctx->feedback.push_back(f);
+	}
+	a.tile_cost = f->d_cost;
+	a.order_out = f->d_order;        // written by the sort that FOLLOWS this frame's render on the stream
+	if (f->has_cost)
+		a.tile_order = f->d_order;        // the order the sort behind the previous frame into this target left
+	f->has_cost = true;
+	return true;
 }
 
 int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, hipStream_t s)
@@ -225,6 +285,8 @@ int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut
 
 	const bool ert  = P->options.early_ray_termination != 0;
 	const int  grad = !P->transfer_function.use_gradient ? 0 : (P->use_precomputed_gradient ? 1 : 2);
+	// (no start-order feedback here: a frame that runs alone is as long as its longest wave whatever the order, and the sort would be
+	// 15 us in front of a 250 us launch; vkv_render_batch has it)
 	switch (P->options.skipping_type)
 	{
 		case VKV_SKIP_NONE: return launch_ert<VKV_SKIP_NONE>(ctx, sched, ert, grad, a, s);
@@ -324,9 +386,14 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: frame %u has no packed sampling image (d_packed_volume)", i);
 		if (host[i].nblocks != host[0].nblocks || host[i].tile_count != host[0].tile_count || host[i].blocks_per_tile != host[0].blocks_per_tile)
 			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: frame %u has a different tile schedule size than frame 0", i);
+		if (ctx->d_debug_orders && i < ctx->debug_order_frames && ctx->debug_order_count == host[i].tile_count)
+			host[i].tile_order = ctx->d_debug_orders + (size_t) i * ctx->debug_order_count;        // diagnostic start orders
 	}
 	if (host[0].nblocks == 0)
 		return VKV_OK;
+	bool any_sort = false;
+	for (uint32_t i = 0; i < n; ++i)
+		any_sort = apply_feedback(ctx, host[i]) || any_sort;
 	uint8_t *scratch = stream_scratch(ctx, s);
 	if (!scratch)
 		return VKV_E_UNSUPPORTED;
@@ -381,6 +448,8 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 		}
 		if (resident == 0)
 			return set_error(ctx, VKV_E_NO_DEVICE, "render_batch: occupancy query failed");
+		if (any_sort)
+			hipLaunchKernelGGL(k_tile_orders_from_cost, dim3(n), dim3(256), 0, s, d_frames);
 		return check_launch(ctx, "render_batch");
 	}
 	switch (P[0].options.skipping_type)
@@ -391,6 +460,10 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 		case VKV_SKIP_ANISOTROPIC_DISTANCE: launch_batch_ert<VKV_SKIP_ANISOTROPIC_DISTANCE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, s); break;
 		default: return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: bad skipping_type %d", P[0].options.skipping_type);
 	}
+	// behind the render, on the same stream: the costs it measured become the start order of the next frames into these targets (the
+	// sort is not in front of anybody's render this way; in front it cost 70 us per 20-frame block of three launches)
+	if (any_sort)
+		hipLaunchKernelGGL(k_tile_orders_from_cost, dim3(n), dim3(256), 0, s, d_frames);
 	return check_launch(ctx, "render_batch");
 }
 

@@ -130,6 +130,8 @@ struct vkv_ctx
 	int   cu_count;        // compute units of the device (grid of the resident-workgroup kernels)
 	char  error[512];
 	void *d_trace;        // diagnostic wave timeline buffer (vkv_debug_trace), normally null
+	const uint32_t *d_debug_orders;        // diagnostic per-frame tile start orders of vkv_render_batch (vkv_debug_tile_orders), normally null
+	uint32_t        debug_order_frames, debug_order_count;
 	std::mutex                                 mutex;
 	std::unordered_map<hipStream_t, uint8_t *> scratch;        // stream -> kScratchBytes of device memory
 	// start orders of tile schedules (centre of the image first), built on first use and kept: immutable device arrays
@@ -147,6 +149,16 @@ struct vkv_ctx
 		uint32_t *d_lut;
 	};
 	std::vector<AddrLut> addr_luts;
+	// start-order feedback: per render target and tile schedule, the tile costs the last frame into that target left behind and the
+	// buffer its longest-first order is written to (raymarch.hip, apply_feedback); heap objects, so their addresses stay valid
+	struct TileFeedback
+	{
+		const void *target;
+		uint32_t    img_w, img_h, tile_w, tile_h, first, stride, count;
+		uint32_t *  d_cost, *d_order;
+		bool        has_cost;        // a frame has been rendered into this target with the cost buffer attached
+	};
+	std::vector<TileFeedback *> feedback;
 };
 
 namespace vkv
