@@ -380,3 +380,42 @@ def test_render_parity_under_each_kernel_selection_switch(switch):
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, "%s:\n%s\n%s" % (switch, r.stdout[-3000:], r.stderr[-1000:])
     assert " passed" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(208, 112), (2608, 1040)])
+def test_render_batch_start_order_feedback_keeps_the_frames(ctx, size):
+    """vkv_render_batch re-orders the tiles of a frame by the costs the previous frame into the same target measured (a counting sort
+    behind the render; more than 10 240 tiles take its two-pass path).  Four launches into the same targets, the views of the targets
+    swapped in between: every frame equals its single-launch render."""
+    opt = abi.VolumeOptions(**T.APP_TF)
+    scene = T.OracleScene(O.synth_volume((64, 56, 48), 1, 123), opt, 4)
+    v, tf = make_gpu_volume(ctx, scene)
+    V.ComputeDistanceMap(ctx).compute(v, tf, abi.SKIP_DISTANCE)
+    ro = abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0)
+    st = torch.cuda.current_stream().cuda_stream
+    sp = V.VolumeRenderSubpass(ctx, v, ro, size)
+    params = []
+    for az in (10.0, 130.0, 250.0):
+        view, proj = T.orbit(az, image_size=size)
+        params.append(sp.bind(scene.params(view, proj, size, ro)))
+    ref = []
+    for p in params:
+        out = torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda")
+        p.d_out_rgba8, p.d_out_color, p.d_out_counts, p.d_out_depth = out.data_ptr(), None, None, None
+        ctx.render(p, st)
+        ref.append(out)
+    targets = [torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda") for _ in params]
+    for launch in range(4):
+        shift = launch // 2  # launches 2 and 3 put other views into the same targets: the remembered costs belong to another view
+        plist = []
+        for j in range(len(params)):
+            q = abi.RenderParams.from_buffer_copy(params[(j + shift) % len(params)])
+            q.d_out_rgba8 = targets[j].data_ptr()
+            plist.append(q)
+        for t in targets:
+            t.fill_(9)
+        ctx.render_batch(plist, st)
+        torch.cuda.synchronize()
+        for j in range(len(params)):
+            assert torch.equal(targets[j], ref[(j + shift) % len(params)]), "launch %d, target %d" % (launch, j)

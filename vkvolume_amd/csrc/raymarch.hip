@@ -220,7 +220,7 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 // turns them into the longest-first order the next frame into that target starts its tiles in.  The first frame into a target, and every frame when
 // VKV_RAYMARCH_FEEDBACK=0, uses the centre-of-image-first order.  Any order renders the same frame.
 // Returns true when `a` now asks for a sort (order_out set).
-static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a)
+static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a, hipStream_t s)
 {
 	static const bool off = [] { const char *e = std::getenv("VKV_RAYMARCH_FEEDBACK"); return e && e[0] == '0'; }();
 	const void *      target = a.out_rgba8 ? (const void *) a.out_rgba8 : (const void *) a.out_color;
@@ -248,17 +248,29 @@ static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a)
 		uint32_t *cost = nullptr, *order = nullptr;
 		if (hipMalloc((void **) &cost, (size_t) a.tile_count * sizeof(uint32_t)) != hipSuccess)
 			return false;
-		if (hipMalloc((void **) &order, (size_t) a.tile_count * sizeof(uint32_t)) != hipSuccess || hipMemset(cost, 0, (size_t) a.tile_count * sizeof(uint32_t)) != hipSuccess)
+		if (hipMalloc((void **) &order, (size_t) a.tile_count * sizeof(uint32_t)) != hipSuccess)
 		{
 			(void) hipFree(cost);
-			(void) hipFree(order);
 			return false;
 		}
-		f = new (std::nothrow) vkv_ctx::TileFeedback{target, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count, cost, order, false};
-		if (!f)
+		f = new (std::nothrow) vkv_ctx::TileFeedback{target, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count, cost, order, false, {}};
+		if (f)
 		{
+			f->identity.resize(a.tile_count);
+			for (uint32_t i = 0; i < a.tile_count; ++i)
+				f->identity[i] = i;
+		}
+		// both buffers are initialised ON THE LAUNCH'S STREAM, ahead of the render that writes the costs and of the sort that reads them
+		// twice (a memset on another stream landing between the sort's two passes would leave holes in the order), and the order starts
+		// out as a valid permutation (a frame that reads it too early - the same target used from two streams without an event - then
+		// renders a wrong picture, not a wild address)
+		if (!f || hipMemsetAsync(cost, 0, (size_t) a.tile_count * sizeof(uint32_t), s) != hipSuccess ||
+		    hipMemcpyAsync(order, f->identity.data(), (size_t) a.tile_count * sizeof(uint32_t), hipMemcpyHostToDevice, s) != hipSuccess)
+		{
+			(void) hipStreamSynchronize(s);
 			(void) hipFree(cost);
 			(void) hipFree(order);
+			delete f;
 			return false;
 		}
 		ctx->feedback.push_back(f);
@@ -393,7 +405,7 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 		return VKV_OK;
 	bool any_sort = false;
 	for (uint32_t i = 0; i < n; ++i)
-		any_sort = apply_feedback(ctx, host[i]) || any_sort;
+		any_sort = apply_feedback(ctx, host[i], s) || any_sort;
 	uint8_t *scratch = stream_scratch(ctx, s);
 	if (!scratch)
 		return VKV_E_UNSUPPORTED;

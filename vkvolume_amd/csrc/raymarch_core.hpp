@@ -1944,6 +1944,8 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 	// 0.03 ms (bench.py).  Several single-frame launches in flight on their own streams prefer the plain order
 	// (VKV_RAYMARCH_TILE_ORDER=linear: 0.157 vs 0.167 ms per frame with three in flight) - their heavy centres then do not coincide.
 	const uint32_t k = A.tile_order ? A.tile_order[rank] : rank;
+	if (k >= A.tile_count)
+		return;        // never with a well-formed order; keeps a damaged one (a target shared by two streams without an event) from becoming a wild address
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t       px, py, o;
 	const bool     inside = block_pixel<1>(A, k * A.blocks_per_tile + sb, (part * WPB + wave) * 64u + lane, px, py, o);
@@ -2070,6 +2072,8 @@ __device__ __forceinline__ void pull_units(const RayMarchArgs *__restrict__ fram
 		const uint32_t      w = v % upt, f = (v / upt) % n, rank = (v / (upt * n)) * 8u + q;
 		const RayMarchArgs &A = frames[f];
 		const uint32_t      k = A.tile_order ? A.tile_order[rank] : rank;
+		if (k >= A.tile_count)
+			continue;
 		uint32_t            px, py, o;
 		const bool          inside = block_pixel<1>(A, k * A.blocks_per_tile + (w >> 2), (w & 3u) * 64u + lane, px, py, o);
 		Ray                 R = {};        // every field defined per unit: nothing of the previous unit's ray is carried round the loop
@@ -2205,7 +2209,9 @@ __device__ __forceinline__ void tile_order_from_cost(uint32_t *__restrict__ cost
 	// larger schedules: second pass over memory
 	for (uint32_t t = threadIdx.x; t < count; t += blockDim.x)
 	{
-		order_out[atomicAdd(&s_bin[kCostBins - 1 - min(cost[t], (uint32_t) kCostBins - 1u)], 1u)] = t;
+		const uint32_t pos = atomicAdd(&s_bin[kCostBins - 1 - min(cost[t], (uint32_t) kCostBins - 1u)], 1u);
+		if (pos < count)        // always, unless somebody changed the costs between the two passes
+			order_out[pos] = t;
 		cost[t] = 0;
 	}
 }
