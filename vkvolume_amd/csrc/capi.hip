@@ -227,6 +227,7 @@ void vkv_destroy(vkv_ctx *ctx)
 		return;
 	{
 		DeviceGuard guard(ctx->device);
+		(void) hipDeviceSynchronize();        // launches that still read the context's tables, scratch or feedback buffers
 		for (auto &kv : ctx->scratch)
 			(void) hipFree(kv.second);
 		for (auto &t : ctx->tile_orders)
