@@ -11,7 +11,7 @@ ctx = lib.Context(0)
 v, tf, frame, skip = bench.build_scene(ctx, "c3")
 fw, fh = frame
 views = bench.cameras(v, fw / fh)
-sp = V.VolumeRenderSubpass(ctx, v, abi.RenderOptions(skipping_type=skip, clip_distance=1.0, early_ray_termination=True), (fw, fh))
+sp = V.VolumeRenderSubpass(ctx, v, abi.RenderOptions(skipping_type=skip, clip_distance=1.0, early_ray_termination=not os.environ.get("NO_ERT")), (fw, fh))
 L = lib.load()
 L.vkv_debug_trace.argtypes = [C.c_void_p, C.c_void_p]
 L.vkv_debug_tile_orders.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
@@ -123,7 +123,17 @@ def lpt_centre_ties(vw):
     return centre[np.argsort(-cost[vw][centre], kind="stable")]
 
 
+def classes(vw, per_octave=1):
+    # coarse cost classes (log2 scale), the library's centre-first order kept inside a class: longest first only roughly, spatially coherent
+    c = cost[vw][centre].astype(np.float64)
+    cls = np.where(c > 0, np.floor(np.log2(np.maximum(c, 1)) * per_octave) + 1, 0)
+    return centre[np.argsort(-cls, kind="stable")]
+
+
 print("fenced blocks of 20 frames (7 + 7 + 6 on three streams), ms per frame:")
+print("  log2 cost classes, centre-first inside  %.4f" % timed([classes(vw) for vw in range(8)]))
+print("  half-octave classes                     %.4f" % timed([classes(vw, 2) for vw in range(8)]))
+print("  quarter-octave classes                  %.4f" % timed([classes(vw, 4) for vw in range(8)]))
 print("  longest first, empty tiles shuffled   %.4f" % timed([lpt_random_ties(vw) for vw in range(8)]))
 print("  longest first, ties centre-first      %.4f" % timed([lpt_centre_ties(vw) for vw in range(8)]))
 print("  centre first (library)        %.4f" % timed(None))

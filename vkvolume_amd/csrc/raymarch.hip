@@ -403,8 +403,10 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	}
 	if (host[0].nblocks == 0)
 		return VKV_OK;
+	// measured start order only with early ray termination: without it every covered tile is about equally long, nothing is gained by
+	// starting the longest first, and an order sorted by cost scatters neighbouring tiles (C3 without ERT: 0.394 against 0.373 ms per frame)
 	bool any_sort = false;
-	for (uint32_t i = 0; i < n; ++i)
+	for (uint32_t i = 0; i < n && P[0].options.early_ray_termination != 0; ++i)
 		any_sort = apply_feedback(ctx, host[i], s) || any_sort;
 	uint8_t *scratch = stream_scratch(ctx, s);
 	if (!scratch)
