@@ -253,7 +253,7 @@ static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a, hipStream_t s)
 			(void) hipFree(cost);
 			return false;
 		}
-		f = new (std::nothrow) vkv_ctx::TileFeedback{target, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count, cost, order, false, {}};
+		f = new (std::nothrow) vkv_ctx::TileFeedback{target, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count, cost, order, false, 0u, {}};
 		if (f)
 		{
 			f->identity.resize(a.tile_count);
@@ -275,10 +275,17 @@ static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a, hipStream_t s)
 		}
 		ctx->feedback.push_back(f);
 	}
+	// costs are measured (and sorted behind the render) on the first frame into a target and then every `period`-th one: a camera that
+	// moves little keeps the order good for a few frames, and the sort kernel + the cost atomics are then paid once per period
+	static const uint32_t period = [] { const char *e = std::getenv("VKV_RAYMARCH_FEEDBACK_PERIOD"); const long v = e ? std::atol(e) : 8; return (uint32_t) (v < 1 ? 1 : v); }();
+	const bool            measure = f->frames % period == 0;
+	++f->frames;
+	if (f->has_cost)
+		a.tile_order = f->d_order;        // the order the last sort behind a frame into this target left
+	if (!measure)
+		return false;
 	a.tile_cost = f->d_cost;
 	a.order_out = f->d_order;        // written by the sort that FOLLOWS this frame's render on the stream
-	if (f->has_cost)
-		a.tile_order = f->d_order;        // the order the sort behind the previous frame into this target left
 	f->has_cost = true;
 	return true;
 }

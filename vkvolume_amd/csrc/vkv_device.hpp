@@ -157,6 +157,7 @@ struct vkv_ctx
 		uint32_t    img_w, img_h, tile_w, tile_h, first, stride, count;
 		uint32_t *  d_cost, *d_order;
 		bool        has_cost;        // a frame has been rendered into this target with the cost buffer attached
+		uint32_t    frames;          // frames rendered into this target so far (costs are measured and sorted every few frames)
 		std::vector<uint32_t> identity;        // 0 .. count - 1: what d_order holds until the first sort (kept: source of an asynchronous copy)
 	};
 	std::vector<TileFeedback *> feedback;
