@@ -63,9 +63,10 @@ def test_gradient_map_parity(ctx, shape, use_gradient):
 
 
 def test_gradient_kernel_shortcuts_are_exact(ctx):
-    """The tiled gradient kernel's two short-cuts, checked exhaustively on the device: (0) its short sqrt (v_sqrt_f32 + one-ulp
-    fix-up, no range rescaling) equals the compiler's correctly rounded sqrt for every float its argument can be - 0 and all of
-    [2^-90, 16): the sum of the squares of three tap sums in [-2, 2] (the 0.25 factors are applied after the root); (1) its one-instruction clamped R8_UNORM store equals rint(clamp(g, 0, 1) * 255) for every non-NaN float."""
+    """The tiled gradient kernel's two short-cuts, checked exhaustively on the device: (0) its short sqrt (x * rsq(x) and one step on the
+    exact residual, no range rescaling) equals the compiler's correctly rounded sqrt for every float its argument can be - 0 and all
+    of [2^-90, 16): the sum of the squares of three tap sums in [-2, 2] (the 0.25 factors are applied after the root); (1) its
+    one-instruction clamped R8_UNORM store equals rint(clamp(g, 0, 1) * 255) for every non-NaN float."""
     import ctypes as C
     L = ctx._lib
     L.vkv_debug_check.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]

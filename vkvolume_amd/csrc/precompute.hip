@@ -34,28 +34,26 @@ __global__ void __launch_bounds__(256) k_gradient_map(const uint8_t *__restrict_
 	grad[vidx(x, y, z, W, H)] = store_unorm8(g);
 }
 
-// LDS-tiled version (the one the launcher uses when the rows are dword-aligned, W % 4 == 0): a workgroup computes a
-// 64 x 8 x 8 block of voxels from a (64+8) x 10 x 10 halo tile staged in LDS with coalesced dword loads, so every volume byte
-// is fetched ~1.6x instead of 4x with byte gathers.
-// Correctly rounded sqrt for x == 0 or x normal with a normal root: v_sqrt_f32 (1 ulp) moved by at most one ulp after looking at
-// the signs of the two residuals - the sequence the compiler emits for __builtin_sqrtf under
-// -fhip-fp32-correctly-rounded-divide-sqrt, without the rescaling of tiny inputs and the inf / nan pass-through around it (7 of its
-// 16 instructions).  The gradient's sum of squares is 0 or >= ~1e-17 (squares of rounding residues of byte / 255 values), far above
-// 2^-96 where the rescaling starts.  vkv_debug_check (what = 0) compares it with __builtin_sqrtf for every float of a range; the GPU
-// tests run it over 0 and all of [2^-90, 16).
+// LDS-tiled version (the one the launcher uses when the rows are dword-aligned, W % 4 == 0): a workgroup computes 64 x 8 x 8 blocks of
+// voxels from (64+8) x 10 x 10 halo tiles staged in LDS with coalesced dword loads, so every volume byte is fetched ~1.8x (mostly from
+// L2) instead of 4x with byte gathers.
+//
+// Correctly rounded sqrt for x == 0 or x normal with a normal root, from the reciprocal root (Markstein's final step): g = x * rsq(x) is
+// within a few ulp, the residual x - g * g is exact in an fma, and g + residual * (0.5 * rsq) rounds to the nearest float of the true
+// root.  Six instructions (v_max keeps x = 0 away from 0 * inf) where __builtin_sqrtf under -fhip-fp32-correctly-rounded-divide-sqrt
+// takes sixteen (v_sqrt_f32, a one-ulp fix-up from two residual signs, rescaling of tiny inputs, inf / nan pass-through).  The
+// gradient's sum of squares is 0 or >= ~1e-17 (squares of rounding residues of byte / 255 values).  vkv_debug_check (what = 0)
+// compares it with __builtin_sqrtf for every float of a range; the GPU tests run it over 0 and all of [2^-90, 16).
 __device__ __forceinline__ float sqrt_rn_normal(float x)
 {
-	const float r  = __builtin_amdgcn_sqrtf(x);
-	const float rm = __int_as_float(__float_as_int(r) - 1), rp = __int_as_float(__float_as_int(r) + 1);
-	const float em = __builtin_fmaf(-rm, r, x), ep = __builtin_fmaf(-rp, r, x);
-	float       q  = (em <= 0.0f) ? rm : r;
-	q              = (ep > 0.0f) ? rp : q;
-	return q;
+	const float y = __builtin_amdgcn_rsqf(__builtin_fmaxf(x, 0x1p-100f));
+	const float g = x * y, h = 0.5f * y;
+	return __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g);
 }
 
 // R8_UNORM store of clamp(g, 0, 1) in one instruction: v_cvt_pk_u8_f32 rounds to nearest even and saturates to [0, 255], so fed
 // g * 255 it equals store_unorm8(g_clamp(g, 0, 1)) for every non-NaN float (vkv_debug_check what = 1 runs over all of them).
-__device__ __forceinline__ uint8_t store_unorm8_clamped(float g) { return (uint8_t) __builtin_amdgcn_cvt_pk_u8_f32(g * 255.0f, 0u, 0u); }
+__device__ __forceinline__ uint32_t store_unorm8_clamped(float g) { return __builtin_amdgcn_cvt_pk_u8_f32(g * 255.0f, 0u, 0u); }
 
 // what = 0: sqrt_rn_normal vs __builtin_sqrtf; what = 1: store_unorm8_clamped vs store_unorm8(g_clamp(., 0, 1))
 __global__ void __launch_bounds__(256) k_check_numerics(int what, uint32_t first_bits, uint64_t count, unsigned long long *mismatches)
@@ -68,87 +66,161 @@ __global__ void __launch_bounds__(256) k_check_numerics(int what, uint32_t first
 	if (what == 0)
 		bad = __float_as_uint(sqrt_rn_normal(x)) != __float_as_uint(__builtin_sqrtf(x));
 	else
-		bad = store_unorm8_clamped(x) != store_unorm8(g_clamp(x, 0.0f, 1.0f));
+		bad = (uint8_t) store_unorm8_clamped(x) != store_unorm8(g_clamp(x, 0.0f, 1.0f));
 	if (bad)
 		atomicAdd(mismatches, 1ull);
 }
 
-constexpr int kGradTileX = 64, kGradTileY = 8, kGradTileZ = 8, kGradPitch = 72;        // pitch = 64 + 4 bytes of halo on each side
+constexpr int kGradTileX = 64, kGradTileY = 8, kGradTileZ = 8, kGradPitch = 72;        // pitch = 64 + 4 texels of halo on each side
+constexpr int kGradSegment = 10;                                                       // tiles one workgroup marches over
 
-__global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__restrict__ vol, uint8_t *__restrict__ grad, int W, int H, int D,
-                                                            float modifier, uint32_t tiles_x, uint32_t tiles_y, uint32_t n_tiles)
+// byte store through a wave-uniform base (SGPR pair) and a 32-bit lane offset: no 64-bit vector address arithmetic per voxel
+__device__ __forceinline__ void store_u8_uniform_base(uint8_t *base, uint32_t off, uint32_t value)
 {
-	__shared__ __align__(16) uint8_t s_tile[(kGradTileZ + 2) * (kGradTileY + 2) * kGradPitch];
-	__shared__ float                 s_unorm[256];        // b / 255 (IEEE division, once per workgroup): a tap costs one LDS read, not four VALU
+	asm volatile("global_store_byte %0, %1, %2" : : "v"(off), "v"(value), "s"(base) : "memory");
+}
+
+// A workgroup MARCHES along z over `seg` consecutive tiles with the next tile's dwords already in flight (held in registers) while the
+// current one is computed: a workgroup that loads, waits, computes and leaves keeps too few bytes in flight per CU to cover the HBM
+// latency (measured on the one-tile-per-workgroup kernel: neither the VALU nor the LDS busy more than half the time; 0.96 -> 0.85 ms
+// on 1024 x 1024 x 795).  The tile holds 16-bit OFFSETS into the 256-entry table of b / 255 (4 b: the shift between the tap read and the
+// table read is paid once per staged texel, not four times per voxel), two per half of a staged dword, which puts the texels of every
+// group of four in the order 0, 2, 1, 3.
+__global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__restrict__ vol, uint8_t *__restrict__ grad, int W, int H, int D,
+                                                            float modifier, uint32_t tiles_x, uint32_t tiles_y, uint32_t tiles_z, uint32_t seg,
+                                                            uint32_t n_wgs)
+{
+	constexpr int kRows = (kGradTileZ + 2) * (kGradTileY + 2), kCols = kGradPitch / 4, kIter = (kRows * kCols + 255) / 256;
+	__shared__ __align__(16) uint16_t s_tile[kRows * kGradPitch];
+	__shared__ float                  s_unorm[256];        // b / 255 (IEEE division, once per workgroup): a tap costs one LDS read, not four VALU
 	s_unorm[threadIdx.x] = unorm8(threadIdx.x);
-	const uint32_t t  = xcd_remap(blockIdx.x, n_tiles);
+	const uint32_t t  = xcd_remap(blockIdx.x, n_wgs);
 	const int      x0 = (int) (t % tiles_x) * kGradTileX;
 	const int      y0 = (int) ((t / tiles_x) % tiles_y) * kGradTileY;
-	const int      z0 = (int) (t / (tiles_x * tiles_y)) * kGradTileZ;
+	const uint32_t k0 = (t / (tiles_x * tiles_y)) * seg, k1 = min(k0 + seg, tiles_z);
 	const int      wd = W >> 2;        // dwords per row
 	const float    quarter_modifier = 0.25f * modifier;
-	// ---- stage: 100 rows x 18 dwords; rows clamp in y and z, dword columns clamp in x (the two x-border bytes are patched below)
-	constexpr int kRows = (kGradTileZ + 2) * (kGradTileY + 2), kCols = kGradPitch / 4;
+	// per-thread staging slots (100 rows x 18 dwords, 8 per thread): row / column of the tile are the same for every tile of the march,
+	// only z moves; rows clamp in y and z, dword columns clamp in x
+	int  off_xy[kIter], rz[kIter];
+	bool left[kIter], right[kIter];
+#pragma unroll
+	for (int j = 0; j < kIter; ++j)
 	{
-		constexpr int kIter = (kRows * kCols + 255) / 256;        // 8 dwords per thread, all in flight before the first LDS store
-		uint32_t      v[kIter];
+		const int d   = min((int) threadIdx.x + 256 * j, kRows * kCols - 1);
+		const int row = d / kCols, col = d - row * kCols;
+		const int gy = min(max(y0 - 1 + row % (kGradTileY + 2), 0), H - 1);
+		const int gc = (x0 >> 2) - 1 + col;
+		left[j] = gc < 0, right[j] = gc >= wd;        // clamp-to-edge in x: texel x = -1 is voxel 0, texel x = W is voxel W - 1
+		off_xy[j] = gy * wd + min(max(gc, 0), wd - 1);
+		rz[j]     = row / (kGradTileY + 2) - 1;
+	}
+	const uint32_t *vol32 = reinterpret_cast<const uint32_t *>(vol);
+	const size_t    plane = (size_t) H * (size_t) wd;
+	uint32_t        v[kIter];
+	auto            fetch_edge = [&](uint32_t k) {
 #pragma unroll
 		for (int j = 0; j < kIter; ++j)
 		{
-			const int d   = min((int) threadIdx.x + 256 * j, kRows * kCols - 1);
-			const int row = d / kCols, col = d - row * kCols;
-			const int gy = min(max(y0 - 1 + row % (kGradTileY + 2), 0), H - 1), gz = min(max(z0 - 1 + row / (kGradTileY + 2), 0), D - 1);
-			const int gc = min(max((x0 >> 2) - 1 + col, 0), wd - 1);
-			v[j]         = reinterpret_cast<const uint32_t *>(vol + ((size_t) gz * H + gy) * (size_t) W)[gc];
+			const int gz = min(max((int) k * kGradTileZ + rz[j], 0), D - 1);
+			uint32_t  w  = vol32[(size_t) gz * plane + (size_t) off_xy[j]];
+			w            = left[j] ? (w << 24) : w;
+			v[j]         = right[j] ? (w >> 24) : w;
 		}
+	};
+	// tiles whose halo needs no clamp in x and z (nearly all of them): one wave-uniform base per tile and a constant 32-bit byte offset per
+	// slot, i.e. no vector address arithmetic at all (10 slices of the volume stay below 2^32 bytes: checked by the launcher)
+	uint32_t voff[kIter];
+#pragma unroll
+	for (int j = 0; j < kIter; ++j)
+		voff[j] = (uint32_t) (((size_t) (rz[j] + 1) * plane + (size_t) off_xy[j]) * 4u);
+	const bool inner_x = x0 > 0 && x0 + kGradTileX + 4 <= W;
+	auto       fetch   = [&](uint32_t k) {
+        if (inner_x && k > 0 && (int) (k + 1) * kGradTileZ < D)
+        {
+            const uint8_t *base = vol + ((size_t) k * kGradTileZ - 1) * plane * 4u;
+#pragma unroll
+            for (int j = 0; j < kIter; ++j)
+            {
+                uint32_t o = voff[j];
+                asm volatile("" : "+v"(o));        // keeps the zero-extension next to the load: scalar base + 32-bit lane offset addressing
+                v[j] = *reinterpret_cast<const uint32_t *>(base + o);
+            }
+        }
+        else
+            fetch_edge(k);
+	};
+	fetch(k0);
+	const int      lx = threadIdx.x & 63, x = x0 + lx, ly0 = (int) (threadIdx.x >> 6) * 2;        // lane = x, each wave two y rows, all z
+	const uint32_t off = (uint32_t) (y0 + ly0) * (uint32_t) W + (uint32_t) x, off1 = off + (uint32_t) W;        // inside one z slice (< 2^32 voxels)
+	constexpr int  sy = kGradPitch, sz = (kGradTileY + 2) * kGradPitch;
+	// position of texel i of a row in the tile (0, 2, 1, 3 within every four), for the lane's x - 1 and x + 1; texel x sits at column x - x0 + 4
+	auto      column = [](int i) { return (i & ~3) | ((i & 1) << 1) | ((i >> 1) & 1); };
+	const int cm = column(4 + lx - 1), cp = column(4 + lx + 1);
+	for (uint32_t k = k0; k < k1; ++k)
+	{
+		__syncthreads();        // the previous tile has been read by everyone
 #pragma unroll
 		for (int j = 0; j < kIter; ++j)
 			if ((int) threadIdx.x + 256 * j < kRows * kCols)
-				reinterpret_cast<uint32_t *>(s_tile)[threadIdx.x + 256 * j] = v[j];
-	}
-	__syncthreads();
-	// clamp-to-edge in x: byte x = -1 must equal voxel 0, byte x = W must equal voxel W-1
-	if (threadIdx.x < kRows)
-	{
-		uint8_t *row = s_tile + threadIdx.x * kGradPitch + 4;        // row[x - x0]
-		if (x0 == 0)
-			row[-1] = row[0];
-		if (x0 + kGradTileX >= W)
-			row[W - x0] = row[W - 1 - x0];
-	}
-	__syncthreads();
-	// ---- compute: lane = x, each wave two y rows, all z
-	const int lx = threadIdx.x & 63, x = x0 + lx;
-	if (x >= W)
-		return;
-	for (int lz = 0; lz < kGradTileZ; ++lz)
-	{
-		const int z = z0 + lz;
-		if (z >= D)
-			break;
-#pragma unroll
-		for (int j = 0; j < 2; ++j)
-		{
-			const int ly = (int) (threadIdx.x >> 6) * 2 + j, y = y0 + ly;
-			if (y >= H)
-				continue;
-			// tile coordinates of (x, y, z) are (lx + 4, ly + 1, lz + 1)
-			const uint8_t *c  = s_tile + ((lz + 1) * (kGradTileY + 2) + (ly + 1)) * kGradPitch + 4 + lx;
-			constexpr int  sy = kGradPitch, sz = (kGradTileY + 2) * kGradPitch;
-			const float    v1 = s_unorm[c[+1 - sy - sz]];        // k.xyy = ( 1,-1,-1)
-			const float    v2 = s_unorm[c[-1 - sy + sz]];        // k.yyx = (-1,-1, 1)
-			const float    v3 = s_unorm[c[-1 + sy - sz]];        // k.yxy = (-1, 1,-1)
-			const float    v4 = s_unorm[c[+1 + sy + sz]];        // k.xxx = ( 1, 1, 1)
-			// get_gradient_compute.glsl:12-20, the operations of gradient_from_taps with the short exact sqrt.  The three factors 0.25 are
-			// taken out: scaling by a power of two commutes with every rounding on the way (squares x 2^-4, their sums, the root x 2^-2;
-			// nothing comes near the denormal range: the sum is 0 or >= ~1e-17), so sqrt(sum of (0.25 s)^2) * m == sqrt(sum of s^2) * (0.25 m)
-			// bit for bit (quarter_modifier = 0.25 * modifier is exact as well)
-			const float sx  = ((v1 - v2) - v3) + v4;
-			const float sy_ = ((-v1 - v2) + v3) + v4;
-			const float sz_ = ((-v1 + v2) - v3) + v4;
+				reinterpret_cast<uint2 *>(s_tile)[threadIdx.x + 256 * j] = make_uint2((v[j] & 0x00ff00ffu) << 2, (v[j] & 0xff00ff00u) >> 6);
+		__syncthreads();
+		if (k + 1 < k1)
+			fetch(k + 1);        // in flight during the arithmetic below
+		const int z0 = (int) k * kGradTileZ;
+		// the four taps of TWO voxels (rows ly0, ly0 + 1 of slice lz; k.xyy, k.yyx, k.yxy, k.xxx of get_gradient_compute.glsl:8-11): all reads
+		// of a stage are issued before the first is used
+		auto taps = [&](int lz, float(&a)[4], float(&b)[4]) {
+			const int      r  = ((lz + 1) * (kGradTileY + 2) + (ly0 + 1)) * kGradPitch;
+			const uint32_t a0 = s_tile[r + cp - sy - sz], a1 = s_tile[r + cm - sy + sz], a2 = s_tile[r + cm + sy - sz], a3 = s_tile[r + cp + sy + sz];
+			const uint32_t b0 = s_tile[r + cp - sz], b1 = s_tile[r + cm + sz], b2 = s_tile[r + cm + 2 * sy - sz], b3 = s_tile[r + cp + 2 * sy + sz];
+			__builtin_amdgcn_wave_barrier();
+			auto at = [&](uint32_t o) { return *reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(s_unorm) + o); };
+			a[0] = at(a0), a[1] = at(a1), a[2] = at(a2), a[3] = at(a3);
+			b[0] = at(b0), b[1] = at(b1), b[2] = at(b2), b[3] = at(b3);
+			__builtin_amdgcn_wave_barrier();
+		};
+		// get_gradient_compute.glsl:12-20, the operations of gradient_from_taps with the short exact sqrt.  The three factors 0.25 are
+		// taken out: scaling by a power of two commutes with every rounding on the way (squares x 2^-4, their sums, the root x 2^-2;
+		// nothing comes near the denormal range: the sum is 0 or >= ~1e-17), so sqrt(sum of (0.25 s)^2) * m == sqrt(sum of s^2) * (0.25 m)
+		// bit for bit (quarter_modifier = 0.25 * modifier is exact as well).
+		// (The empty asm statements keep the three chains scalar: the packed v_pk_add_f32 the compiler forms otherwise issue at 4.4 cycles
+		// for two results, no faster than two full-rate scalar operations, and cost two v_mov to assemble their operands.)
+		auto finish = [&](const float(&q)[4]) -> uint32_t {
+			float tx = q[0] - q[1], ty = -q[0] - q[1];
+			asm volatile("" : "+v"(tx));
+			asm volatile("" : "+v"(ty));
+			float       sx = (tx - q[2]) + q[3], sy_ = (ty + q[2]) + q[3];
+			const float sz_ = ((-q[0] + q[1]) - q[2]) + q[3];
+			asm volatile("" : "+v"(sx));
+			asm volatile("" : "+v"(sy_));
 			const float len = sqrt_rn_normal((sx * sx + sy_ * sy_) + sz_ * sz_);
-			grad[vidx(x, y, z, W, H)] = store_unorm8_clamped(len * quarter_modifier);
+			return store_unorm8_clamped(len * quarter_modifier);
+		};
+		uint8_t *gz = grad + (size_t) z0 * (size_t) W * (size_t) H;        // wave-uniform base, advanced per slice on the scalar unit
+		if (x0 + kGradTileX <= W && y0 + kGradTileY <= H && z0 + kGradTileZ <= D)
+		{        // interior tile: no masks, the eight slices unrolled
+#pragma unroll
+			for (int lz = 0; lz < kGradTileZ; ++lz)
+			{
+				float a[4], b[4];
+				taps(lz, a, b);
+				store_u8_uniform_base(gz, off, finish(a));
+				store_u8_uniform_base(gz, off1, finish(b));
+				gz += (size_t) W * (size_t) H;
+			}
 		}
+		else if (x < W)
+			for (int lz = 0; lz < kGradTileZ && z0 + lz < D; ++lz)
+			{
+				float a[4], b[4];
+				taps(lz, a, b);
+				if (y0 + ly0 < H)
+					gz[off] = (uint8_t) finish(a);
+				if (y0 + ly0 + 1 < H)
+					gz[off1] = (uint8_t) finish(b);
+				gz += (size_t) W * (size_t) H;
+			}
 	}
 }
 
@@ -1039,14 +1111,18 @@ int launch_gradient_map(vkv_ctx *ctx, const uint8_t *d_vol, uint8_t *d_grad, Vkv
 	// the tiled kernel folds the three factors 0.25 into the modifier: exact unless 0.25 * modifier is denormal (or the modifier no number)
 	const float m_abs    = std::fabs(tf->grad_magnitude_modifier);
 	const bool  m_normal = m_abs == 0.0f || (m_abs >= 1e-30f && m_abs <= 1e30f);
-	if (tf->use_gradient && m_normal && (e.width & 3u) == 0 && (((uintptr_t) d_vol) & 3u) == 0)
+	if (tf->use_gradient && m_normal && (e.width & 3u) == 0 && (((uintptr_t) d_vol) & 3u) == 0 && (uint64_t) e.width * e.height * (kGradTileZ + 2) <= 0xffffffffull)
 	{
 		const uint64_t tx = (e.width + kGradTileX - 1) / kGradTileX, ty = (e.height + kGradTileY - 1) / kGradTileY,
 		               tz = (e.depth + kGradTileZ - 1) / kGradTileZ;
-		if (tx * ty * tz <= 0x7fffffffull)
+		// kGradSegment tiles per workgroup, fewer when the volume would not give every CU its eight workgroups otherwise
+		const uint64_t want = (uint64_t) 8 * (uint64_t) std::max(1, ctx->cu_count);
+		const uint32_t seg  = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(kGradSegment, tx * ty * tz / want));
+		const uint64_t n_wgs = tx * ty * ((tz + seg - 1) / seg);
+		if (n_wgs <= 0x7fffffffull)
 		{
-			hipLaunchKernelGGL(k_gradient_map_tiled, dim3((uint32_t) (tx * ty * tz)), dim3(256), 0, s, d_vol, d_grad, (int) e.width, (int) e.height,
-			                   (int) e.depth, tf->grad_magnitude_modifier, (uint32_t) tx, (uint32_t) ty, (uint32_t) (tx * ty * tz));
+			hipLaunchKernelGGL(k_gradient_map_tiled, dim3((uint32_t) n_wgs), dim3(256), 0, s, d_vol, d_grad, (int) e.width, (int) e.height, (int) e.depth,
+			                   tf->grad_magnitude_modifier, (uint32_t) tx, (uint32_t) ty, (uint32_t) tz, seg, (uint32_t) n_wgs);
 			return check_launch(ctx, "gradient_map");
 		}
 	}
