@@ -81,6 +81,24 @@ def test_gradient_kernel_shortcuts_are_exact(ctx):
     assert bad.tolist() == [0, 0]
 
 
+@pytest.mark.parametrize("shape,segment", [((260, 40, 50), 3), ((192, 24, 67), 2), ((132, 9, 33), 10), ((64, 8, 80), 4), ((200, 17, 26), 255)])
+def test_gradient_map_marching_workgroups(ctx, shape, segment):
+    """The tiled kernel's workgroups march over `segment` tiles in z with the next tile prefetched; volumes this small run one tile per
+    workgroup unless VKV_GRADIENT_SEGMENT (read per call) forces the march: interior and edge tiles in x, clamped first / last tiles in
+    z, a last segment that is shorter, a depth that is no multiple of the tile."""
+    import os
+    vol = T.random_volume(shape, seed=21 + segment)
+    tf = lib.transfer_function_uniform(abi.VolumeOptions(**T.APP_TF))
+    d_vol, d_grad = dev(vol), torch.empty(vol.shape, dtype=torch.uint8, device="cuda")
+    os.environ["VKV_GRADIENT_SEGMENT"] = str(segment)
+    try:
+        ctx.gradient_map(d_vol.data_ptr(), d_grad.data_ptr(), abi.Extent3D(*shape), tf, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["VKV_GRADIENT_SEGMENT"]
+    assert np.array_equal(d_grad.cpu().numpy(), O.gradient_map(vol, tf))
+
+
 def test_gradient_map_smooth_volume(ctx):
     vol = O.synth_volume((96, 80, 72), 1, 5)
     tf = lib.transfer_function_uniform(abi.VolumeOptions(**T.APP_TF))

@@ -1117,7 +1117,9 @@ int launch_gradient_map(vkv_ctx *ctx, const uint8_t *d_vol, uint8_t *d_grad, Vkv
 		               tz = (e.depth + kGradTileZ - 1) / kGradTileZ;
 		// kGradSegment tiles per workgroup, fewer when the volume would not give every CU its eight workgroups otherwise
 		const uint64_t want = (uint64_t) 8 * (uint64_t) std::max(1, ctx->cu_count);
-		const uint32_t seg  = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(kGradSegment, tx * ty * tz / want));
+		uint32_t       seg  = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(kGradSegment, tx * ty * tz / want));
+		if (const char *env = std::getenv("VKV_GRADIENT_SEGMENT"))        // read per call: lets a test march a small volume
+			seg = (uint32_t) std::min<long>(std::max<long>(std::atol(env), 1), 255);
 		const uint64_t n_wgs = tx * ty * ((tz + seg - 1) / seg);
 		if (n_wgs <= 0x7fffffffull)
 		{
