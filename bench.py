@@ -403,7 +403,7 @@ def main():
         gb1 = float(np.mean(frame_bytes)) / (ms1 * 1e-3) / 1e9
         single = {"ms_per_launch": round(ms1, 4), "achieved": round(gb1, 2), "frac": round(gb1 / HBM_PEAK_GBS, 5),
                   "Mray_per_s": round(rays_per_frame_all / ms1 / 1e3, 1), "per_view_ms": [round(x, 4) for x in per_view],
-                  "note": "one vkv_render launch per frame with nothing else on the GPU: median of 5 per view, mean over the 8 views"}
+                  "note": "one vkv_render launch per frame with nothing else on the GPU: median of 5 per view, mean over the 8 views (the same view into the same target: measured start order, 0.256 ms with VKV_RAYMARCH_FEEDBACK=0)"}
 
     # whole-job sample rates need every rank's counters
     tot = torch.tensor([sum(n_vs[k % N_VIEWS] for k in range(args.steps)), sum(n_ds[k % N_VIEWS] for k in range(args.steps)),
@@ -440,7 +440,7 @@ def main():
                    "output": "RGBA8",
                    "submission": ("vkv_render_batch, up to %d frames per launch, consecutive launches on %d HIP stream(s); tile start order from the "
                                   "tile costs measured on earlier frames into the same target (each target shows the same orbit view every block: the best "
-                                  "case for that feedback; VKV_RAYMARCH_FEEDBACK=0 measured 0.1205 instead of 0.1157 ms per frame on c3)" % (fpl, nbs)) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams" % (fif, fif)),
+                                  "case for that feedback; VKV_RAYMARCH_FEEDBACK=0 measured 0.1205 instead of 0.1157 ms per frame on c3)" % (fpl, nbs)) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams (measured start order per target as well)" % (fif, fif)),
                    "occupied_voxel_percent": round(occupied_voxel_percent(ctx, v, tf), 4)},
         "covered_Mray_per_s": round(cov_total / elapsed / 1e6, 3), "covered_fraction": round(cov_total / (rays_per_frame_all * args.steps), 4),
         "volume_samples_per_s": round(vs_total / elapsed, 1), "distance_probes_per_s": round(ds_total / elapsed, 1),

@@ -383,6 +383,37 @@ def test_render_parity_under_each_kernel_selection_switch(switch):
 
 
 @pytest.mark.gpu
+def test_render_start_order_feedback_against_the_oracle(ctx):
+    """vkv_render (one frame per launch) measures tile costs on the first frame into a target and every 8th one after it and starts the
+    tiles of the following frames longest first: 19 frames into ONE set of output buffers, two views alternating in blocks of three (so
+    orders derived from the other view are used too), every frame compared with the oracle (counters bit-exact)."""
+    opt = abi.VolumeOptions(**T.APP_TF)
+    scene = T.OracleScene(O.synth_volume((64, 56, 48), 1, 321), opt, 4)
+    v, tf = make_gpu_volume(ctx, scene)
+    V.ComputeDistanceMap(ctx).compute(v, tf, abi.SKIP_DISTANCE)
+    size = (208, 112)
+    ro = abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0)
+    assert ro.early_ray_termination
+    sp = V.VolumeRenderSubpass(ctx, v, ro, size)
+    views, refs = [], []
+    for az in (25.0, 205.0):
+        view, proj = T.orbit(az, image_size=size)
+        params = scene.params(view, proj, size, ro)
+        views.append(sp.bind(params))
+        refs.append(scene.render(params))
+    color = torch.empty((size[1], size[0], 4), dtype=torch.float32, device="cuda")
+    counts = torch.empty((size[1], size[0], 3), dtype=torch.int32, device="cuda")
+    depth = torch.empty((size[1], size[0]), dtype=torch.float32, device="cuda")
+    for frame in range(19):
+        k = (frame // 3) % 2
+        color.fill_(-1.0), counts.fill_(0xFFFF), depth.fill_(-1.0)
+        sp.draw(views[k], color, None, counts, depth)
+        torch.cuda.synchronize()
+        got = (color.cpu().numpy(), counts.cpu().numpy().astype(np.uint32), depth.cpu().numpy(), None)
+        compare_render(got, refs[k], "frame %d (view %d)" % (frame, k))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("size", [(208, 112), (2608, 1040)])
 def test_render_batch_start_order_feedback_keeps_the_frames(ctx, size):
     """vkv_render_batch re-orders the tiles of a frame by the costs the previous frame into the same target measured (a counting sort
