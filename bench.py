@@ -235,7 +235,8 @@ def main():
                 images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
         bufs, my_rays = gather.buffers, gather.my_ray_count()
     else:
-        nbuf = fpl * nbs if submit == "batch" else fif
+        # per-frame submission: as many targets as keep every target on ONE of the orbit views (like the slots of the batch path)
+        nbuf = fpl * nbs if submit == "batch" else -(-fif // N_VIEWS) * N_VIEWS
         bufs, my_rays = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)], fw * fh
     torch.cuda.synchronize()
     # algorithmic bytes of one frame (this rank's part): 8 B per trilinear footprint of the volume, 8 more for the gradient map's when the
@@ -440,7 +441,7 @@ def main():
                    "output": "RGBA8",
                    "submission": ("vkv_render_batch, up to %d frames per launch, consecutive launches on %d HIP stream(s); tile start order from the "
                                   "tile costs measured on earlier frames into the same target (each target shows the same orbit view every block: the best "
-                                  "case for that feedback; VKV_RAYMARCH_FEEDBACK=0 measured 0.1205 instead of 0.1157 ms per frame on c3)" % (fpl, nbs)) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams (measured start order per target as well)" % (fif, fif)),
+                                  "case for that feedback; VKV_RAYMARCH_FEEDBACK=0 measured 0.1205 instead of 0.1157 ms per frame on c3)" % (fpl, nbs)) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams (measured start order per target as well; each of the %d targets shows one orbit view)" % (fif, fif, nbuf)),
                    "occupied_voxel_percent": round(occupied_voxel_percent(ctx, v, tf), 4)},
         "covered_Mray_per_s": round(cov_total / elapsed / 1e6, 3), "covered_fraction": round(cov_total / (rays_per_frame_all * args.steps), 4),
         "volume_samples_per_s": round(vs_total / elapsed, 1), "distance_probes_per_s": round(ds_total / elapsed, 1),

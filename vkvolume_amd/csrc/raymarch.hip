@@ -253,7 +253,7 @@ static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a, hipStream_t s)
 			(void) hipFree(cost);
 			return false;
 		}
-		f = new (std::nothrow) vkv_ctx::TileFeedback{target, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count, cost, order, false, 0u, {}};
+		f = new (std::nothrow) vkv_ctx::TileFeedback{target, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count, cost, order, false, 0u, 0u, {}};
 		if (f)
 		{
 			f->identity.resize(a.tile_count);
@@ -278,12 +278,37 @@ static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a, hipStream_t s)
 	// costs are measured (and sorted behind the render) on the first frame into a target and then every `period`-th one: a camera that
 	// moves little keeps the order good for a few frames, and the sort kernel + the cost atomics are then paid once per period
 	static const uint32_t period = [] { const char *e = std::getenv("VKV_RAYMARCH_FEEDBACK_PERIOD"); const long v = e ? std::atol(e) : 8; return (uint32_t) (v < 1 ? 1 : v); }();
-	const bool            measure = f->frames % period == 0;
+	// the view of this frame: central ray (normalised) and camera position in texture space.  Costs measured on a view that was more
+	// than ~12 degrees away (or from a camera that has moved by more than a fifth of its distance to the volume's centre) say little
+	// about this frame - an order sorted by them scatters the heavy tiles (measured: -3 % for targets that alternate between views
+	// 45 degrees apart) - so such a frame starts centre-first, and the next measurement comes after 4 frames instead of `period`.
+	float dir[3], len2 = 0.0f;
+	for (int i = 0; i < 3; ++i)
+	{
+		dir[i] = a.dir00[i] + 0.5f * ((float) a.img_w * a.ddx[i] + (float) a.img_h * a.ddy[i]);
+		len2 += dir[i] * dir[i];
+	}
+	const float inv = len2 > 0.0f ? 1.0f / std::sqrt(len2) : 0.0f;
+	float       cosine = 0.0f, moved2 = 0.0f, dist2 = 0.0f;
+	for (int i = 0; i < 3; ++i)
+	{
+		dir[i] *= inv;
+		cosine += dir[i] * f->view_dir[i];
+		moved2 += (a.cam[i] - f->view_pos[i]) * (a.cam[i] - f->view_pos[i]);
+		dist2 += (f->view_pos[i] - 0.5f) * (f->view_pos[i] - 0.5f);
+	}
+	const bool     stale   = f->has_cost && !(cosine >= 0.978f && moved2 <= 0.04f * dist2);
+	const uint32_t since   = f->frames - f->measured_at;
+	const bool     measure = !f->has_cost || since >= period || (stale && since >= std::min(period, 4u));
+	if (measure)
+		f->measured_at = f->frames;
 	++f->frames;
-	if (f->has_cost)
+	if (f->has_cost && !stale)
 		a.tile_order = f->d_order;        // the order the last sort behind a frame into this target left
 	if (!measure)
 		return false;
+	for (int i = 0; i < 3; ++i)
+		f->view_dir[i] = dir[i], f->view_pos[i] = a.cam[i];
 	a.tile_cost = f->d_cost;
 	a.order_out = f->d_order;        // written by the sort that FOLLOWS this frame's render on the stream
 	f->has_cost = true;

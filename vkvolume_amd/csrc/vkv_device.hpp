@@ -158,7 +158,9 @@ struct vkv_ctx
 		uint32_t *  d_cost, *d_order;
 		bool        has_cost;        // a frame has been rendered into this target with the cost buffer attached
 		uint32_t    frames;          // frames rendered into this target so far (costs are measured and sorted every few frames)
+		uint32_t    measured_at = 0; // value of `frames` at the last measured frame
 		std::vector<uint32_t> identity;        // 0 .. count - 1: what d_order holds until the first sort (kept: source of an asynchronous copy)
+		float       view_dir[3] = {0, 0, 0}, view_pos[3] = {0, 0, 0};        // central ray and camera position (texture space) of the measured frame
 	};
 	std::vector<TileFeedback *> feedback;
 };
