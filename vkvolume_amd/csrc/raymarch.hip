@@ -223,6 +223,9 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a, hipStream_t s)
 {
 	static const bool off = [] { const char *e = std::getenv("VKV_RAYMARCH_FEEDBACK"); return e && e[0] == '0'; }();
+	// costs are measured (and sorted behind the render) on the first frame into a target and then every `period`-th one: a camera that
+	// moves little keeps the order good for a few frames, and the sort kernel + the cost atomics are then paid once per period
+	static const uint32_t period = [] { const char *e = std::getenv("VKV_RAYMARCH_FEEDBACK_PERIOD"); const long v = e ? std::atol(e) : 8; return (uint32_t) (v < 1 ? 1 : v); }();
 	const void *      target = a.out_rgba8 ? (const void *) a.out_rgba8 : (const void *) a.out_color;
 	if (off || !target || a.tile_count < 64 || ctx->d_debug_orders)
 		return false;
@@ -253,7 +256,7 @@ static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a, hipStream_t s)
 			(void) hipFree(cost);
 			return false;
 		}
-		f = new (std::nothrow) vkv_ctx::TileFeedback{target, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count, cost, order, false, 0u, 0u, {}};
+		f = new (std::nothrow) vkv_ctx::TileFeedback{target, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count, cost, order, false, 0u, 0u, period, 0u, {}};
 		if (f)
 		{
 			f->identity.resize(a.tile_count);
@@ -275,13 +278,10 @@ static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a, hipStream_t s)
 		}
 		ctx->feedback.push_back(f);
 	}
-	// costs are measured (and sorted behind the render) on the first frame into a target and then every `period`-th one: a camera that
-	// moves little keeps the order good for a few frames, and the sort kernel + the cost atomics are then paid once per period
-	static const uint32_t period = [] { const char *e = std::getenv("VKV_RAYMARCH_FEEDBACK_PERIOD"); const long v = e ? std::atol(e) : 8; return (uint32_t) (v < 1 ? 1 : v); }();
 	// the view of this frame: central ray (normalised) and camera position in texture space.  Costs measured on a view that was more
 	// than ~12 degrees away (or from a camera that has moved by more than a fifth of its distance to the volume's centre) say little
 	// about this frame - an order sorted by them scatters the heavy tiles (measured: -3 % for targets that alternate between views
-	// 45 degrees apart) - so such a frame starts centre-first, and the next measurement comes after 4 frames instead of `period`.
+	// 45 degrees apart) - so such a frame starts centre-first.
 	float dir[3], len2 = 0.0f;
 	for (int i = 0; i < 3; ++i)
 	{
@@ -299,12 +299,21 @@ static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a, hipStream_t s)
 	}
 	const bool     stale   = f->has_cost && !(cosine >= 0.978f && moved2 <= 0.04f * dist2);
 	const uint32_t since   = f->frames - f->measured_at;
-	const bool     measure = !f->has_cost || since >= period || (stale && since >= std::min(period, 4u));
+	const bool     measure = !f->has_cost || since >= f->period;
 	if (measure)
+	{
+		// a measurement whose order no frame could use (the target kept jumping between far views) doubles the distance to the next
+		// one, up to 8 periods: such a target then pays next to nothing for the feedback it cannot use
+		f->period      = (f->has_cost && f->used == 0) ? std::min(2u * f->period, 8u * period) : period;
 		f->measured_at = f->frames;
+		f->used        = 0;
+	}
 	++f->frames;
 	if (f->has_cost && !stale)
+	{
 		a.tile_order = f->d_order;        // the order the last sort behind a frame into this target left
+		++f->used;
+	}
 	if (!measure)
 		return false;
 	for (int i = 0; i < 3; ++i)

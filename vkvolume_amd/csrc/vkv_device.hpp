@@ -159,6 +159,8 @@ struct vkv_ctx
 		bool        has_cost;        // a frame has been rendered into this target with the cost buffer attached
 		uint32_t    frames;          // frames rendered into this target so far (costs are measured and sorted every few frames)
 		uint32_t    measured_at = 0; // value of `frames` at the last measured frame
+		uint32_t    period = 8;      // frames until the next measurement (doubles while no frame can use the measured order)
+		uint32_t    used = 0;        // frames since the last measurement that started in its order
 		std::vector<uint32_t> identity;        // 0 .. count - 1: what d_order holds until the first sort (kept: source of an asynchronous copy)
 		float       view_dir[3] = {0, 0, 0}, view_pos[3] = {0, 0, 0};        // central ray and camera position (texture space) of the measured frame
 	};
