@@ -573,7 +573,7 @@ __device__ __forceinline__ void ray_finish(const RayMarchArgs &A, Ray &R, bool m
 		if (A.out_color)
 			reinterpret_cast<float4 *>(A.out_color)[o] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		if (A.out_rgba8)
-			reinterpret_cast<uint32_t *>(A.out_rgba8)[o] = 0u;
+			__builtin_nontemporal_store(0u, reinterpret_cast<uint32_t *>(A.out_rgba8) + o);
 		if (A.out_counts)
 			A.out_counts[o * 3 + 0] = A.out_counts[o * 3 + 1] = A.out_counts[o * 3 + 2] = 0;
 		if (A.out_depth)
@@ -609,9 +609,11 @@ __device__ __forceinline__ void ray_finish(const RayMarchArgs &A, Ray &R, bool m
 	}
 	if (A.out_color)
 		reinterpret_cast<float4 *>(A.out_color)[o] = make_float4(R.r, R.g, R.b, R.a);
+	// (non-temporal: the frame is not read again by this kernel, and its 8 MB per frame would otherwise push volume bricks out of the L2s:
+	// 0.1157 -> 0.1139 ms per frame on C3)
 	if (A.out_rgba8)
-		reinterpret_cast<uint32_t *>(A.out_rgba8)[o] = (uint32_t) quantise_rgba8(R.r) | ((uint32_t) quantise_rgba8(R.g) << 8) |
-		                                               ((uint32_t) quantise_rgba8(R.b) << 16) | ((uint32_t) quantise_rgba8(R.a) << 24);
+		__builtin_nontemporal_store((uint32_t) quantise_rgba8(R.r) | ((uint32_t) quantise_rgba8(R.g) << 8) |
+		                                               ((uint32_t) quantise_rgba8(R.b) << 16) | ((uint32_t) quantise_rgba8(R.a) << 24), reinterpret_cast<uint32_t *>(A.out_rgba8) + o);
 	if (A.out_counts)
 	{
 		A.out_counts[o * 3 + 0] = R.n_vol;
