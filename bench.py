@@ -408,7 +408,7 @@ def main():
         gb1 = float(np.mean(frame_bytes)) / (ms1 * 1e-3) / 1e9
         single = {"ms_per_launch": round(ms1, 4), "achieved": round(gb1, 2), "frac": round(gb1 / HBM_PEAK_GBS, 5),
                   "Mray_per_s": round(rays_per_frame_all / ms1 / 1e3, 1), "per_view_ms": [round(x, 4) for x in per_view],
-                  "note": "one vkv_render launch per frame with nothing else on the GPU: a view rendered 7 times in a row into its own target (a static camera: start order from the costs measured on the first of them, caches warm from the same view; the views in turn measure 0.251, VKV_RAYMARCH_FEEDBACK=0 0.256 / 0.249 ms), median of the last 5, mean over the 8 views"}
+                  "note": "one vkv_render launch per frame with nothing else on the GPU: a view rendered 7 times in a row into its own target (a static camera: start order from the costs measured on the first of them, caches warm from the same view; the views in turn measure about 0.245, VKV_RAYMARCH_FEEDBACK=0 about 0.25 / 0.245 ms), median of the last 5, mean over the 8 views"}
 
     # whole-job sample rates need every rank's counters
     tot = torch.tensor([sum(n_vs[k % N_VIEWS] for k in range(args.steps)), sum(n_ds[k % N_VIEWS] for k in range(args.steps)),
@@ -445,7 +445,7 @@ def main():
                    "output": "RGBA8",
                    "submission": ("vkv_render_batch, up to %d frames per launch, consecutive launches on %d HIP stream(s); tile start order from the "
                                   "tile costs measured on earlier frames into the same target (each target shows the same orbit view every block: the best "
-                                  "case for that feedback; VKV_RAYMARCH_FEEDBACK=0 measured 0.1205 instead of 0.1157 ms per frame on c3)" % (fpl, nbs)) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams (measured start order per target as well; each of the %d targets shows one orbit view)" % (fif, fif, nbuf)),
+                                  "case for that feedback; VKV_RAYMARCH_FEEDBACK=0 measured 0.119 instead of 0.114 ms per frame on c3)" % (fpl, nbs)) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams (measured start order per target as well; each of the %d targets shows one orbit view)" % (fif, fif, nbuf)),
                    "occupied_voxel_percent": round(occupied_voxel_percent(ctx, v, tf), 4)},
         "covered_Mray_per_s": round(cov_total / elapsed / 1e6, 3), "covered_fraction": round(cov_total / (rays_per_frame_all * args.steps), 4),
         "volume_samples_per_s": round(vs_total / elapsed, 1), "distance_probes_per_s": round(ds_total / elapsed, 1),
