@@ -414,6 +414,30 @@ def test_render_start_order_feedback_against_the_oracle(ctx):
 
 
 @pytest.mark.gpu
+def test_start_order_feedback_forgets_old_targets(ctx):
+    """The context keeps feedback state for at most 256 targets and drops the oldest beyond that: 300 targets in turn, twice (the second
+    round finds its first targets forgotten and starts over), every frame equal to the first one."""
+    opt = abi.VolumeOptions(**T.APP_TF)
+    scene = T.OracleScene(O.synth_volume((48, 40, 36), 1, 77), opt, 4)
+    v, tf = make_gpu_volume(ctx, scene)
+    V.ComputeDistanceMap(ctx).compute(v, tf, abi.SKIP_DISTANCE)
+    size = (128, 128)  # 64 tiles: the smallest schedule that takes part in the feedback
+    ro = abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0)
+    sp = V.VolumeRenderSubpass(ctx, v, ro, size)
+    view, proj = T.orbit(40.0, image_size=size)
+    p = sp.bind(scene.params(view, proj, size, ro))
+    targets = [torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda") for _ in range(300)]
+    for rnd in range(2):
+        for t in targets:
+            t.fill_(7)
+            sp.draw(p, None, t)
+        torch.cuda.synchronize()
+        assert int(targets[0].sum().item()) > 0
+        for j, t in enumerate(targets[1:]):
+            assert torch.equal(t, targets[0]), "round %d, target %d" % (rnd, j + 1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("size", [(208, 112), (2608, 1040)])
 def test_render_batch_start_order_feedback_keeps_the_frames(ctx, size):
     """vkv_render_batch re-orders the tiles of a frame by the costs the previous frame into the same target measured (a counting sort
