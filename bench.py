@@ -29,8 +29,9 @@ configs[4]): the frame stays 7680x4320 whatever N is.  value = rays of all ranks
 
 Rank 0 prints ONE JSON line.  `roofline` prices the ray-march kernel by ALGORITHMIC bytes (16 B per volume sample,
 1 B per distance probe, 4 B per ray of RGBA8 output) of one launch over that launch's HIP-event duration; `cpu_baseline` times the
-CPU oracle (a scalar port of the reference shaders) on a pixel-strided sample of the same frames; `--verify-cpu` also compares
-those oracle pixels (three counters + RGBA8) with the device's, bit for bit.
+CPU oracle (a scalar port of the reference shaders) on a pixel-strided sample of the same frames (at most three passes), and the
+pixels it rendered (three counters + RGBA8) are then compared with the device's frames, bit for bit: `verified_against_cpu` in the
+line, exit status 1 on a mismatch (`--no-verify-cpu` skips the comparison).
 """
 import argparse
 import json
@@ -38,6 +39,59 @@ import math
 import os
 import sys
 import time
+
+
+
+def self_launch(argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the PARENT of the job.  It starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a
+    child BEFORE anything here has touched the GPU (no exec from a process that has initialised HIP: it never initialises it), relays
+    the one JSON line rank 0 prints and exits with the children's status.  `--dry-launch` prints the child command line instead."""
+    import socket
+    import subprocess
+    n, dry = 1, False
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+        elif a == "--dry-launch":
+            dry = True
+    if n <= 1 or "WORLD_SIZE" in os.environ:
+        return  # a rank of an existing job (or N = 1): run in this process
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    child_args = [a for a in argv if a != "--dry-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.abspath(__file__)] + child_args
+    if dry:
+        print(json.dumps({"dry_launch": cmd, "n_ranks": n}))
+        raise SystemExit(0)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out_line in proc.stdout:  # rank 0 prints exactly one JSON line; anything else a child writes to stdout goes to stderr
+        t = out_line.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr)
+    rc = proc.wait()
+    if rc != 0:
+        raise SystemExit(rc if rc > 0 else 1)
+    if line is None:
+        print("bench.py: the ranks finished without a result line", file=sys.stderr)
+        raise SystemExit(1)
+    print(line, flush=True)
+    raise SystemExit(0)
+
+
+if __name__ == "__main__":
+    self_launch(sys.argv[1:])
 
 # ROCclr multiplexes HIP streams onto 4 hardware queues by default; frames in flight, the assembly stream and RCCL's own
 # stream need one each or they serialise behind each other (measured: 0.27 -> 0.20 ms per step on the gather path).
@@ -52,7 +106,7 @@ if ROOT not in sys.path:
 
 from vkvolume_amd import abi, camera, lib, multigpu, volume as V  # noqa: E402
 
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_traffic.json")  # PMC-measured HBM bytes per launch (own rocprofv3 passes)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_traffic.json")  # PMC-measured HBM bytes per launch (own rocprofv3 passes)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 WORKLOADS = {
@@ -73,6 +127,16 @@ GRID = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
 TILE = 16
 N_VIEWS = 8
 B_OUT = 4  # bytes per ray of the RGBA8 frame
+
+
+def kernel_source_digest():
+    """sha256 over the integrator's source files: ties profiles/*_traffic.json to the kernel it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("raymarch_core.hpp", "raymarch.hip", "vkv_device.hpp", "Makefile"):
+        with open(os.path.join(ROOT, "vkvolume_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def build_scene(ctx, name, tf_preset="app"):
@@ -149,8 +213,11 @@ def main():
                     "communicator of our own, no torch.distributed on the data path; 0.190 ms per step in the same test)")
     ap.add_argument("--force-gather", action="store_true", help="exercise the tile gather / de-interleave path with a 1-rank process group")
     ap.add_argument("--verify", action="store_true", help="after timing, check the assembled frame of the last step against a direct render")
-    ap.add_argument("--verify-cpu", action="store_true", help="compare the CPU oracle's pixels (counters + RGBA8) with the device's, bit for bit")
+    ap.add_argument("--verify-cpu", action="store_true", help="(default since round 3; kept for old command lines) compare the CPU oracle's pixels with the device's")
+    ap.add_argument("--no-verify-cpu", action="store_true", help="do not compare the pixels the CPU baseline rendered (counters + RGBA8) with the device's frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 without WORLD_SIZE: print the torch.distributed.run command line the "
+                    "parent would start, and exit")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
 
@@ -158,8 +225,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if world not in GRID:
         raise SystemExit("--gpus must be 1, 2, 4 or 8")
@@ -264,16 +329,32 @@ def main():
                 row.append(q)
             batch_params.append(row)
 
+    # the same parameter blocks with gl_FragDepth written as well (frag:315-321; the reference's subpass always writes depth): timed in a
+    # block of its own after the headline blocks, reported as ms_per_step_with_depth
+    depth_bufs, batch_params_depth = None, None
+    if submit == "batch" and not use_gather:
+        depth_bufs = [torch.zeros((fh, fw), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+        batch_params_depth = []
+        for view_i in range(N_VIEWS):
+            row = []
+            for j in range(nbuf):
+                q = abi.RenderParams.from_buffer_copy(batch_params[view_i][j])
+                q.d_out_depth = depth_bufs[j].data_ptr()
+                row.append(q)
+            batch_params_depth.append(row)
+
     last_slot, last_owner = [0], [0]
+    with_depth = [False]
 
     def run_batch(n_steps, timed):
         k, launch = 0, 0
+        bp = batch_params_depth if with_depth[0] else batch_params
         for n in split_frames(n_steps, fpl):  # 20 steps with 8 per launch: 7 + 7 + 6, not 8 + 8 + 4
             st = streams[launch % nbs]  # stream of this launch
             slot = (launch % nsets) if gather else (launch % nbs)  # its set of output buffers
             owner = (launch % world) if rotate else 0  # gather path: the rank that assembles this launch's frames
             launch += 1
-            plist = [batch_params[(k + j) % N_VIEWS][slot * fpl + j] for j in range(n)]
+            plist = [bp[(k + j) % N_VIEWS][slot * fpl + j] for j in range(n)]
             last_slot[0] = slot * fpl + n - 1  # output buffer of the block's last step (--verify)
             with torch.cuda.stream(st):
                 if gather and freed[slot] is not None:
@@ -382,6 +463,22 @@ def main():
             break
     elapsed = float(np.median(blocks))
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+
+    # ---- the same block with gl_FragDepth written too (not the headline: BASELINE's metric is the colour frame) ------
+    depth_ms = None
+    if batch_params_depth is not None:
+        with_depth[0] = True
+        run(args.warmup, False)
+        dblocks, dtotal = [], 0.0
+        while dtotal < min(0.5, args.min_seconds) and len(dblocks) < 1024:
+            fence()
+            t0 = time.perf_counter()
+            run(args.steps, False)
+            fence()
+            dblocks.append(time.perf_counter() - t0)
+            dtotal += dblocks[-1]
+        with_depth[0] = False
+        depth_ms = float(np.median(dblocks)) / args.steps * 1e3
     alg_avg = sum(kernel_bytes) / len(kernel_bytes)
     achieved_gbs = alg_avg / (kernel_ms_avg * 1e-3) / 1e9
 
@@ -427,11 +524,14 @@ def main():
         return
 
     value = rays_per_frame_all * args.steps / elapsed / 1e6
+    aggregate_gbs = sum(frame_bytes[k % N_VIEWS] for k in range(args.steps)) / elapsed / 1e9
+    kernel_name = "k_raymarch_lean_batch" if (submit == "batch" and fpl > 1) else "k_raymarch_lean"
+    concurrent = nbs if submit == "batch" else fif
     extent = WORKLOADS[args.workload][0]
     out = {
         "metric": "Mray/s", "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic", "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
         "repeats": len(blocks), "host_enqueue_ms_per_step": round(float(np.median(enqueue_times)) / args.steps * 1e3, 4), "ms_per_step_min_max": [round(min(blocks) / args.steps * 1e3, 4), round(max(blocks) / args.steps * 1e3, 4)],
         "config": {"workload": "%s (%s): %dx%dx%d uint8 synthetic shells, %dx%d frame, %s, block 4, TF %s, "
                                "8 orbit views" % (args.workload, WORKLOAD_NOTE[args.workload], *extent, fw, fh,
@@ -449,40 +549,48 @@ def main():
                    "occupied_voxel_percent": round(occupied_voxel_percent(ctx, v, tf), 4)},
         "covered_Mray_per_s": round(cov_total / elapsed / 1e6, 3), "covered_fraction": round(cov_total / (rays_per_frame_all * args.steps), 4),
         "volume_samples_per_s": round(vs_total / elapsed, 1), "distance_probes_per_s": round(ds_total / elapsed, 1),
-        "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
-                     "kernel": "k_raymarch_lean_batch" if (submit == "batch" and fpl > 1) else "k_raymarch_lean", "kernel_ms_avg": round(kernel_ms_avg, 4),
+        "roofline": {"bound": "hbm", "achieved": round(aggregate_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(aggregate_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                     "kernel": kernel_name, "kernel_ms_avg": round(kernel_ms_avg, 4),
                      "frames_per_launch": round(sum(kernel_frames) / len(kernel_frames), 3),
                      "algorithmic_bytes_per_launch": int(alg_avg),
-                     "achieved_aggregate": round(sum(frame_bytes[k % N_VIEWS] for k in range(args.steps)) / elapsed / 1e9, 2),
-                     "frac_aggregate": round(sum(frame_bytes[k % N_VIEWS] for k in range(args.steps)) / elapsed / 1e9 / HBM_PEAK_GBS, 5),
-                     "concurrent_launches": (nbs if submit == "batch" else fif),
+                     "achieved_per_launch": round(achieved_gbs, 2), "frac_per_launch": round(achieved_gbs / HBM_PEAK_GBS, 5),
+                     "concurrent_launches": concurrent,
                      "note": "algorithmic (requested) bytes: 16 B/volume sample (8 with the intensity-only TF) + 1 B/distance probe + 4 B/ray, summed over the frames of a launch; NOT "
-                             "DRAM traffic. achieved = bytes of a launch / HIP-event duration of that launch, averaged over the timed launches; "
-                             "achieved_aggregate / frac_aggregate = this rank's bytes of one timed block / its wall time (with concurrent_launches > 1 "
-                             "the launches of a block overlap, so one launch's duration covers work of the others: per-launch achieved is then a "
-                             "share of the device, the aggregate is the device; single_frame is the same kernel with nothing else running); "
-                             "HIP events bracket every launch at N = 1 "
-                             "and every 7th launch on the gather path (where launches of consecutive frames overlap)"},
+                             "DRAM traffic. achieved / frac = the DEVICE-level rate: this rank's algorithmic bytes of one timed block / the block's wall "
+                             "time between its fences (what the chip delivered, whatever the launches' overlap). achieved_per_launch / frac_per_launch = "
+                             "bytes of one launch / the HIP-event duration of that launch (kernel_ms_avg), averaged over the timed launches: with "
+                             "concurrent_launches > 1 the launches of a block overlap, one launch's duration then covers work of the others and the "
+                             "per-launch figure is only that launch's share of the device; with concurrent_launches = 1 the two agree up to the "
+                             "gaps between launches. single_frame is the same kernel with nothing else running. HIP events bracket every launch at "
+                             "N = 1 and every 7th launch on the gather path (where launches of consecutive frames overlap)"},
     }
     if single is not None:
         out["single_frame"] = single
+    if depth_ms is not None:
+        out["ms_per_step_with_depth"] = round(depth_ms, 4)
 
     # HBM traffic cannot be read from inside the process; it comes from separate rocprofv3 --pmc passes over this same
-    # command (FETCH_SIZE and WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), committed under profiles/
+    # command (FETCH_SIZE and WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes and calibrated on the integrator's own gather
+    # pattern, tools/micro/gather_fetch.hip), committed under profiles/.  The file names the sources it was measured on (a digest of the
+    # integrator's source files + the commit): a tree whose integrator differs gets "traffic": null instead of a stale figure.
     try:
         with open(TRAFFIC_FILE) as f:
             tr = json.load(f)
+        out["roofline"]["traffic_commit"] = tr.get("commit")
         if (tr.get("workload") == args.workload and world == 1 and tr.get("kernel") == out["roofline"]["kernel"] and args.tf == "app"
                 and args.skip is None and not args.no_ert):
-            # measured with 8 frames per launch: scaled to this run's average launch
-            out["roofline"]["traffic"] = int(tr["traffic_bytes_per_launch"] * out["roofline"]["frames_per_launch"] / tr.get("frames_per_launch", 8))
-            out["roofline"]["traffic_source"] = tr["source"]
+            if tr.get("kernel_source_sha256") == kernel_source_digest():
+                # measured with 8 frames per launch: scaled to this run's average launch
+                out["roofline"]["traffic"] = int(tr["traffic_bytes_per_launch"] * out["roofline"]["frames_per_launch"] / tr.get("frames_per_launch", 8))
+                out["roofline"]["traffic_source"] = tr["source"]
+            else:
+                out["roofline"]["traffic_source"] = "withheld: %s was measured on other integrator sources than this tree's" % os.path.basename(TRAFFIC_FILE)
     except (OSError, ValueError, KeyError):
         pass
 
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(ctx, sp, v, params, (fw, fh), args.cpu_seconds, args.verify_cpu, out)
+        out["cpu_baseline"] = cpu_baseline(ctx, sp, v, params, (fw, fh), args.cpu_seconds, not args.no_verify_cpu, out)
     print(json.dumps(out), file=json_out, flush=True)
     if native:
         gather.close()
@@ -533,7 +641,7 @@ def cpu_baseline(ctx, sp, v, params, frame, target_seconds, verify_cpu, out):
         rays += sum(r.rays for r in last)
         passes += 1
         dt = time.perf_counter() - t
-        if dt >= target_seconds or passes >= 64:
+        if dt >= target_seconds or passes >= 3:  # a pass renders every sampled pixel of all 8 views: more than three only repeat it
             break
     if verify_cpu:
         fw, fh = frame
