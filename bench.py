@@ -231,9 +231,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     use_gather = world > 1 or args.force_gather
-    # N > 1 (and the one-rank --force-gather proxy): batch launches with ONE gather per launch (torch exchange), or round 1's single-frame
-    # launches with one exchange per frame (--submit streams; always with the native exchange)
-    submit = "streams" if (use_gather and args.exchange == "native") else (args.submit or "batch")
+    # N > 1 (and the one-rank --force-gather proxy): batch launches with ONE gather per launch - through torch.distributed.gather or, with
+    # --exchange native, through the C ABI (vkv_assemble_frames) - or round 1's single-frame launches with one exchange per frame
+    # (--submit streams)
+    submit = args.submit or "batch"
     if submit == "streams":
         # several single-frame launches in flight prefer the plain tile order (their heavy image centres then do not coincide: 0.134 vs
         # 0.141 ms per frame on C3); the library reads the switch once, before its first launch
@@ -283,9 +284,13 @@ def main():
     nsets = nbs + 1  # gather path: one more buffer set than render streams, so a launch does not wait for the exchange nbs launches back
     if use_gather and submit == "batch":
         rotate = args.frame_owner == "rotate" and world > 1
-        gather = multigpu.BatchTileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda", frames=fpl, n_sets=nsets, any_root=rotate)
-        if rank == 0 or rotate:
-            images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nsets * fpl)]
+        if args.exchange == "native":
+            gather = multigpu.NativeBatchExchange(ctx, dist, rank, world, (fw, fh), TILE, 4, frames=fpl, n_sets=nsets, any_root=rotate)
+            images = gather.images or []
+        else:
+            gather = multigpu.BatchTileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda", frames=fpl, n_sets=nsets, any_root=rotate)
+            if rank == 0 or rotate:
+                images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nsets * fpl)]
         nbuf = nsets * fpl
         bufs, my_rays = gather.buffers, gather.my_ray_count()
     elif use_gather:
@@ -303,6 +308,9 @@ def main():
         # per-frame submission: as many targets as keep every target on ONE of the orbit views (like the slots of the batch path)
         nbuf = fpl * nbs if submit == "batch" else -(-fif // N_VIEWS) * N_VIEWS
         bufs, my_rays = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)], fw * fh
+    # set-up: the per-target state of the start-order feedback (vkv_render itself never allocates)
+    for t in bufs:
+        ctx.register_target(t.data_ptr(), (fw, fh), tiles)
     torch.cuda.synchronize()
     # algorithmic bytes of one frame (this rank's part): 8 B per trilinear footprint of the volume, 8 more for the gradient map's when the
     # transfer function has a gradient term, 1 B per distance probe
@@ -345,6 +353,7 @@ def main():
 
     last_slot, last_owner = [0], [0]
     with_depth = [False]
+    native = gather is not None and args.exchange == "native"
 
     def run_batch(n_steps, timed):
         k, launch = 0, 0
@@ -369,9 +378,19 @@ def main():
                 if timed:
                     e1.record(st)
                     launches.append((e0, e1, sum(frame_bytes[(k + j) % N_VIEWS] for j in range(n)), n))
-                if gather:
+                if gather and native:
+                    rendered = torch.cuda.Event()
+                    rendered.record(st)
+                elif gather:
                     gather.start(slot, owner, n)  # ONE collective for the launch's n frames, ordered after the render
-            if gather:
+            if gather and native:
+                # vkv_assemble_frames on the exchange stream, behind the launch: one ncclGather + one de-interleave kernel, nothing waits on the host
+                xchg.wait_event(rendered)
+                gather.assemble(slot, owner, n, xchg)
+                freed[slot] = torch.cuda.Event()
+                freed[slot].record(xchg)
+                last_owner[0] = owner
+            elif gather:
                 with torch.cuda.stream(side):
                     got = gather.finish(slot)
                     if got is not None:
@@ -423,7 +442,6 @@ def main():
                     freed[b] = torch.cuda.Event()
                     freed[b].record(side)
 
-    native = gather is not None and args.exchange == "native"
     run = run_batch if submit == "batch" else run_streams
 
     def fence():
@@ -489,6 +507,8 @@ def main():
         # the earlier rounds' figure; the median per view (one frame in eight also measures tile costs and is followed by the 20 us sort
         # kernel: inside the bracket, outside the median)
         own = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(N_VIEWS)]
+        for t in own:
+            ctx.register_target(t.data_ptr(), (fw, fh), tiles)
         ts = [[] for _ in range(N_VIEWS)]
         for i in range(N_VIEWS):
             for rnd in range(7):
@@ -540,7 +560,7 @@ def main():
                                                   "imin 0.1 imax 1 gmin 0 gmax 0.2" if args.tf == "app" else "imin 0.1 imax 1 gmin 0 gmax 0 (intensity only)"),
                    "parallelism": "screen tiles 16x16 round-robin over %d GPU(s), RCCL gather to %s" % (
                        world, ("rank l mod N for launch l (one gather per launch)" if submit == "batch" else "rank k mod N for frame k") if rotate else "rank 0")
-                   + (" (vkv_assemble_frame: ncclGather + de-interleave)" if native else " (torch.distributed.gather)")
+                   + ((" (vkv_assemble_frames: one ncclGather + one de-interleave per launch)" if submit == "batch" else " (vkv_assemble_frame: ncclGather + de-interleave)") if native else " (torch.distributed.gather)")
                    if world > 1 else "1 GPU",
                    "output": "RGBA8",
                    "submission": ("vkv_render_batch, up to %d frames per launch, consecutive launches on %d HIP stream(s); tile start order from the "

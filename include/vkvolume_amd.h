@@ -10,7 +10,14 @@
  *   - every function returns 0 on success, a negative VKV_E_* code for argument /
  *     capability errors, or a positive `hipError_t` value when the HIP runtime failed;
  *   - device functions ENQUEUE on `stream` and do not synchronise (the reference's
- *     compute_submit() fence wait, src/volume_render.cpp:301-327, is the caller's job);
+ *     compute_submit() fence wait, src/volume_render.cpp:301-327, is the caller's job).
+ *     They neither allocate device memory nor wait for the device once the SET-UP calls below
+ *     (vkv_create, vkv_prepare_render, vkv_register_target; marked "set-up call") have seen the
+ *     shapes, streams and targets they are used with: the small device tables a launch needs
+ *     (tile start order, address tables, per-stream scratch) come out of an arena allocated by
+ *     vkv_create and are uploaded asynchronously on the launch's stream; nothing is ever freed
+ *     or re-used while a launch could still read it (only vkv_forget_target, vkv_release_stream
+ *     and vkv_destroy give device memory back, and they say what they wait for);
  *   - pointers named `d_*` are device pointers owned by the caller; POD structs are
  *     passed by const pointer and copied at call time;
  *   - volumes are dense uint8, x fastest: index = (z*height + y)*width + x
@@ -173,10 +180,37 @@ typedef struct VkvRenderParams
 typedef struct vkv_ctx vkv_ctx;
 
 /* ---- context ------------------------------------------------------------------------------- */
+/* set-up call: allocates the context's device arena (VkvTuning.arena_bytes of the environment default, 8 MiB). */
 int         vkv_create(int device_ordinal, vkv_ctx **out_ctx);
+/* set-up call: waits for the device, then frees everything the context owns. */
 void        vkv_destroy(vkv_ctx *ctx);
 const char *vkv_last_error(const vkv_ctx *ctx);
 const char *vkv_version(void);
+
+/* Tuning switches of one context (A/B switches of the launchers; every setting renders the same bits).  vkv_create fills them from the
+ * environment variables named below, ONCE; afterwards the environment is not consulted again: the behaviour of a linked library depends
+ * on its context, not on the host's environment at first use.  vkv_set_tuning replaces the whole block (read it with vkv_get_tuning,
+ * change fields, write it back); it applies to calls made after it returns. */
+typedef struct VkvTuning
+{
+	uint32_t struct_size;              /* sizeof(VkvTuning): set by vkv_get_tuning, checked by vkv_set_tuning                       */
+	int32_t  scheduler;                /* 0 lane = ray on static tiles (default); 1 persistent waves with lane re-fill   VKV_RAYMARCH_SCHEDULER=persistent */
+	int32_t  batch_mode;               /* vkv_render_batch: 0 workgroup per tile (default); 1 resident workgroups pulling 8x8 units   VKV_RAYMARCH_BATCH=pull */
+	int32_t  batch_sequential;         /* vkv_render_batch: 1 = frames one after the other instead of interleaved       VKV_RAYMARCH_BATCH_ORDER=sequential */
+	int32_t  tile_order_linear;        /* 1 = tiles start in schedule order instead of centre-of-image first             VKV_RAYMARCH_TILE_ORDER=linear */
+	int32_t  address_tables;           /* packed image: 0 none, 1 two-level LDS tables, 2 + one entry per voxel index (default)   VKV_RAYMARCH_LUT=0|2(two-level)|1 */
+	uint32_t full_table_lds_limit;     /* LDS bytes per workgroup up to which the per-voxel tables are used (17920)       VKV_RAYMARCH_FULL_LIMIT */
+	int32_t  screen_cull;              /* 1 = pixels outside the screen bound of the volume's box skip the ray set-up (default)   VKV_RAYMARCH_CULL=0 */
+	int32_t  feedback;                 /* 1 = registered targets start their tiles in the order their last measured frame suggests (default)   VKV_RAYMARCH_FEEDBACK=0 */
+	uint32_t feedback_period;          /* frames between two cost measurements of a target (8)                            VKV_RAYMARCH_FEEDBACK_PERIOD */
+	float    tile_mix_heavy;           /* experiment: central share of the tiles spread over the first tile_mix_spread of the order (0 = off)   VKV_RAYMARCH_TILE_MIX=h,s */
+	float    tile_mix_spread;
+	uint32_t gradient_segment;         /* vkv_gradient_map: tiles a workgroup marches in z; 0 = automatic                 VKV_GRADIENT_SEGMENT */
+	int32_t  pack_tile;                /* vkv_pack_volume: 0 automatic, 2 / 4 = bricks per workgroup edge                 VKV_PACK_TILE */
+	uint32_t arena_bytes;              /* read-only: size of the device arena vkv_create allocated                        VKV_ARENA_BYTES */
+} VkvTuning;
+int vkv_get_tuning(const vkv_ctx *ctx, VkvTuning *out);
+int vkv_set_tuning(vkv_ctx *ctx, const VkvTuning *tuning);
 
 /* ---- host-side helpers (pure CPU, no device access) ------------------------------------------ */
 
@@ -280,6 +314,29 @@ int vkv_transfer_function_tables(vkv_ctx *ctx, const uint8_t *d_transfer_functio
                                  uint32_t *d_tables, void *stream);
 int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_transfer_function, uint32_t *d_tables, void *stream);
 
+/* VolumeRenderSubpass::prepare, src/volume_render_subpass.cpp:95-157 (where the reference builds its pipelines and descriptor layouts).
+ * Set-up call: creates, for `count` parameter blocks as a later vkv_render / vkv_render_batch on `stream` will pass them, everything that
+ * launch takes from the context: the stream's scratch block, the address tables of the packed image's extent, the tile start order of the
+ * schedule; uploads are waited for before it returns.  A launch that finds one of them missing still creates it on the fly out of the
+ * arena with an asynchronous upload on its own stream (no device-wide wait; if the arena is exhausted the launch runs without the table:
+ * plain tile order / address arithmetic in registers, same bits) - vkv_prepare_render only moves that work to set-up time. */
+int vkv_prepare_render(vkv_ctx *ctx, const VkvRenderParams *params, uint32_t count, void *stream);
+
+/* Start-order feedback needs device state per render target (one uint32 cost and one uint32 order entry per tile of the schedule): a
+ * renderer draws into the same swap-chain images again and again with a camera that moves little, so the tiles that took longest in the
+ * last measured frame are started first in the next ones (any order renders the same bits).
+ * vkv_register_target - set-up call: allocates and initialises that state for frames of image_width x image_height pixels rendered with
+ *   tile schedule `tiles` into `d_target` (the d_out_rgba8 or, without one, d_out_color pointer of the parameter block).  Targets that
+ *   were never registered are rendered in the centre-first order: vkv_render never allocates.  Registering a target again replaces
+ *   its state (waits for the device first, like vkv_forget_target).
+ * vkv_forget_target - set-up call: waits for the device (launches that still use the state), then frees it. */
+int vkv_register_target(vkv_ctx *ctx, const void *d_target, uint32_t image_width, uint32_t image_height, const VkvTileSchedule *tiles);
+int vkv_forget_target(vkv_ctx *ctx, const void *d_target);
+
+/* Gives the 128 KiB scratch block vkv_render_batch / vkv_compute_distance_map / ... keep per HIP stream back to the context's pool.
+ * Call it before destroying a stream that was handed to this context, when all work enqueued on it has completed (it does not wait). */
+int vkv_release_stream(vkv_ctx *ctx, void *stream);
+
 /* VolumeRenderSubpass::draw, src/volume_render_subpass.cpp:159-294 (shaders/volume_render.frag). */
 int vkv_render(vkv_ctx *ctx, const VkvRenderParams *params, void *stream);
 
@@ -318,6 +375,15 @@ int vkv_gather_tiles(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, size_t
 int vkv_assemble_frame(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, void *d_image, uint32_t image_width, uint32_t image_height,
                        uint32_t tile_width, uint32_t tile_height, uint32_t n_ranks, uint32_t rank, uint32_t tiles_per_rank,
                        uint32_t bytes_per_pixel, int32_t root, void *nccl_comm, void *stream);
+
+/* The exchange of a whole vkv_render_batch launch in ONE collective (what a C or C++ renderer binds for frames in flight; the Python
+ * bench does the same through torch.distributed): d_tiles holds this rank's compact tile buffers of `frames` frames back to back,
+ * [frame][tiles_per_rank tiles]; one ncclGather brings them to `root` as [rank][frame][tiles] in d_gathered (scratch of
+ * n_ranks * frames * tiles_per_rank tiles on the root), and ONE de-interleave kernel there writes frame f into d_images[f] (host array
+ * of `frames` device pointers, 1 .. VKV_MAX_BATCH; copied at call time).  d_gathered / d_images may be NULL on the other ranks. */
+int vkv_assemble_frames(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, void *const *d_images, uint32_t frames, uint32_t image_width,
+                        uint32_t image_height, uint32_t tile_width, uint32_t tile_height, uint32_t n_ranks, uint32_t rank, uint32_t tiles_per_rank,
+                        uint32_t bytes_per_pixel, int32_t root, void *nccl_comm, void *stream);
 
 /* Deterministic synthetic uint8 volume, generated on the device. kind 0 = soft
  * sphere (config C1), kind 1 = ellipsoid shells + hash noise (configs C2..C5). */

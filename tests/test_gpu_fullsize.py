@@ -85,11 +85,11 @@ def check_maps_and_frames(ctx, v, tf, size, label):
         if mode == abi.SKIP_DISTANCE:
             c_lin, img_lin = count_frame(ctx, v, size, 45.0, mode, packed=False)  # linear buffers vs packed image: same bits
             assert torch.equal(c, c_lin) and torch.equal(img, img_lin)
-            os.environ["VKV_RAYMARCH_SCHEDULER"] = "persistent"
+            ctx.set_tuning(scheduler=1)  # persistent waves with lane re-fill
             try:
                 c_p, img_p = count_frame(ctx, v, size, 45.0, mode)
             finally:
-                os.environ.pop("VKV_RAYMARCH_SCHEDULER", None)
+                ctx.set_tuning(scheduler=0)
             assert torch.equal(c, c_p) and torch.equal(img, img_p)
     assert totals[3] <= totals[2] <= totals[1] <= totals[0], label + ": %r" % totals
     assert totals[2] < 0.2 * totals[0]

@@ -84,18 +84,17 @@ def test_gradient_kernel_shortcuts_are_exact(ctx):
 @pytest.mark.parametrize("shape,segment", [((260, 40, 50), 3), ((192, 24, 67), 2), ((132, 9, 33), 10), ((64, 8, 80), 4), ((200, 17, 26), 255)])
 def test_gradient_map_marching_workgroups(ctx, shape, segment):
     """The tiled kernel's workgroups march over `segment` tiles in z with the next tile prefetched; volumes this small run one tile per
-    workgroup unless VKV_GRADIENT_SEGMENT (read per call) forces the march: interior and edge tiles in x, clamped first / last tiles in
+    workgroup unless VkvTuning.gradient_segment forces the march: interior and edge tiles in x, clamped first / last tiles in
     z, a last segment that is shorter, a depth that is no multiple of the tile."""
-    import os
     vol = T.random_volume(shape, seed=21 + segment)
     tf = lib.transfer_function_uniform(abi.VolumeOptions(**T.APP_TF))
     d_vol, d_grad = dev(vol), torch.empty(vol.shape, dtype=torch.uint8, device="cuda")
-    os.environ["VKV_GRADIENT_SEGMENT"] = str(segment)
+    ctx.set_tuning(gradient_segment=segment)
     try:
         ctx.gradient_map(d_vol.data_ptr(), d_grad.data_ptr(), abi.Extent3D(*shape), tf, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
     finally:
-        del os.environ["VKV_GRADIENT_SEGMENT"]
+        ctx.set_tuning(gradient_segment=0)
     assert np.array_equal(d_grad.cpu().numpy(), O.gradient_map(vol, tf))
 
 
@@ -214,7 +213,7 @@ def gpu_render(ctx, v, params, want_rgba8=False):
     # static tile scheduler} must give the same bits
     for packed, sched in ((True, "persistent"), (False, "persistent"), (True, "tiles"), (False, "tiles")):
         v.use_packed = packed
-        os.environ["VKV_RAYMARCH_SCHEDULER"] = sched
+        ctx.set_tuning(scheduler=1 if sched == "persistent" else 0)
         p = sp.bind(params)
         assert bool(p.d_packed_volume) == packed and bool(p.d_transfer_function_bits) == packed
         c, n, d = color.clone(), counts.clone(), depth.clone()
@@ -223,7 +222,7 @@ def gpu_render(ctx, v, params, want_rgba8=False):
         torch.cuda.synchronize()
         outs.append((c.cpu().numpy(), n.cpu().numpy().astype(np.uint32), d.cpu().numpy(), None if q is None else q.cpu().numpy()))
     v.use_packed = True
-    os.environ.pop("VKV_RAYMARCH_SCHEDULER", None)
+    ctx.set_tuning(scheduler=0)
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert (a is None and b is None) or np.array_equal(a, b), "sampling-layout / scheduler variants disagree"

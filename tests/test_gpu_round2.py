@@ -1,5 +1,6 @@
 """GPU: transfer-function acceleration tables (separable greyscale claim checked on the device, generic RGBA fallback),
 stream re-entrancy of one context, several volumes in one subpass, a reloaded Volume object."""
+import ctypes as C
 import os
 import subprocess
 import sys
@@ -114,7 +115,7 @@ def test_one_context_on_three_streams(ctx):
         assert int(count.item()) == expect_count
     # two persistent-scheduler renders in flight on two streams
     size = (160, 96)
-    os.environ["VKV_RAYMARCH_SCHEDULER"] = "persistent"
+    ctx.set_tuning(scheduler=1)
     try:
         refs, outs, params = [], [], []
         for k, (v, tf) in enumerate(vols):
@@ -133,7 +134,7 @@ def test_one_context_on_three_streams(ctx):
         for k in range(2):
             assert np.array_equal(outs[k].cpu().numpy().astype(np.uint32), refs[k].counts)
     finally:
-        os.environ.pop("VKV_RAYMARCH_SCHEDULER", None)
+        ctx.set_tuning(scheduler=0)
 
 
 def run_offscreen(tmp_path, *flags):
@@ -269,8 +270,8 @@ def test_native_rccl_gather_and_assemble(ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("skipping_type", [abi.SKIP_NONE, abi.SKIP_DISTANCE, abi.SKIP_ANISOTROPIC_DISTANCE])
-def test_render_batch_pull_kernel_equals_single_launches(ctx, skipping_type, monkeypatch):
-    """VKV_RAYMARCH_BATCH=pull (resident workgroups, waves pull 8x8 units from per-XCD ticket counters): same frames, bit for bit."""
+def test_render_batch_pull_kernel_equals_single_launches(ctx, skipping_type):
+    """VkvTuning.batch_mode = 1 (resident workgroups, waves pull 8x8 units from per-XCD ticket counters): same frames, bit for bit."""
     opt = abi.VolumeOptions(**T.APP_TF)
     scene = T.OracleScene(O.synth_volume((96, 80, 72), 1, 91), opt, 4)
     v, tf = make_gpu_volume(ctx, scene)
@@ -301,11 +302,13 @@ def test_render_batch_pull_kernel_equals_single_launches(ctx, skipping_type, mon
         q = abi.RenderParams.from_buffer_copy(p)
         point(q, o)
         plist.append(q)
-    monkeypatch.setenv("VKV_RAYMARCH_BATCH", "pull")
-    for _ in range(2):  # twice: the ticket counters are re-armed by every launch
-        ctx.render_batch(plist, st)
-    torch.cuda.synchronize()
-    monkeypatch.delenv("VKV_RAYMARCH_BATCH")
+    ctx.set_tuning(batch_mode=1)
+    try:
+        for _ in range(2):  # twice: the ticket counters are re-armed by every launch
+            ctx.render_batch(plist, st)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_tuning(batch_mode=0)
     for i, (a, b) in enumerate(zip(single, pulled)):
         for k in a:
             assert torch.equal(a[k], b[k]), "frame %d: %s differs between the pull kernel and the single launch" % (i, k)
@@ -368,18 +371,85 @@ def test_scatter_tiles_reads_one_frame_of_a_gathered_batch(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["VKV_RAYMARCH_LUT=0", "VKV_RAYMARCH_LUT=2", "VKV_RAYMARCH_CULL=0", "VKV_RAYMARCH_TILE_ORDER=linear"])
+@pytest.mark.parametrize("switch", ["address_tables=0", "address_tables=1", "screen_cull=0", "tile_order_linear=1", "full_table_lds_limit=0"])
 def test_render_parity_under_each_kernel_selection_switch(switch):
     """The launcher picks one of three instantiations of the integrator (footprint address in registers / two-level LDS tables / one
     entry per voxel index), a tile start order and the screen bound by itself; small test volumes always get the same choice.  The
-    library reads these A/B switches once per process, so the render parity tests are re-run in a child process under each of them."""
-    name, value = switch.split("=")
+    render parity tests are re-run in a child process whose contexts start from the matching environment default (vkv_create reads
+    VKV_RAYMARCH_* once per context), and the same switches are flipped through vkv_set_tuning in
+    test_tuning_block_switches_render_the_same_bits."""
+    env_of = {"address_tables=0": ("VKV_RAYMARCH_LUT", "0"), "address_tables=1": ("VKV_RAYMARCH_LUT", "2"), "screen_cull=0": ("VKV_RAYMARCH_CULL", "0"),
+              "tile_order_linear=1": ("VKV_RAYMARCH_TILE_ORDER", "linear"), "full_table_lds_limit=0": ("VKV_RAYMARCH_FULL_LIMIT", "1")}
+    name, value = env_of[switch]
     env = dict(os.environ, **{name: value})
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-x", "-q", "-k", "render", "-p", "no:cacheprovider"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, "%s:\n%s\n%s" % (switch, r.stdout[-3000:], r.stderr[-1000:])
     assert " passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_tuning_block_switches_render_the_same_bits():
+    """vkv_get_tuning / vkv_set_tuning: the environment is read once by vkv_create; afterwards only the block decides.  Every switch of
+    the launchers renders the same frame (RGBA8 + counters) through vkv_render and vkv_render_batch."""
+    c = lib.Context(0)
+    try:
+        t0 = c.get_tuning()
+        assert t0.struct_size == C.sizeof(abi.Tuning) and t0.address_tables == 2 and t0.feedback == 1 and t0.feedback_period == 8 and t0.screen_cull == 1
+        assert t0.arena_bytes >= (1 << 20)
+        bad = abi.Tuning.from_buffer_copy(t0)
+        bad.struct_size = 8
+        assert c._lib.vkv_set_tuning(c.handle, C.byref(bad)) == abi.VKV_E_INVALID_ARGUMENT
+        bad = abi.Tuning.from_buffer_copy(t0)
+        bad.address_tables = 7
+        assert c._lib.vkv_set_tuning(c.handle, C.byref(bad)) == abi.VKV_E_INVALID_ARGUMENT
+        os.environ["VKV_RAYMARCH_LUT"] = "0"  # too late for this context: it must not change anything
+        try:
+            assert c.get_tuning().address_tables == 2
+        finally:
+            del os.environ["VKV_RAYMARCH_LUT"]
+        opt = abi.VolumeOptions(**T.APP_TF)
+        scene = T.OracleScene(O.synth_volume((72, 64, 56), 1, 4242), opt, 4)
+        v, tf = make_gpu_volume(c, scene)
+        V.ComputeDistanceMap(c).compute(v, tf, abi.SKIP_DISTANCE)
+        size = (208, 112)
+        ro = abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0)
+        sp = V.VolumeRenderSubpass(c, v, ro, size)
+        st = torch.cuda.current_stream().cuda_stream
+        views = [sp.bind(scene.params(*T.orbit(az, image_size=size), size, ro)) for az in (15.0, 140.0, 260.0)]
+
+        def frames():
+            out = []
+            for p in views:
+                rgba, cnt = torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda"), torch.zeros((size[1], size[0], 3), dtype=torch.int32, device="cuda")
+                q = abi.RenderParams.from_buffer_copy(p)
+                q.d_out_rgba8, q.d_out_counts, q.d_out_color, q.d_out_depth = rgba.data_ptr(), cnt.data_ptr(), None, None
+                c.render(q, st)
+                out.append((rgba, cnt))
+            plist, outs = [], []
+            for p in views:
+                rgba, cnt = torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda"), torch.zeros((size[1], size[0], 3), dtype=torch.int32, device="cuda")
+                q = abi.RenderParams.from_buffer_copy(p)
+                q.d_out_rgba8, q.d_out_counts, q.d_out_color, q.d_out_depth = rgba.data_ptr(), cnt.data_ptr(), None, None
+                plist.append(q)
+                outs.append((rgba, cnt))
+            c.render_batch(plist, st)
+            torch.cuda.synchronize()
+            return out + outs
+
+        ref = frames()
+        assert int(ref[0][1].sum().item()) > 0
+        for fields in (dict(address_tables=0), dict(address_tables=1), dict(full_table_lds_limit=0), dict(screen_cull=0), dict(tile_order_linear=1),
+                       dict(batch_sequential=1), dict(batch_mode=1), dict(scheduler=1), dict(feedback=0), dict(tile_mix_heavy=0.3, tile_mix_spread=0.6)):
+            c.set_tuning(**fields)
+            got = frames()
+            reset = {k: getattr(t0, k) for k in fields}
+            c.set_tuning(**reset)
+            for i, ((a, b), (x, y)) in enumerate(zip(ref, got)):
+                assert torch.equal(a, x) and torch.equal(b, y), "%r changes frame %d" % (fields, i)
+    finally:
+        c.close()
 
 
 @pytest.mark.gpu
@@ -404,6 +474,7 @@ def test_render_start_order_feedback_against_the_oracle(ctx):
     color = torch.empty((size[1], size[0], 4), dtype=torch.float32, device="cuda")
     counts = torch.empty((size[1], size[0], 3), dtype=torch.int32, device="cuda")
     depth = torch.empty((size[1], size[0]), dtype=torch.float32, device="cuda")
+    ctx.register_target(color.data_ptr(), size, views[0].tiles)  # the feedback state of this target (vkv_render itself never allocates)
     for frame in range(19):
         k = (frame // 3) % 2
         color.fill_(-1.0), counts.fill_(0xFFFF), depth.fill_(-1.0)
@@ -411,12 +482,14 @@ def test_render_start_order_feedback_against_the_oracle(ctx):
         torch.cuda.synchronize()
         got = (color.cpu().numpy(), counts.cpu().numpy().astype(np.uint32), depth.cpu().numpy(), None)
         compare_render(got, refs[k], "frame %d (view %d)" % (frame, k))
+    ctx.forget_target(color.data_ptr())
 
 
 @pytest.mark.gpu
-def test_start_order_feedback_forgets_old_targets(ctx):
-    """The context keeps feedback state for at most 256 targets and drops the oldest beyond that: 300 targets in turn, twice (the second
-    round finds its first targets forgotten and starts over), every frame equal to the first one."""
+def test_start_order_feedback_targets_are_registered_and_forgotten(ctx):
+    """Feedback state exists only for targets handed to vkv_register_target: 300 targets in turn, twice, half of them registered (and
+    forgotten, re-registered with another schedule, registered twice): every frame equals the first one, registered or not, and a
+    target registered for ANOTHER schedule is rendered without feedback instead of with a stale order."""
     opt = abi.VolumeOptions(**T.APP_TF)
     scene = T.OracleScene(O.synth_volume((48, 40, 36), 1, 77), opt, 4)
     v, tf = make_gpu_volume(ctx, scene)
@@ -427,7 +500,15 @@ def test_start_order_feedback_forgets_old_targets(ctx):
     view, proj = T.orbit(40.0, image_size=size)
     p = sp.bind(scene.params(view, proj, size, ro))
     targets = [torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda") for _ in range(300)]
-    for rnd in range(2):
+    other = abi.full_frame_tiles(size[0], size[1], 32, 32)
+    for j, t in enumerate(targets):
+        if j % 2 == 0:
+            ctx.register_target(t.data_ptr(), size, p.tiles)
+        if j % 10 == 0:
+            ctx.register_target(t.data_ptr(), size, p.tiles)  # again: replaces the state
+        if j % 14 == 0:
+            ctx.register_target(t.data_ptr(), size, other)  # registered for another schedule: this render gets no feedback
+    for rnd in range(3):
         for t in targets:
             t.fill_(7)
             sp.draw(p, None, t)
@@ -435,6 +516,12 @@ def test_start_order_feedback_forgets_old_targets(ctx):
         assert int(targets[0].sum().item()) > 0
         for j, t in enumerate(targets[1:]):
             assert torch.equal(t, targets[0]), "round %d, target %d" % (rnd, j + 1)
+        if rnd == 0:
+            for t in targets[::4]:
+                ctx.forget_target(t.data_ptr())
+    for t in targets:
+        ctx.forget_target(t.data_ptr())  # unknown targets are fine
+    assert ctx._lib.vkv_register_target(ctx.handle, None, 128, 128, C.byref(p.tiles)) == abi.VKV_E_INVALID_ARGUMENT
 
 
 @pytest.mark.gpu
@@ -461,6 +548,8 @@ def test_render_batch_start_order_feedback_keeps_the_frames(ctx, size):
         ctx.render(p, st)
         ref.append(out)
     targets = [torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda") for _ in params]
+    for t in targets:
+        ctx.register_target(t.data_ptr(), size, params[0].tiles)
     for launch in range(4):
         shift = launch // 2  # launches 2 and 3 put other views into the same targets: the remembered costs belong to another view
         plist = []
@@ -474,3 +563,5 @@ def test_render_batch_start_order_feedback_keeps_the_frames(ctx, size):
         torch.cuda.synchronize()
         for j in range(len(params)):
             assert torch.equal(targets[j], ref[(j + shift) % len(params)]), "launch %d, target %d" % (launch, j)
+    for t in targets:
+        ctx.forget_target(t.data_ptr())

@@ -17,8 +17,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "vkvolume_amd.h")
 
 
-def declared_functions():
-    src = open(HEADER).read()
+DEBUG_HEADER = os.path.join(ROOT, "include", "vkvolume_amd_debug.h")
+
+
+def declared_functions(header=HEADER):
+    src = open(header).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(vkv_[a-z_0-9]+)\s*\(", src)))
 
@@ -28,8 +31,14 @@ def test_library_exports_every_declared_symbol():
     names = declared_functions()
     assert len(names) >= 15
     assert sorted(names) == sorted(lib.EXPORTS)
-    for n in names:
+    debug = declared_functions(DEBUG_HEADER)
+    assert sorted(debug) == sorted(lib.DEBUG_EXPORTS)  # the diagnostic entry points have a header of their own
+    for n in names + debug:
         assert hasattr(L, n), n
+    # nothing else with the library's prefix is exported: no undeclared entry points
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
+    exported = sorted(set(re.findall(r"\b(vkv_[a-z_0-9]+)$", out, flags=re.M)))
+    assert exported == sorted(names + debug), set(exported) ^ set(names + debug)
     assert b"gfx950" in L.vkv_version()
 
 
@@ -39,7 +48,8 @@ def test_ctypes_mirror_matches_c_layout(tmp_path):
     out = subprocess.check_output([str(exe)]).decode().split("\n")
     mirror = {"VkvExtent3D": abi.Extent3D, "VkvTransferFunctionUniform": abi.TransferFunctionUniform, "VkvVolumeOptions": abi.VolumeOptions,
               "VkvCameraUniform": abi.CameraUniform, "VkvRayCastUniform": abi.RayCastUniform, "VkvRayGen": abi.RayGen,
-              "VkvRenderOptions": abi.RenderOptions, "VkvTileSchedule": abi.TileSchedule, "VkvRenderParams": abi.RenderParams}
+              "VkvRenderOptions": abi.RenderOptions, "VkvTileSchedule": abi.TileSchedule, "VkvRenderParams": abi.RenderParams,
+              "VkvTuning": abi.Tuning}
     n = 0
     for line in out:
         f = line.split()

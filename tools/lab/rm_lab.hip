@@ -20,17 +20,11 @@ template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF>
 int launch_lean(const RayMarchArgs &a, hipStream_t s)
 {
 	const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile;
-	size_t         lds  = (LF & kLeanLut) ? (size_t) a.lut_words * 4 : 0;
-	if ((LF & kLeanLut) && (!a.addr_lut || lds > 48 * 1024))
+	if ((LF & kLeanLut) && (!a.addr_lut || (size_t) a.lut_words * 4 > 48 * 1024))
 		return -103;
-	if ((LF & kLeanFull) != 0)
-	{
-		const size_t fb = full_lut_bytes(a.W, a.H, a.D);
-		if (kFullLutWord * 4 + fb > 48 * 1024)
-			return -104;
-		if (kFullLutWord * 4 + fb > sizeof(RmLds))
-			lds = std::max(lds, kFullLutWord * 4 + fb - sizeof(RmLds));
-	}
+	if ((LF & kLeanFull) != 0 && kFullLutWord * 4 + full_lut_bytes(a.W, a.H, a.D) > 48 * 1024)
+		return -104;
+	const size_t lds = lean_lds_bytes((LF & kLeanFull) ? 2 : ((LF & kLeanLut) ? 1 : 0), a.lut_words, a.W, a.H, a.D);
 	if ((LF & kLeanScalar) != 0 && !map_fits_u24((uint32_t) a.mw, (uint32_t) a.mh, (uint32_t) a.md))
 		return -105;
 	hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, LF>), dim3(grid), dim3(256), lds, s, a);
@@ -40,15 +34,14 @@ int launch_lean(const RayMarchArgs &a, hipStream_t s)
 template <int SKIP, bool ERT, int GRAD, uint32_t LF, int WPB>
 __global__ void __launch_bounds__(WPB * 64) k_lab_lean_wpb(const RayMarchArgs A)
 {
-	__shared__ RmLds L;
-	lean_block<SKIP, ERT, GRAD, true, LF, WPB>(A, blockIdx.x, L);
+	lean_block<SKIP, ERT, GRAD, true, LF, WPB>(A, blockIdx.x, lean_lds());
 }
 
 template <int SKIP, bool ERT, int GRAD, int WPB>
 int launch_wpb(const RayMarchArgs &a, hipStream_t s)
 {
 	const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile * (4 / WPB);
-	hipLaunchKernelGGL((k_lab_lean_wpb<SKIP, ERT, GRAD, kLeanDefault | kLeanLut, WPB>), dim3(grid), dim3(WPB * 64), (size_t) a.lut_words * 4, s, a);
+	hipLaunchKernelGGL((k_lab_lean_wpb<SKIP, ERT, GRAD, kLeanDefault | kLeanLut, WPB>), dim3(grid), dim3(WPB * 64), lean_lds_bytes(1, a.lut_words, a.W, a.H, a.D), s, a);
 	return (int) hipGetLastError();
 }
 
@@ -126,7 +119,7 @@ extern "C" int vkv_lab_render(vkv_ctx *ctx, const VkvRenderParams *P, int varian
 		lut[a]        = std::min(std::max(v, 0.0f), 1.0f);
 	}
 	RayMarchArgs a;
-	const int    rc = vkv::fill_render_args(ctx, P, lut, a);
+	const int    rc = vkv::fill_render_args(ctx, P, lut, a, (hipStream_t) stream, vkv::tuning_of(ctx), false);
 	if (rc != VKV_OK || a.nblocks == 0)
 		return rc;
 	if (!a.packed || !P->transfer_function.use_gradient || !P->use_precomputed_gradient)

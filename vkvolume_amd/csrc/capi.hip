@@ -17,6 +17,7 @@
 #include "../host/load_volume.h"
 #include "../host/vkv_math.hpp"
 #include "vkv_device.hpp"
+#include "../../include/vkvolume_amd_debug.h"
 
 namespace vkv
 {
@@ -27,6 +28,8 @@ int launch_distance_map(vkv_ctx *, uint8_t *, uint8_t *, VkvExtent3D, hipStream_
 int launch_distance_map_anisotropic(vkv_ctx *, uint8_t *const[8], uint8_t *, VkvExtent3D, hipStream_t);
 int launch_synth_volume(vkv_ctx *, uint8_t *, VkvExtent3D, uint32_t, uint32_t, hipStream_t);
 int launch_scatter_tiles(vkv_ctx *, const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
+int launch_scatter_tiles_frames(vkv_ctx *, const void *, void *const *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
+int prepare_render(vkv_ctx *, const VkvRenderParams *, uint32_t, hipStream_t);
 int launch_render(vkv_ctx *, const VkvRenderParams *, const float *, hipStream_t);
 int launch_render_batch(vkv_ctx *, const VkvRenderParams *, uint32_t, const float *, hipStream_t);
 int launch_pack_volume(vkv_ctx *, const uint8_t *, const uint8_t *, VkvExtent3D, void *, hipStream_t);
@@ -47,37 +50,118 @@ int set_error(vkv_ctx *ctx, int code, const char *fmt, ...)
 	return code;
 }
 
-uint8_t *stream_scratch(vkv_ctx *ctx, hipStream_t stream)
+VkvTuning tuning_of(vkv_ctx *ctx)
+{
+	std::lock_guard<std::mutex> lock(ctx->mutex);
+	return ctx->tuning;
+}
+
+// `bytes` of device memory that stay valid until vkv_destroy (caller holds ctx->mutex).  Launch paths only take from the arena; set-up
+// calls may fall back to hipMalloc.
+static void *arena_take(vkv_ctx *ctx, size_t bytes, bool setup)
+{
+	const size_t need = (bytes + 255u) & ~(size_t) 255u;
+	if (ctx->arena && ctx->arena_used + need <= ctx->arena_bytes)
+	{
+		void *p = ctx->arena + ctx->arena_used;
+		ctx->arena_used += need;
+		return p;
+	}
+	if (!setup)
+		return nullptr;
+	void *p = nullptr;
+	if (hipMalloc(&p, need) != hipSuccess)
+		return nullptr;
+	ctx->overflow.push_back(p);
+	return p;
+}
+
+uint8_t *stream_scratch(vkv_ctx *ctx, hipStream_t stream, bool setup)
 {
 	std::lock_guard<std::mutex> lock(ctx->mutex);
 	auto                        it = ctx->scratch.find(stream);
 	if (it != ctx->scratch.end())
 		return it->second;
-	uint8_t *        p = nullptr;
-	const hipError_t e = hipMalloc((void **) &p, kScratchBytes);
-	if (e != hipSuccess)
+	uint8_t *p = nullptr;
+	if (!ctx->free_scratch.empty())
 	{
-		set_error(ctx, (int) e, "scratch allocation: %s", hipGetErrorString(e));
+		p = ctx->free_scratch.back();
+		ctx->free_scratch.pop_back();
+	}
+	else
+		p = static_cast<uint8_t *>(arena_take(ctx, kScratchBytes, setup));
+	if (!p)
+	{
+		set_error(ctx, VKV_E_UNSUPPORTED, "no room for the scratch block of a new stream: the context's arena is full (call vkv_prepare_render at set-up "
+		                                  "time, give finished streams back with vkv_release_stream, or raise VKV_ARENA_BYTES)");
 		return nullptr;
 	}
 	ctx->scratch.emplace(stream, p);
 	return p;
 }
 
-const uint32_t *packed_addr_lut(vkv_ctx *ctx, int W, int H, int D, uint32_t *lut_y, uint32_t *lut_z, uint32_t *words)
+// Device copy of a new table: memory out of the arena, asynchronous upload from the entry's own host copy on the launch's stream, an
+// event behind it for launches on other streams.  Caller holds ctx->mutex.  False (and nothing allocated that matters) when there is no room.
+static bool table_upload(vkv_ctx *ctx, vkv_ctx::Table &t, hipStream_t s, bool setup)
+{
+	const size_t bytes = t.host.size() * sizeof(uint32_t);
+	t.d                = static_cast<uint32_t *>(arena_take(ctx, bytes, setup));
+	if (!t.d)
+		return false;
+	if (hipEventCreateWithFlags(&t.uploaded, hipEventDisableTiming) != hipSuccess)
+		return false;        // (the arena bytes stay taken: harmless)
+	if (hipMemcpyAsync(t.d, t.host.data(), bytes, hipMemcpyHostToDevice, s) != hipSuccess || hipEventRecord(t.uploaded, s) != hipSuccess)
+	{
+		(void) hipEventDestroy(t.uploaded);
+		t.uploaded = nullptr;
+		return false;
+	}
+	t.upload_stream = s;
+	if (setup)
+	{        // a set-up call hands out finished tables
+		(void) hipEventSynchronize(t.uploaded);
+		t.ready = true;
+	}
+	return true;
+}
+
+// the table for a launch on stream s: behind its upload (caller holds ctx->mutex)
+static const uint32_t *table_on_stream(vkv_ctx::Table &t, hipStream_t s, bool setup)
+{
+	if (t.ready)
+		return t.d;
+	if (setup ? hipEventSynchronize(t.uploaded) == hipSuccess : hipEventQuery(t.uploaded) == hipSuccess)
+	{
+		t.ready = true;
+		return t.d;
+	}
+	if (s != t.upload_stream && hipStreamWaitEvent(s, t.uploaded, 0) != hipSuccess)
+		return nullptr;
+	return t.d;
+}
+
+constexpr size_t kMaxCachedTables = 1024;        // per kind; beyond that a launch runs without (never evicts: a launch may still read any of them)
+
+const uint32_t *packed_addr_lut(vkv_ctx *ctx, int W, int H, int D, uint32_t *lut_y, uint32_t *lut_z, uint32_t *words, hipStream_t stream, bool setup)
 {
 	std::lock_guard<std::mutex> lock(ctx->mutex);
-	for (const auto &t : ctx->addr_luts)
-		if (t.W == W && t.H == H && t.D == D)
+	for (auto *t : ctx->addr_luts)
+		if (t->W == W && t->H == H && t->D == D)
 		{
-			*lut_y = t.lut_y, *lut_z = t.lut_z, *words = t.words;
-			return t.d_lut;
+			*lut_y = t->lut_y, *lut_z = t->lut_z, *words = t->words;
+			return table_on_stream(t->table, stream, setup);
 		}
+	if (ctx->addr_luts.size() >= kMaxCachedTables)
+		return nullptr;
 	// two levels per axis: position inside a macro-brick (32 entries: padded index b & 31) and the macro-brick term (b >> 5)
 	const PackedDims pd  = packed_dims(W, H, D);
 	const uint32_t   nmx = (uint32_t) (W + 1) / 32 + 1, nmy = (uint32_t) (H + 1) / 32 + 1, nmz = (uint32_t) (D + 1) / 32 + 1;
 	const uint32_t   ny = 96 + nmx, nz = (ny + nmy + 1) & ~1u, total = nz + 2 * nmz;
-	std::vector<uint32_t> h(total, 0u);
+	auto *           e  = new (std::nothrow) vkv_ctx::AddrLut{W, H, D, ny, nz, total, {}};
+	if (!e)
+		return nullptr;
+	std::vector<uint32_t> &h = e->table.host;
+	h.assign(total, 0u);
 	for (uint32_t j = 0; j < 32; ++j)
 	{
 		h[j]      = (((j >> 2) & 7u) << 8) + (j & 3u) * 2u;
@@ -93,35 +177,30 @@ const uint32_t *packed_addr_lut(vkv_ctx *ctx, int W, int H, int D, uint32_t *lut
 		const uint64_t z = ((uint64_t) m * (uint64_t) pd.my * (uint64_t) pd.mx) << 17;
 		h[nz + 2 * m] = (uint32_t) z, h[nz + 2 * m + 1] = (uint32_t) (z >> 32);
 	}
-	uint32_t *d = nullptr;
-	if (hipMalloc((void **) &d, (size_t) total * sizeof(uint32_t)) != hipSuccess)
-		return nullptr;
-	if (hipMemcpy(d, h.data(), (size_t) total * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+	if (!table_upload(ctx, e->table, stream, setup))
 	{
-		(void) hipFree(d);
+		delete e;
 		return nullptr;
 	}
-	if (ctx->addr_luts.size() >= 32)
-	{
-		(void) hipDeviceSynchronize();
-		(void) hipFree(ctx->addr_luts.front().d_lut);
-		ctx->addr_luts.erase(ctx->addr_luts.begin());
-	}
-	ctx->addr_luts.push_back({W, H, D, ny, nz, total, d});
+	ctx->addr_luts.push_back(e);
 	*lut_y = ny, *lut_z = nz, *words = total;
-	return d;
+	return e->table.d;
 }
 
-const uint32_t *tile_start_order(vkv_ctx *ctx, uint32_t img_w, uint32_t img_h, uint32_t tile_w, uint32_t tile_h, uint32_t first, uint32_t stride, uint32_t count)
+const uint32_t *tile_start_order(vkv_ctx *ctx, uint32_t img_w, uint32_t img_h, uint32_t tile_w, uint32_t tile_h, uint32_t first, uint32_t stride, uint32_t count,
+                                 hipStream_t stream, bool setup)
 {
 	if (count < 2)
 		return nullptr;
 	const uint32_t tiles_x = (img_w + tile_w - 1) / tile_w, tiles_y = (img_h + tile_h - 1) / tile_h;
 	std::lock_guard<std::mutex> lock(ctx->mutex);
-	for (const auto &t : ctx->tile_orders)
-		if (t.tiles_x == tiles_x && t.tiles_y == tiles_y && t.tile_w == tile_w && t.tile_h == tile_h && t.img_w == img_w && t.img_h == img_h && t.first == first &&
-		    t.stride == stride && t.count == count)
-			return t.d_order;
+	const float mix_heavy_f = ctx->tuning.tile_mix_heavy, mix_spread_f = ctx->tuning.tile_mix_spread;
+	for (auto *t : ctx->tile_orders)
+		if (t->tiles_x == tiles_x && t->tiles_y == tiles_y && t->tile_w == tile_w && t->tile_h == tile_h && t->img_w == img_w && t->img_h == img_h && t->first == first &&
+		    t->stride == stride && t->count == count && t->mix_heavy == mix_heavy_f && t->mix_spread == mix_spread_f)
+			return table_on_stream(t->table, stream, setup);
+	if (ctx->tile_orders.size() >= kMaxCachedTables)
+		return nullptr;
 	std::vector<std::pair<double, uint32_t>> key(count);
 	for (uint32_t k = 0; k < count; ++k)
 	{
@@ -133,11 +212,10 @@ const uint32_t *tile_start_order(vkv_ctx *ctx, uint32_t img_w, uint32_t img_h, u
 	std::vector<uint32_t> order(count);
 	for (uint32_t r = 0; r < count; ++r)
 		order[r] = key[r].second;
-	// experiment (VKV_RAYMARCH_TILE_MIX=<heavy share>,<spread>): the central <heavy share> of the tiles is spread evenly over the first
+	// experiment (VkvTuning.tile_mix_heavy / tile_mix_spread): the central <heavy share> of the tiles is spread evenly over the first
 	// <spread> of the start order, the remaining (border) tiles fill the gaps and the end
-	static const char *mix_env = std::getenv("VKV_RAYMARCH_TILE_MIX");
-	double mix_heavy = 0.0, mix_spread = 0.0;
-	if (mix_env && std::sscanf(mix_env, "%lf,%lf", &mix_heavy, &mix_spread) == 2 && mix_heavy > 0.0 && mix_heavy < 1.0 && mix_spread >= mix_heavy && mix_spread <= 1.0)
+	const double mix_heavy = mix_heavy_f, mix_spread = mix_spread_f;
+	if (mix_heavy > 0.0 && mix_heavy < 1.0 && mix_spread >= mix_heavy && mix_spread <= 1.0)
 	{
 		// in groups of eight ranks: rank r runs on XCD r & 7, so a group gives every XCD one tile of the same kind
 		const uint32_t groups = count / 8, nh = (uint32_t) (mix_heavy * groups), span = (uint32_t) (mix_spread * groups);
@@ -156,23 +234,17 @@ const uint32_t *tile_start_order(vkv_ctx *ctx, uint32_t img_w, uint32_t img_h, u
 			mixed.push_back(order[r]);
 		order.swap(mixed);
 	}
-	uint32_t *d = nullptr;
-	if (hipMalloc((void **) &d, (size_t) count * sizeof(uint32_t)) != hipSuccess)
+	auto *e = new (std::nothrow) vkv_ctx::TileOrder{tiles_x, tiles_y, tile_w, tile_h, img_w, img_h, first, stride, count, mix_heavy_f, mix_spread_f, {}};
+	if (!e)
 		return nullptr;
-	if (hipMemcpy(d, order.data(), (size_t) count * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+	e->table.host.swap(order);
+	if (!table_upload(ctx, e->table, stream, setup))
 	{
-		(void) hipFree(d);
+		delete e;
 		return nullptr;
 	}
-	if (ctx->tile_orders.size() >= 64)
-	{        // a renderer uses a handful of schedules; drop the oldest rather than grow without bound.  Launches that still read it
-		 // must have finished: synchronise before freeing
-		(void) hipDeviceSynchronize();
-		(void) hipFree(ctx->tile_orders.front().d_order);
-		ctx->tile_orders.erase(ctx->tile_orders.begin());
-	}
-	ctx->tile_orders.push_back({tiles_x, tiles_y, tile_w, tile_h, img_w, img_h, first, stride, count, d});
-	return d;
+	ctx->tile_orders.push_back(e);
+	return e->table.d;
 }
 
 int check_launch(vkv_ctx *ctx, const char *what)
@@ -196,6 +268,50 @@ extern "C" {
 
 const char *vkv_version(void) { return "vkvolume_amd 0.1.0 (gfx950)"; }
 
+// defaults of the tuning block, then the environment (read HERE, once per context, and nowhere else)
+static void default_tuning(VkvTuning &t)
+{
+	std::memset(&t, 0, sizeof(t));
+	t.struct_size          = (uint32_t) sizeof(VkvTuning);
+	t.address_tables       = 2;
+	t.full_table_lds_limit = 17920;        // = kFullLdsLimit (raymarch_core.hpp): 9 workgroups per CU
+	t.screen_cull          = 1;
+	t.feedback             = 1;
+	t.feedback_period      = 8;
+	t.arena_bytes          = 8u << 20;
+	auto env = [](const char *name) -> const char * { const char *e = std::getenv(name); return (e && e[0]) ? e : nullptr; };
+	if (const char *e = env("VKV_RAYMARCH_SCHEDULER"))
+		t.scheduler = e[0] == 'p';
+	if (const char *e = env("VKV_RAYMARCH_BATCH"))
+		t.batch_mode = e[0] == 'p';
+	if (const char *e = env("VKV_RAYMARCH_BATCH_ORDER"))
+		t.batch_sequential = e[0] == 's';
+	if (const char *e = env("VKV_RAYMARCH_TILE_ORDER"))
+		t.tile_order_linear = e[0] == 'l';
+	if (const char *e = env("VKV_RAYMARCH_LUT"))
+		t.address_tables = e[0] == '0' ? 0 : (e[0] == '2' ? 1 : 2);
+	if (const char *e = env("VKV_RAYMARCH_FULL_LIMIT"))
+		t.full_table_lds_limit = (uint32_t) std::max(0l, std::atol(e));
+	if (const char *e = env("VKV_RAYMARCH_CULL"))
+		t.screen_cull = e[0] != '0';
+	if (const char *e = env("VKV_RAYMARCH_FEEDBACK"))
+		t.feedback = e[0] != '0';
+	if (const char *e = env("VKV_RAYMARCH_FEEDBACK_PERIOD"))
+		t.feedback_period = (uint32_t) std::max(1l, std::atol(e));
+	if (const char *e = env("VKV_RAYMARCH_TILE_MIX"))
+	{
+		double h = 0.0, sp = 0.0;
+		if (std::sscanf(e, "%lf,%lf", &h, &sp) == 2)
+			t.tile_mix_heavy = (float) h, t.tile_mix_spread = (float) sp;
+	}
+	if (const char *e = env("VKV_GRADIENT_SEGMENT"))
+		t.gradient_segment = (uint32_t) std::min(std::max(std::atol(e), 0l), 255l);
+	if (const char *e = env("VKV_PACK_TILE"))
+		t.pack_tile = std::atoi(e);
+	if (const char *e = env("VKV_ARENA_BYTES"))
+		t.arena_bytes = (uint32_t) std::min(std::max(std::atol(e), 1l << 20), 1l << 30);
+}
+
 int vkv_create(int device_ordinal, vkv_ctx **out_ctx)
 {
 	if (!out_ctx)
@@ -217,6 +333,17 @@ int vkv_create(int device_ordinal, vkv_ctx **out_ctx)
 	ctx->error[0] = 0;
 	ctx->d_trace  = nullptr;
 	ctx->d_debug_orders = nullptr, ctx->debug_order_frames = ctx->debug_order_count = 0;
+	default_tuning(ctx->tuning);
+	{        // the arena every later launch carves its tables and scratch blocks out of (the one allocation of the render path)
+		DeviceGuard guard(device_ordinal);
+		void *      p = nullptr;
+		if (hipMalloc(&p, ctx->tuning.arena_bytes) != hipSuccess)
+		{
+			delete ctx;
+			return VKV_E_NO_DEVICE;
+		}
+		ctx->arena = static_cast<uint8_t *>(p), ctx->arena_bytes = ctx->tuning.arena_bytes, ctx->arena_used = 0;
+	}
 	*out_ctx      = ctx;        // the caller's current device is left as it is: every entry point switches to ctx->device itself
 	return VKV_OK;
 }
@@ -228,24 +355,135 @@ void vkv_destroy(vkv_ctx *ctx)
 	{
 		DeviceGuard guard(ctx->device);
 		(void) hipDeviceSynchronize();        // launches that still read the context's tables, scratch or feedback buffers
-		for (auto &kv : ctx->scratch)
-			(void) hipFree(kv.second);
-		for (auto &t : ctx->tile_orders)
-			(void) hipFree(t.d_order);
-		for (auto &t : ctx->addr_luts)
-			(void) hipFree(t.d_lut);
+		for (auto *t : ctx->tile_orders)
+		{
+			if (t->table.uploaded)
+				(void) hipEventDestroy(t->table.uploaded);
+			delete t;
+		}
+		for (auto *t : ctx->addr_luts)
+		{
+			if (t->table.uploaded)
+				(void) hipEventDestroy(t->table.uploaded);
+			delete t;
+		}
 		for (auto *f : ctx->feedback)
 		{
 			(void) hipFree(f->d_cost);
 			(void) hipFree(f->d_order);
 			delete f;
 		}
+		for (void *p : ctx->overflow)
+			(void) hipFree(p);
+		(void) hipFree(ctx->arena);
 	}
 	delete ctx;
 }
 
-// Diagnostic hook (not part of the public header): per-wave timeline of the next vkv_render launches into d_buffer
-// (4 x u64 per wave of the static scheduler's grid); nullptr switches it off.
+int vkv_get_tuning(const vkv_ctx *ctx, VkvTuning *out)
+{
+	if (!ctx || !out)
+		return VKV_E_INVALID_ARGUMENT;
+	std::lock_guard<std::mutex> lock(const_cast<vkv_ctx *>(ctx)->mutex);
+	*out = ctx->tuning;
+	return VKV_OK;
+}
+
+int vkv_set_tuning(vkv_ctx *ctx, const VkvTuning *tuning)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (!tuning || tuning->struct_size != sizeof(VkvTuning))
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "set_tuning: struct_size must be sizeof(VkvTuning) = %zu (start from vkv_get_tuning)", sizeof(VkvTuning));
+	if (tuning->scheduler < 0 || tuning->scheduler > 1 || tuning->batch_mode < 0 || tuning->batch_mode > 1 || tuning->address_tables < 0 ||
+	    tuning->address_tables > 2 || tuning->feedback_period == 0 || tuning->gradient_segment > 255u ||
+	    (tuning->pack_tile != 0 && tuning->pack_tile != 2 && tuning->pack_tile != 4))
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "set_tuning: field out of range");
+	std::lock_guard<std::mutex> lock(ctx->mutex);
+	const uint32_t              arena = ctx->tuning.arena_bytes;
+	ctx->tuning                       = *tuning;
+	ctx->tuning.arena_bytes           = arena;        // read-only
+	return VKV_OK;
+}
+
+int vkv_release_stream(vkv_ctx *ctx, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	std::lock_guard<std::mutex> lock(ctx->mutex);
+	auto                        it = ctx->scratch.find((hipStream_t) stream);
+	if (it != ctx->scratch.end())
+	{
+		ctx->free_scratch.push_back(it->second);
+		ctx->scratch.erase(it);
+	}
+	return VKV_OK;
+}
+
+int vkv_register_target(vkv_ctx *ctx, const void *d_target, uint32_t image_width, uint32_t image_height, const VkvTileSchedule *tiles)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
+	if (!d_target || !tiles || image_width == 0 || image_height == 0 || tiles->tile_width == 0 || tiles->tile_height == 0 || tiles->tile_stride == 0)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "register_target: null pointer or zero size");
+	(void) vkv_forget_target(ctx, d_target);        // a target has one state: registering it again replaces it
+	if (tiles->tile_count == 0)
+		return VKV_OK;
+	uint32_t *cost = nullptr, *order = nullptr;
+	const size_t bytes = (size_t) tiles->tile_count * sizeof(uint32_t);
+	hipError_t   e     = hipMalloc((void **) &cost, bytes);
+	if (e == hipSuccess)
+		e = hipMalloc((void **) &order, bytes);
+	std::vector<uint32_t> identity(tiles->tile_count);
+	for (uint32_t i = 0; i < tiles->tile_count; ++i)
+		identity[i] = i;
+	// the order starts out as a valid permutation, the costs as zero; both are complete when this call returns
+	if (e == hipSuccess)
+		e = hipMemset(cost, 0, bytes);
+	if (e == hipSuccess)
+		e = hipMemcpy(order, identity.data(), bytes, hipMemcpyHostToDevice);
+	auto *f = e == hipSuccess ? new (std::nothrow) vkv_ctx::TileFeedback{d_target, image_width, image_height, tiles->tile_width, tiles->tile_height, tiles->tile_first,
+	                                                                      tiles->tile_stride, tiles->tile_count, cost, order, false, 0u, 0u, 8u, 0u}
+	                          : nullptr;
+	if (!f)
+	{
+		(void) hipFree(cost);
+		(void) hipFree(order);
+		return set_error(ctx, e != hipSuccess ? (int) e : VKV_E_UNSUPPORTED, "register_target: %s", e != hipSuccess ? hipGetErrorString(e) : "out of memory");
+	}
+	std::lock_guard<std::mutex> lock(ctx->mutex);
+	f->period = ctx->tuning.feedback_period;
+	ctx->feedback.push_back(f);
+	return VKV_OK;
+}
+
+int vkv_forget_target(vkv_ctx *ctx, const void *d_target)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard            guard(ctx->device);
+	vkv_ctx::TileFeedback *f = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(ctx->mutex);
+		for (size_t i = 0; i < ctx->feedback.size(); ++i)
+			if (ctx->feedback[i]->target == d_target)
+			{
+				f = ctx->feedback[i];
+				ctx->feedback.erase(ctx->feedback.begin() + (long) i);
+				break;
+			}
+	}
+	if (!f)
+		return VKV_OK;
+	(void) hipDeviceSynchronize();        // launches that still write costs or read the order (the entry is out of the list: no new ones)
+	(void) hipFree(f->d_cost);
+	(void) hipFree(f->d_order);
+	delete f;
+	return VKV_OK;
+}
+
+// ---- diagnostic entry points: include/vkvolume_amd_debug.h (not part of the drop-in boundary) ----
 int vkv_debug_trace(vkv_ctx *ctx, void *d_buffer)
 {
 	if (!ctx)
@@ -254,9 +492,6 @@ int vkv_debug_trace(vkv_ctx *ctx, void *d_buffer)
 	return VKV_OK;
 }
 
-// Diagnostic hook (not part of the public header): the next vkv_render_batch launches take frame i's tile start order from
-// d_orders + i * count (device array of schedule-entry indices, a permutation of 0 .. count - 1) instead of the centre-first order, when
-// count equals the schedule's tile count; nullptr switches it off.  For start-order experiments (tools/tile_order_feedback.py).
 int vkv_debug_tile_orders(vkv_ctx *ctx, const uint32_t *d_orders, uint32_t frames, uint32_t count)
 {
 	if (!ctx)
@@ -265,9 +500,6 @@ int vkv_debug_tile_orders(vkv_ctx *ctx, const uint32_t *d_orders, uint32_t frame
 	return VKV_OK;
 }
 
-// Diagnostic hook (not part of the public header): counts the floats with bit patterns [first_bits, first_bits + count) for which a
-// short-cut of the gradient kernel differs from the plain form (what = 0: the short correctly rounded sqrt vs __builtin_sqrtf,
-// what = 1: the one-instruction clamped R8_UNORM store); *d_mismatches (device, zeroed by the caller) += that.
 int vkv_debug_check(vkv_ctx *ctx, int32_t what, uint32_t first_bits, uint64_t count, uint64_t *d_mismatches, void *stream)
 {
 	if (!ctx)
@@ -700,6 +932,7 @@ struct Rccl
 	nccl_gather_fn gather = nullptr;
 	nccl_error_fn  error  = nullptr;
 	bool           tried  = false;
+	std::string    why;        // the loader's message when no library could be opened (dlerror() clears itself: captured once)
 };
 Rccl       g_rccl;
 std::mutex g_rccl_mutex;
@@ -720,7 +953,17 @@ const Rccl &rccl()
 			h = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
 	for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
 		if (!h)
+		{
 			h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+			if (!h)
+			{
+				const char *msg = dlerror();
+				g_rccl.why += (g_rccl.why.empty() ? "" : "; ");
+				g_rccl.why += msg ? msg : name;
+			}
+		}
+	if (h && !dlsym(h, "ncclGather"))
+		g_rccl.why = "the RCCL library that was found does not export ncclGather";
 	if (h)
 	{
 		g_rccl.handle = h;
@@ -742,7 +985,7 @@ int vkv_gather_tiles(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, size_t
 		return VKV_OK;
 	const Rccl &r = rccl();
 	if (!r.gather)
-		return set_error(ctx, VKV_E_UNSUPPORTED, "gather_tiles: no RCCL library with ncclGather could be loaded (%s)", dlerror() ? dlerror() : "librccl.so.1");
+		return set_error(ctx, VKV_E_UNSUPPORTED, "gather_tiles: no RCCL library with ncclGather could be loaded (%s)", r.why.empty() ? "librccl.so.1" : r.why.c_str());
 	const int rc = r.gather(d_tiles, d_gathered, bytes_per_rank, 0 /* ncclInt8 / ncclChar */, root, nccl_comm, (hipStream_t) stream);
 	if (rc != 0)
 		return set_error(ctx, 1000 + rc, "gather_tiles: ncclGather: %s", r.error ? r.error(rc) : "error");
@@ -765,6 +1008,52 @@ int vkv_assemble_frame(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, void
 	if (rc != VKV_OK || !is_root)
 		return rc;
 	return vkv_scatter_tiles(ctx, d_gathered, d_image, image_width, image_height, tile_width, tile_height, n_ranks, tiles_per_rank, bytes_per_pixel, stream);
+}
+
+int vkv_assemble_frames(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, void *const *d_images, uint32_t frames, uint32_t image_width, uint32_t image_height,
+                        uint32_t tile_width, uint32_t tile_height, uint32_t n_ranks, uint32_t rank, uint32_t tiles_per_rank, uint32_t bytes_per_pixel, int32_t root,
+                        void *nccl_comm, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	if (n_ranks == 0 || rank >= n_ranks || root < 0 || (uint32_t) root >= n_ranks || frames == 0 || frames > VKV_MAX_BATCH)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: bad rank / root / n_ranks, or frames not in 1 .. %d", VKV_MAX_BATCH);
+	const bool is_root = rank == (uint32_t) root;
+	if (is_root && (!d_gathered || !d_images))
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: the root needs d_gathered and d_images");
+	if (is_root)
+		for (uint32_t f = 0; f < frames; ++f)
+			if (!d_images[f])
+				return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: d_images[%u] is null", f);
+	if (!image_width || !image_height || !tile_width || !tile_height)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: zero size");
+	const uint64_t tiles = (uint64_t) ((image_width + tile_width - 1) / tile_width) * ((image_height + tile_height - 1) / tile_height);
+	if ((uint64_t) tiles_per_rank * n_ranks < tiles)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: the ranks' buffers hold fewer tiles than the image");
+	// ONE collective for the whole launch: [frame][tiles] of every rank -> [rank][frame][tiles] on the root
+	const size_t bytes_per_rank = (size_t) frames * tiles_per_rank * tile_width * tile_height * bytes_per_pixel;
+	int          rc             = vkv_gather_tiles(ctx, d_tiles, d_gathered, bytes_per_rank, root, nccl_comm, stream);
+	if (rc != VKV_OK || !is_root)
+		return rc;
+	DeviceGuard guard(ctx->device);
+	return launch_scatter_tiles_frames(ctx, d_gathered, d_images, frames, image_width, image_height, tile_width, tile_height, n_ranks, tiles_per_rank, bytes_per_pixel,
+	                                   (hipStream_t) stream);
+}
+
+int vkv_prepare_render(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t count, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard guard(ctx->device);
+	if (!P || count == 0 || count > VKV_MAX_BATCH)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "prepare_render: count must be 1 .. %d", VKV_MAX_BATCH);
+	for (uint32_t i = 0; i < count; ++i)
+	{
+		const int rc = check_render_params(ctx, &P[i]);
+		if (rc != VKV_OK)
+			return rc;
+	}
+	return prepare_render(ctx, P, count, (hipStream_t) stream);
 }
 
 int vkv_synth_volume(vkv_ctx *ctx, uint8_t *d_volume, VkvExtent3D extent, uint32_t kind, uint32_t seed, void *stream)

@@ -1101,6 +1101,28 @@ __global__ void __launch_bounds__(256) k_scatter_tiles(const T *__restrict__ gat
 	image[(size_t) y * iw + x] = gathered[src];
 }
 
+// the frames of one gathered vkv_render_batch launch in one grid: blockIdx.z = frame; the source holds [rank][frame][tiles]
+struct ScatterImages
+{
+	void *image[VKV_MAX_BATCH];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_scatter_tiles_frames(const T *__restrict__ gathered, const ScatterImages images, uint32_t iw, uint32_t ih, uint32_t tw, uint32_t th,
+                                                              uint32_t n_ranks, uint32_t tiles_per_rank, uint32_t frames)
+{
+	const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+	const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+	const uint32_t f = blockIdx.z;
+	if (x >= iw || y >= ih)
+		return;
+	const uint32_t tiles_x = (iw + tw - 1) / tw;
+	const uint32_t t       = (y / th) * tiles_x + (x / tw);
+	const uint32_t rank = t % n_ranks, k = t / n_ranks;
+	const size_t   src = ((((size_t) rank * frames + f) * tiles_per_rank + k) * th + (y % th)) * tw + (x % tw);
+	static_cast<T *>(images.image[f])[(size_t) y * iw + x] = gathered[src];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------------------------
@@ -1122,8 +1144,8 @@ int launch_gradient_map(vkv_ctx *ctx, const uint8_t *d_vol, uint8_t *d_grad, Vkv
 		// kGradSegment tiles per workgroup, fewer when the volume would not give every CU its eight workgroups otherwise
 		const uint64_t want = (uint64_t) 8 * (uint64_t) std::max(1, ctx->cu_count);
 		uint32_t       seg  = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(kGradSegment, tx * ty * tz / want));
-		if (const char *env = std::getenv("VKV_GRADIENT_SEGMENT"))        // read per call: lets a test march a small volume
-			seg = (uint32_t) std::min<long>(std::max<long>(std::atol(env), 1), 255);
+		if (const uint32_t forced = tuning_of(ctx).gradient_segment)        // VkvTuning: lets a test march a small volume
+			seg = std::min(forced, 255u);
 		const uint64_t n_wgs = tx * ty * ((tz + seg - 1) / seg);
 		if (n_wgs <= 0x7fffffffull)
 		{
@@ -1381,7 +1403,7 @@ int launch_pack_volume(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_grad
 	const PackedDims pd = packed_dims((int) e.width, (int) e.height, (int) e.depth);
 	if ((e.width & 3u) == 0 && ((((uintptr_t) d_vol) | ((uintptr_t) d_grad)) & 3u) == 0)
 	{
-		static const int tile_env = [] { const char *v = std::getenv("VKV_PACK_TILE"); return v ? std::atoi(v) : 0; }();        // A/B switch: 2 or 4
+		const int tile_env = tuning_of(ctx).pack_tile;        // A/B switch: 2 or 4
 		const bool     big = tile_env ? tile_env == 4 : (pd.by >= 16 && pd.bz >= 16);
 		const uint32_t t   = big ? 4u : 2u;
 		const uint32_t gx = (uint32_t) (pd.bx + 7) / 8, gy = ((uint32_t) pd.by + t - 1) / t, gz = ((uint32_t) pd.bz + t - 1) / t;
@@ -1555,6 +1577,27 @@ int launch_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, ui
 	else
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "scatter_tiles: bytes_per_pixel must be 4 or 16");
 	return check_launch(ctx, "scatter_tiles");
+}
+
+int launch_scatter_tiles_frames(vkv_ctx *ctx, const void *d_gathered, void *const *d_images, uint32_t frames, uint32_t iw, uint32_t ih, uint32_t tw, uint32_t th,
+                                uint32_t n_ranks, uint32_t tiles_per_rank, uint32_t bpp, hipStream_t s)
+{
+	ScatterImages imgs = {};
+	uintptr_t     align = (uintptr_t) d_gathered;
+	for (uint32_t f = 0; f < frames; ++f)
+		imgs.image[f] = d_images[f], align |= (uintptr_t) d_images[f];
+	if (bpp == 4 && (iw & 3u) == 0 && (tw & 3u) == 0 && (align & 15u) == 0)
+		hipLaunchKernelGGL(k_scatter_tiles_frames<uint4>, dim3((iw / 4 + 63) / 64, (ih + 3) / 4, frames), dim3(256), 0, s, (const uint4 *) d_gathered, imgs, iw / 4, ih,
+		                   tw / 4, th, n_ranks, tiles_per_rank, frames);
+	else if (bpp == 4)
+		hipLaunchKernelGGL(k_scatter_tiles_frames<uint32_t>, dim3((iw + 63) / 64, (ih + 3) / 4, frames), dim3(256), 0, s, (const uint32_t *) d_gathered, imgs, iw, ih, tw,
+		                   th, n_ranks, tiles_per_rank, frames);
+	else if (bpp == 16)
+		hipLaunchKernelGGL(k_scatter_tiles_frames<uint4>, dim3((iw + 63) / 64, (ih + 3) / 4, frames), dim3(256), 0, s, (const uint4 *) d_gathered, imgs, iw, ih, tw, th,
+		                   n_ranks, tiles_per_rank, frames);
+	else
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: bytes_per_pixel must be 4 or 16");
+	return check_launch(ctx, "assemble_frames");
 }
 
 }        // namespace vkv

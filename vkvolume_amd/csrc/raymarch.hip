@@ -27,26 +27,25 @@ constexpr uint32_t kLfFull  = kLfLut | kLeanFull;                          // + 
 struct LeanChoice
 {
 	int    kind;        // 0 plain, 1 two-level tables, 2 full tables
-	size_t lds;         // dynamic LDS bytes
+	size_t lds;         // dynamic LDS bytes (lean_lds_bytes: the kernels' whole LDS layout lives in the dynamic segment)
 };
 
-static LeanChoice choose_lean(const RayMarchArgs &a)
+static LeanChoice choose_lean(const RayMarchArgs &a, const VkvTuning &T)
 {
 	const size_t lut_bytes = (size_t) a.lut_words * sizeof(uint32_t);
 	if (!a.packed || !a.addr_lut || lut_bytes > kMaxLutBytes || !map_fits_u24((uint32_t) a.mw, (uint32_t) a.mh, (uint32_t) a.md))
-		return {0, 0};
-	static const bool no_full = [] { const char *e = std::getenv("VKV_RAYMARCH_LUT"); return e && e[0] == '2'; }();        // A/B switch: two-level only
+		return {0, lean_lds_bytes(0, 0, a.W, a.H, a.D)};
+	const bool        no_full  = T.address_tables < 2;        // A/B switch: two-level only
 	const size_t      full_end = kFullLutWord * 4 + full_lut_bytes(a.W, a.H, a.D);        // from the start of RmLds
 	// the full tables hold offsets in units of two bytes in 32 bits: a packed image of up to 8 GiB
 	const bool        fits_u32 = packed_bytes(packed_dims(a.W, a.H, a.D)) <= (1ull << 33);
-	static const size_t full_limit = [] { const char *e = std::getenv("VKV_RAYMARCH_FULL_LIMIT"); return e ? (size_t) std::atol(e) : kFullLdsLimit; }();        // A/B switch
-	if (!no_full && fits_u32 && full_end <= full_limit)
-		return {2, std::max(lut_bytes, full_end > sizeof(RmLds) ? full_end - sizeof(RmLds) : (size_t) 0)};
-	return {1, lut_bytes};
+	if (!no_full && fits_u32 && full_end <= (size_t) T.full_table_lds_limit)
+		return {2, lean_lds_bytes(2, a.lut_words, a.W, a.H, a.D)};
+	return {1, lean_lds_bytes(1, a.lut_words, a.W, a.H, a.D)};
 }
 
 template <int SKIP, bool ERT, int GRAD, bool PACKED>
-static int launch_one(vkv_ctx *ctx, int sched, RayMarchArgs &a, hipStream_t s)
+static int launch_one(vkv_ctx *ctx, int sched, const VkvTuning &T, RayMarchArgs &a, hipStream_t s)
 {
 	if (sched == kSchedPersistent)
 	{
@@ -75,7 +74,7 @@ static int launch_one(vkv_ctx *ctx, int sched, RayMarchArgs &a, hipStream_t s)
 		bool launched = false;
 		if constexpr (PACKED && GRAD != 2)
 		{
-			const LeanChoice c = choose_lean(a);
+			const LeanChoice c = choose_lean(a, T);
 			if (c.kind == 2)
 				hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfFull>), dim3(grid), dim3(256), c.lds, s, a);
 			else if (c.kind == 1)
@@ -83,27 +82,27 @@ static int launch_one(vkv_ctx *ctx, int sched, RayMarchArgs &a, hipStream_t s)
 			launched = c.kind != 0;
 		}
 		if (!launched)
-			hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfPlain>), dim3(grid), dim3(256), 0, s, a);
+			hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfPlain>), dim3(grid), dim3(256), lean_lds_bytes(0, 0, a.W, a.H, a.D), s, a);
 	}
 	return check_launch(ctx, "render");
 }
 
 template <int SKIP, bool ERT, bool PACKED>
-static int launch_grad(vkv_ctx *ctx, int sched, int grad, RayMarchArgs &a, hipStream_t s)
+static int launch_grad(vkv_ctx *ctx, int sched, const VkvTuning &T, int grad, RayMarchArgs &a, hipStream_t s)
 {
 	if (grad == 0)
-		return launch_one<SKIP, ERT, 0, PACKED>(ctx, sched, a, s);
+		return launch_one<SKIP, ERT, 0, PACKED>(ctx, sched, T, a, s);
 	if (grad == 1)
-		return launch_one<SKIP, ERT, 1, PACKED>(ctx, sched, a, s);
-	return launch_one<SKIP, ERT, 2, PACKED>(ctx, sched, a, s);
+		return launch_one<SKIP, ERT, 1, PACKED>(ctx, sched, T, a, s);
+	return launch_one<SKIP, ERT, 2, PACKED>(ctx, sched, T, a, s);
 }
 
 template <int SKIP>
-static int launch_ert(vkv_ctx *ctx, int sched, bool ert, int grad, RayMarchArgs &a, hipStream_t s)
+static int launch_ert(vkv_ctx *ctx, int sched, const VkvTuning &T, bool ert, int grad, RayMarchArgs &a, hipStream_t s)
 {
 	if (a.packed)
-		return ert ? launch_grad<SKIP, true, true>(ctx, sched, grad, a, s) : launch_grad<SKIP, false, true>(ctx, sched, grad, a, s);
-	return ert ? launch_grad<SKIP, true, false>(ctx, sched, grad, a, s) : launch_grad<SKIP, false, false>(ctx, sched, grad, a, s);
+		return ert ? launch_grad<SKIP, true, true>(ctx, sched, T, grad, a, s) : launch_grad<SKIP, false, true>(ctx, sched, T, grad, a, s);
+	return ert ? launch_grad<SKIP, true, false>(ctx, sched, T, grad, a, s) : launch_grad<SKIP, false, false>(ctx, sched, T, grad, a, s);
 }
 
 // Conservative pixel bound of the unit box [0,1]^3 (texture space) as seen through the ray generator of the kernel: pixel (px, py) looks
@@ -111,11 +110,10 @@ static int launch_ert(vkv_ctx *ctx, int sched, bool ert, int grad, RayMarchArgs 
 // g > 0.  The bound is the min / max over the eight corners, widened by two pixels (the device evaluates the direction in fp32: it can
 // disagree with this double-precision solve by a tiny fraction of a pixel); a corner at or behind the camera plane, or a degenerate
 // generator, disables it.  Pixels outside cannot hit the box, whatever the clip plane or the depth test do afterwards.
-static void screen_bound_of_box(RayMarchArgs &a)
+static void screen_bound_of_box(RayMarchArgs &a, const VkvTuning &T)
 {
 	a.cull_x0 = 0u, a.cull_x1 = ~0u, a.cull_y0 = 0u, a.cull_y1 = ~0u;
-	static const bool off = [] { const char *e = std::getenv("VKV_RAYMARCH_CULL"); return e && e[0] == '0'; }();        // A/B switch
-	if (off)
+	if (!T.screen_cull)        // A/B switch
 		return;
 	// inverse of M = [ddx ddy dir00] (columns) by the adjugate
 	const double M[3][3] = {{a.ddx[0], a.ddy[0], a.dir00[0]}, {a.ddx[1], a.ddy[1], a.dir00[1]}, {a.ddx[2], a.ddy[2], a.dir00[2]}};
@@ -152,7 +150,7 @@ static void screen_bound_of_box(RayMarchArgs &a)
 }
 
 // VkvRenderParams -> kernel arguments.  Returns VKV_OK with a.nblocks == 0 when the schedule is empty.
-int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, RayMarchArgs &a)
+int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, RayMarchArgs &a, hipStream_t s, const VkvTuning &T, bool setup)
 {
 	for (int i = 0; i < 3; ++i)
 	{
@@ -202,13 +200,11 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 	a.tile_cost = nullptr, a.order_out = nullptr;        // start-order feedback: attached by the launchers
 	a.trace       = reinterpret_cast<unsigned long long *>(ctx->d_trace);
 	a.back        = (int) std::ceil(P->transfer_function.sampling_factor);
-	static const bool in_order = [] { const char *e = std::getenv("VKV_RAYMARCH_TILE_ORDER"); return e && e[0] == 'l'; }();        // "linear": A/B switch
 	a.addr_lut = nullptr, a.lut_y = a.lut_z = a.lut_words = 0;
-	static const bool no_lut = [] { const char *e = std::getenv("VKV_RAYMARCH_LUT"); return e && e[0] == '0'; }();        // A/B switch
-	if (a.packed && !no_lut)
-		a.addr_lut = packed_addr_lut(ctx, a.W, a.H, a.D, &a.lut_y, &a.lut_z, &a.lut_words);
-	screen_bound_of_box(a);
-	a.tile_order  = in_order ? nullptr : tile_start_order(ctx, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count);
+	if (a.packed && T.address_tables != 0)
+		a.addr_lut = packed_addr_lut(ctx, a.W, a.H, a.D, &a.lut_y, &a.lut_z, &a.lut_words, s, setup);
+	screen_bound_of_box(a, T);
+	a.tile_order  = T.tile_order_linear ? nullptr : tile_start_order(ctx, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count, s, setup);
 	for (int i = 0; i < 256; ++i)
 		a.alpha_lut[i] = alpha_lut[i];
 	return VKV_OK;
@@ -217,20 +213,21 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 // Start-order feedback.  A renderer draws into the same target again and again with a camera that moves little from frame to frame,
 // so the tiles that were expensive last time are expensive now: every marching wave leaves its iteration count in a per-target cost
 // buffer (atomicMax per tile), and a small sort kernel behind the render (k_tile_orders_from_cost, one workgroup per frame, same stream)
-// turns them into the longest-first order the next frame into that target starts its tiles in.  The first frame into a target, and every frame when
-// VKV_RAYMARCH_FEEDBACK=0, uses the centre-of-image-first order.  Any order renders the same frame.
-// Returns true when `a` now asks for a sort (order_out set).
+// turns them into the longest-first order the next frame into that target starts its tiles in.  The per-target device state is created by
+// vkv_register_target (a set-up call): a target that was never registered, the first frame into a registered one, and every frame when
+// VkvTuning.feedback is 0, use the centre-of-image-first order.  Nothing is allocated, freed or waited for here.  Any order renders the
+// same frame.  Returns true when `a` now asks for a sort (order_out set).
 static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a, hipStream_t s)
 {
-	static const bool off = [] { const char *e = std::getenv("VKV_RAYMARCH_FEEDBACK"); return e && e[0] == '0'; }();
+	(void) s;
 	// costs are measured (and sorted behind the render) on the first frame into a target and then every `period`-th one: a camera that
 	// moves little keeps the order good for a few frames, and the sort kernel + the cost atomics are then paid once per period
-	static const uint32_t period = [] { const char *e = std::getenv("VKV_RAYMARCH_FEEDBACK_PERIOD"); const long v = e ? std::atol(e) : 8; return (uint32_t) (v < 1 ? 1 : v); }();
 	const void *      target = a.out_rgba8 ? (const void *) a.out_rgba8 : (const void *) a.out_color;
-	if (off || !target || a.tile_count < 64 || ctx->d_debug_orders)
-		return false;
 	vkv_ctx::TileFeedback *     f = nullptr;
 	std::lock_guard<std::mutex> lock(ctx->mutex);
+	const uint32_t              period = ctx->tuning.feedback_period < 1u ? 1u : ctx->tuning.feedback_period;
+	if (!ctx->tuning.feedback || !target || a.tile_count < 64 || ctx->d_debug_orders)
+		return false;
 	for (auto *e : ctx->feedback)
 		if (e->target == target && e->img_w == a.img_w && e->img_h == a.img_h && e->tile_w == a.tile_w && e->tile_h == a.tile_h && e->first == a.tile_first &&
 		    e->stride == a.tile_stride && e->count == a.tile_count)
@@ -239,45 +236,7 @@ static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a, hipStream_t s)
 			break;
 		}
 	if (!f)
-	{
-		if (ctx->feedback.size() >= 256)
-		{        // a renderer has a handful of targets: drop the oldest entry rather than grow without bound (its buffers may still be in use)
-			(void) hipDeviceSynchronize();
-			(void) hipFree(ctx->feedback.front()->d_cost);
-			(void) hipFree(ctx->feedback.front()->d_order);
-			delete ctx->feedback.front();
-			ctx->feedback.erase(ctx->feedback.begin());
-		}
-		uint32_t *cost = nullptr, *order = nullptr;
-		if (hipMalloc((void **) &cost, (size_t) a.tile_count * sizeof(uint32_t)) != hipSuccess)
-			return false;
-		if (hipMalloc((void **) &order, (size_t) a.tile_count * sizeof(uint32_t)) != hipSuccess)
-		{
-			(void) hipFree(cost);
-			return false;
-		}
-		f = new (std::nothrow) vkv_ctx::TileFeedback{target, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count, cost, order, false, 0u, 0u, period, 0u, {}};
-		if (f)
-		{
-			f->identity.resize(a.tile_count);
-			for (uint32_t i = 0; i < a.tile_count; ++i)
-				f->identity[i] = i;
-		}
-		// both buffers are initialised ON THE LAUNCH'S STREAM, ahead of the render that writes the costs and of the sort that reads them
-		// twice (a memset on another stream landing between the sort's two passes would leave holes in the order), and the order starts
-		// out as a valid permutation (a frame that reads it too early - the same target used from two streams without an event - then
-		// renders a wrong picture, not a wild address)
-		if (!f || hipMemsetAsync(cost, 0, (size_t) a.tile_count * sizeof(uint32_t), s) != hipSuccess ||
-		    hipMemcpyAsync(order, f->identity.data(), (size_t) a.tile_count * sizeof(uint32_t), hipMemcpyHostToDevice, s) != hipSuccess)
-		{
-			(void) hipStreamSynchronize(s);
-			(void) hipFree(cost);
-			(void) hipFree(order);
-			delete f;
-			return false;
-		}
-		ctx->feedback.push_back(f);
-	}
+		return false;        // not registered (or registered for another schedule): centre-first
 	// the view of this frame: central ray (normalised) and camera position in texture space.  Costs measured on a view that was more
 	// than ~12 degrees away (or from a camera that has moved by more than a fifth of its distance to the volume's centre) say little
 	// about this frame - an order sorted by them scatters the heavy tiles (measured: -3 % for targets that alternate between views
@@ -326,15 +285,15 @@ static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a, hipStream_t s)
 
 int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, hipStream_t s)
 {
+	const VkvTuning T = tuning_of(ctx);
 	RayMarchArgs a;
-	const int    rc = fill_render_args(ctx, P, alpha_lut, a);
+	const int    rc = fill_render_args(ctx, P, alpha_lut, a, s, T, false);
 	if (rc != VKV_OK || a.nblocks == 0)
 		return rc;
 
-	// scheduler: one lane per ray on static 8x8 tiles; VKV_RAYMARCH_SCHEDULER=persistent selects the lane-refilling persistent
+	// scheduler: one lane per ray on static 8x8 tiles; VkvTuning.scheduler = 1 selects the lane-refilling persistent
 	// waves (bit-identical output; measured 2.7x slower: the re-fill breaks the spatial coherence of a wave)
-	const char *env   = std::getenv("VKV_RAYMARCH_SCHEDULER");        // read per call so a test can flip it
-	const int   sched = (env && env[0] == 'p') ? (int) kSchedPersistent : (int) kSchedLean;
+	const int   sched = T.scheduler == 1 ? (int) kSchedPersistent : (int) kSchedLean;
 
 	const bool ert  = P->options.early_ray_termination != 0;
 	const int  grad = !P->transfer_function.use_gradient ? 0 : (P->use_precomputed_gradient ? 1 : 2);
@@ -344,10 +303,10 @@ int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut
 	int        rc2;
 	switch (P->options.skipping_type)
 	{
-		case VKV_SKIP_NONE: rc2 = launch_ert<VKV_SKIP_NONE>(ctx, sched, ert, grad, a, s); break;
-		case VKV_SKIP_BLOCK: rc2 = launch_ert<VKV_SKIP_BLOCK>(ctx, sched, ert, grad, a, s); break;
-		case VKV_SKIP_DISTANCE: rc2 = launch_ert<VKV_SKIP_DISTANCE>(ctx, sched, ert, grad, a, s); break;
-		case VKV_SKIP_ANISOTROPIC_DISTANCE: rc2 = launch_ert<VKV_SKIP_ANISOTROPIC_DISTANCE>(ctx, sched, ert, grad, a, s); break;
+		case VKV_SKIP_NONE: rc2 = launch_ert<VKV_SKIP_NONE>(ctx, sched, T, ert, grad, a, s); break;
+		case VKV_SKIP_BLOCK: rc2 = launch_ert<VKV_SKIP_BLOCK>(ctx, sched, T, ert, grad, a, s); break;
+		case VKV_SKIP_DISTANCE: rc2 = launch_ert<VKV_SKIP_DISTANCE>(ctx, sched, T, ert, grad, a, s); break;
+		case VKV_SKIP_ANISOTROPIC_DISTANCE: rc2 = launch_ert<VKV_SKIP_ANISOTROPIC_DISTANCE>(ctx, sched, T, ert, grad, a, s); break;
 		default: return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: bad skipping_type %d", P->options.skipping_type);
 	}
 	if (rc2 == VKV_OK && sort)
@@ -356,6 +315,23 @@ int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut
 		rc2 = check_launch(ctx, "render (start order)");
 	}
 	return rc2;
+}
+
+// vkv_prepare_render: everything a later launch of these parameter blocks on `s` takes from the context, created now (set-up call)
+int prepare_render(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, hipStream_t s)
+{
+	const VkvTuning T = tuning_of(ctx);
+	float           lut[256] = {};
+	for (uint32_t i = 0; i < n; ++i)
+	{
+		RayMarchArgs a;
+		const int    rc = fill_render_args(ctx, &P[i], lut, a, s, T, true);
+		if (rc != VKV_OK)
+			return rc;
+	}
+	if (!stream_scratch(ctx, s, true))
+		return VKV_E_UNSUPPORTED;
+	return VKV_OK;
 }
 
 // ---- several frames in one launch --------------------------------------------------------------------------------
@@ -371,7 +347,7 @@ static void launch_batch_kind(LeanChoice c, const RayMarchArgs *d_frames, uint32
 		if (c.kind != 0)
 			return;
 	}
-	hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfPlain>), dim3(grid), dim3(256), 0, s, d_frames, n, gpf);
+	hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfPlain>), dim3(grid), dim3(256), sizeof(RmLds), s, d_frames, n, gpf);
 }
 
 template <int SKIP, bool ERT>
@@ -418,7 +394,7 @@ static uint32_t launch_pull_kind(vkv_ctx *ctx, LeanChoice c, const RayMarchArgs 
 		if (c.kind == 1)
 			return launch_pull_one<SKIP, ERT, GRAD, kLfLut>(ctx, d_frames, n, d_heads, c.lds, units, s);
 	}
-	return launch_pull_one<SKIP, ERT, GRAD, kLfPlain>(ctx, d_frames, n, d_heads, 0, units, s);
+	return launch_pull_one<SKIP, ERT, GRAD, kLfPlain>(ctx, d_frames, n, d_heads, sizeof(RmLds), units, s);
 }
 
 template <int SKIP>
@@ -437,10 +413,11 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	// the argument blocks go through this stream's scratch buffer: an earlier batch on the same stream has finished with it by the
 	// time the copy (same stream) runs
 	static_assert(kMaxBatch * sizeof(RayMarchArgs) <= kScratchBytes - kBatchArgsOffset, "batch argument blocks must fit the stream scratch");
+	const VkvTuning           T = tuning_of(ctx);
 	std::vector<RayMarchArgs> host(n);
 	for (uint32_t i = 0; i < n; ++i)
 	{
-		const int rc = fill_render_args(ctx, &P[i], alpha_luts + (size_t) i * 256, host[i]);
+		const int rc = fill_render_args(ctx, &P[i], alpha_luts + (size_t) i * 256, host[i], s, T, false);
 		if (rc != VKV_OK)
 			return rc;
 		if (!host[i].packed)
@@ -473,24 +450,23 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 		return set_error(ctx, VKV_E_UNSUPPORTED, "render_batch: too many workgroups for one launch");
 	const bool ert  = P[0].options.early_ray_termination != 0;
 	const int  grad = !P[0].transfer_function.use_gradient ? 0 : (P[0].use_precomputed_gradient ? 1 : 2);
-	// frames interleaved in groups of eight workgroups (default) or one frame after the other (VKV_RAYMARCH_BATCH_ORDER=sequential, A/B
+	// frames interleaved in groups of eight workgroups (default) or one frame after the other (VkvTuning.batch_sequential, A/B
 	// switch: measured 0.183 vs 0.169 ms per frame on C3 with 8 frames per launch)
-	static const bool sequential = [] { const char *e = std::getenv("VKV_RAYMARCH_BATCH_ORDER"); return e && e[0] == 's'; }();
+	const bool        sequential = T.batch_sequential != 0;
 	const uint32_t    gpf        = sequential ? (uint32_t) (grid / n / 8) : 0u;
-	LeanChoice        choice     = choose_lean(host[0]);
+	LeanChoice        choice     = choose_lean(host[0], T);
 	for (uint32_t i = 1; i < n; ++i)
 	{        // one kernel for all frames: the most general choice any of them needs
-		const LeanChoice c = choose_lean(host[i]);
+		const LeanChoice c = choose_lean(host[i], T);
 		if (c.kind != choice.kind || c.lds != choice.lds || host[i].lut_words != host[0].lut_words)
 			choice = {0, 0};
 	}
-	// VKV_RAYMARCH_BATCH=pull: resident workgroups whose waves pull 8x8 units from per-XCD ticket counters (k_raymarch_lean_pull), possible
+	// VkvTuning.batch_mode = 1 (pull): resident workgroups whose waves pull 8x8 units from per-XCD ticket counters (k_raymarch_lean_pull), possible
 	// when every frame shares the LDS tables (same packed image and extents, TF tables, opacity table).  Bit-identical; measured on C3 with 8
 	// frames per launch: the CU stays full (7 900 of 8 192 wave slots against 5 300) and everything but the last marching tiles is done after
 	// 0.83 ms instead of 1.0, but those last tiles - the volume's silhouette, 100-250 iterations of cold probes - then run 340 us with their
 	// four 8x8 units on four different CUs (150 us as one workgroup on one CU): 0.151 ms per frame against 0.137.  Not the default.
-	const char *      batch_env = std::getenv("VKV_RAYMARCH_BATCH");        // read per call so a test can flip it
-	bool              pull      = batch_env && batch_env[0] == 'p' && !sequential;
+	bool              pull      = T.batch_mode == 1 && !sequential;
 	const uint64_t    units     = (uint64_t) host[0].tile_count * host[0].blocks_per_tile * 4u * n;
 	for (uint32_t i = 1; i < n && pull; ++i)
 	{

@@ -1449,10 +1449,19 @@ __device__ __forceinline__ void packed_filter_g(uint32_t q00, uint32_t q10, uint
 	out_g = __builtin_fmaf(wz, c1 - c0, c0) * kInv255;
 }
 
-// LDS copy of the two-level per-axis address tables (dynamic shared memory of the kernels that use kLeanLut; ~1.5 KB):
+// The LDS of the lean kernels is ONE dynamic segment whose layout the launcher sizes (lean_lds_bytes): RmLds at its start, behind it
+// either the two-level address tables (kLeanLut) or, starting inside RmLds behind the separable transfer-function tables, the
+// per-voxel-index tables (kLeanFull).  Nothing here depends on where the compiler puts static __shared__ objects (the workgroup
+// reduction behind __syncthreads_or owns 256 bytes of them).
+extern __shared__ __align__(16) uint32_t s_lean_lds[];
+static_assert(sizeof(RmLds) % 16 == 0, "the address tables behind RmLds are read as 64-bit words");
+
+__device__ __forceinline__ RmLds &lean_lds() { return *reinterpret_cast<RmLds *>(s_lean_lds); }
+
+// LDS copy of the two-level per-axis address tables (behind RmLds; ~1.5 KB):
 // words [0, 32) x position inside a macro-brick, [32, 64) y, [64, 96) z; then the macro-brick terms: x at word 96, y at A.lut_y,
 // z (64-bit, already an address inside the packed image) at A.lut_z.
-extern __shared__ __align__(16) uint32_t s_addr_lut[];
+#define s_addr_lut (s_lean_lds + sizeof(RmLds) / 4)
 constexpr uint32_t kLutXm = 96;
 
 __device__ __forceinline__ void stage_addr_lut(const RayMarchArgs &A)
@@ -1492,13 +1501,27 @@ __device__ __forceinline__ const uint8_t *packed_footprint_lut(const RayMarchArg
 // Y[H + 2], Z[D + 2], 32-bit offsets in units of TWO bytes (every term is even; a packed image of up to 8 GiB).  Built by the workgroup
 // from the two-level tables (each entry = in-macro term + macro term).  11.4 KB at 1024 x 1024 x 795: too much on top of the general
 // transfer-function tables, so they are only used with the separable transfer function, whose tables end 4 112 bytes into RmLds: the
-// full tables start there and run on into the dynamic segment (which begins where the static one ends).  Small on purpose: a workgroup
+// full tables start there and run on past the end of RmLds (the launcher sizes the segment: lean_lds_bytes).  Small on purpose: a workgroup
 // keeps its LDS until its longest wave is done, so the LDS per workgroup decides how many waves a CU holds on average.
 constexpr uint32_t kFullLutWord  = 1028;         // = sizeof(RmLds::s) / 4, checked below
 __host__ __device__ __forceinline__ bool map_fits_u24(uint32_t mw, uint32_t mh, uint32_t md) { return (uint64_t) mh * md < (1ull << 24) && mw < (1u << 24); }
-constexpr size_t   kFullLdsLimit = 17920;        // static + dynamic LDS of a workgroup that still lets 9 workgroups share a CU
+constexpr size_t   kFullLdsLimit = 17920;        // LDS of a workgroup that still lets 9 workgroups share a CU
 
 __host__ __device__ __forceinline__ size_t full_lut_bytes(int W, int H, int D) { return (size_t) (W + 2 + H + 2 + D + 2) * 4; }
+
+// dynamic LDS of a lean kernel: kind 0 = RmLds alone, 1 = + two-level tables of lut_words, 2 = whichever of that and the per-voxel-index
+// tables (which start kFullLutWord words into RmLds) ends later (a kLeanFull kernel falls back to the two-level tables when the
+// transfer function is not separable)
+__host__ __forceinline__ size_t lean_lds_bytes(int kind, uint32_t lut_words, int W, int H, int D)
+{
+	const size_t two_level = sizeof(RmLds) + (size_t) lut_words * 4;
+	if (kind == 0)
+		return sizeof(RmLds);
+	if (kind == 1)
+		return two_level;
+	const size_t full_end = (size_t) kFullLutWord * 4 + full_lut_bytes(W, H, D);
+	return two_level > full_end ? two_level : full_end;
+}
 
 __device__ __forceinline__ uint32_t *full_lut_base(const RmLds &L) { return const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(&L)) + kFullLutWord; }
 
@@ -2014,7 +2037,7 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF>
 __global__ void __launch_bounds__(256) k_raymarch_lean(const RayMarchArgs A)
 {
-	__shared__ RmLds L;
+	RmLds &L = lean_lds();
 	lean_block<SKIP, ERT, GRAD, PACKED, LF>(A, blockIdx.x, L);
 }
 
@@ -2025,8 +2048,8 @@ __global__ void __launch_bounds__(256) k_raymarch_lean(const RayMarchArgs A)
 template <int SKIP, bool ERT, int GRAD, uint32_t LF>
 __global__ void __launch_bounds__(256) k_raymarch_lean_batch(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t groups_per_frame)
 {
-	__shared__ RmLds L;
-	const uint32_t   g = blockIdx.x >> 3;
+	RmLds &        L = lean_lds();
+	const uint32_t g = blockIdx.x >> 3;
 	// groups_per_frame == 0: frames interleaved in groups of eight workgroups; otherwise one frame after the other (A/B switch of the launcher)
 	const uint32_t f = groups_per_frame == 0 ? g % n : g / groups_per_frame, gi = groups_per_frame == 0 ? g / n : g % groups_per_frame;
 	lean_block<SKIP, ERT, GRAD, true, LF>(frames[f], (gi << 3) | (blockIdx.x & 7u), L);
@@ -2126,7 +2149,7 @@ __device__ __forceinline__ void pull_units(const RayMarchArgs *__restrict__ fram
 template <int SKIP, bool ERT, int GRAD, uint32_t LF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_raymarch_lean_pull(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t *__restrict__ heads)
 {
-	__shared__ RmLds    L;
+	RmLds &             L  = lean_lds();
 	const RayMarchArgs &A0 = frames[0];
 	if ((LF & kLeanLut) != 0 && GRAD != 2)
 	{        // before the barrier of stage_tables_er
@@ -2234,6 +2257,6 @@ __global__ void __launch_bounds__(256) k_tile_orders_from_cost(const RayMarchArg
 namespace vkv
 {
 // raymarch.hip: VkvRenderParams -> kernel arguments (shared with tools/lab)
-int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, RayMarchArgs &a);
+int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, RayMarchArgs &a, hipStream_t s, const VkvTuning &T, bool setup);
 }        // namespace vkv
 

@@ -124,6 +124,12 @@ __host__ __device__ __forceinline__ size_t packed_brick_offset(int bx, int by, i
 // Host-side context (capi.hip owns it).
 // Device scratch is handed out PER STREAM (stream_scratch): calls on one stream are ordered, so they may share a buffer; calls on
 // different streams never touch the same bytes, which makes every entry point re-entrant across streams of one context.
+//
+// Device memory policy (include/vkvolume_amd.h, "Conventions"): vkv_create allocates one ARENA; the small immutable tables a launch needs
+// (tile start orders, address tables) and the per-stream scratch blocks are carved out of it and are never freed or re-used before
+// vkv_destroy, so no launch can ever read a freed table, whatever the streams and threads do.  A table is uploaded asynchronously on the
+// stream of the launch that first needs it; launches on other streams are ordered behind that upload with an event until it has completed.
+// Only the set-up calls (vkv_prepare_render, vkv_register_target) fall back to hipMalloc when the arena is full.
 struct vkv_ctx
 {
 	int   device;
@@ -132,25 +138,41 @@ struct vkv_ctx
 	void *d_trace;        // diagnostic wave timeline buffer (vkv_debug_trace), normally null
 	const uint32_t *d_debug_orders;        // diagnostic per-frame tile start orders of vkv_render_batch (vkv_debug_tile_orders), normally null
 	uint32_t        debug_order_frames, debug_order_count;
-	std::mutex                                 mutex;
+	std::mutex      mutex;
+	VkvTuning       tuning;        // vkv_create: defaults + environment; vkv_set_tuning replaces it (read under the mutex, copied per call)
+	// ---- device arena ----
+	uint8_t *           arena = nullptr;
+	size_t              arena_bytes = 0, arena_used = 0;
+	std::vector<void *> overflow;        // hipMalloc blocks set-up calls took when the arena was full; freed by vkv_destroy
 	std::unordered_map<hipStream_t, uint8_t *> scratch;        // stream -> kScratchBytes of device memory
-	// start orders of tile schedules (centre of the image first), built on first use and kept: immutable device arrays
+	std::vector<uint8_t *>                     free_scratch;   // blocks given back by vkv_release_stream
+	// an immutable device table with its host copy (the source of the asynchronous upload: it must outlive the call)
+	struct Table
+	{
+		std::vector<uint32_t> host;
+		uint32_t *            d = nullptr;
+		hipEvent_t            uploaded = nullptr;        // recorded behind the upload
+		hipStream_t           upload_stream = nullptr;
+		bool                  ready = false;            // the upload is known to have completed: no more waits
+	};
+	// start orders of tile schedules (centre of the image first), built on first use and kept (heap objects: stable addresses)
 	struct TileOrder
 	{
-		uint32_t  tiles_x, tiles_y, tile_w, tile_h, img_w, img_h, first, stride, count;
-		uint32_t *d_order;
+		uint32_t tiles_x, tiles_y, tile_w, tile_h, img_w, img_h, first, stride, count;
+		float    mix_heavy, mix_spread;
+		Table    table;
 	};
-	std::vector<TileOrder> tile_orders;
-	// per-axis address tables of the packed sampling image, per volume extent (immutable device arrays)
+	std::vector<TileOrder *> tile_orders;
+	// per-axis address tables of the packed sampling image, per volume extent
 	struct AddrLut
 	{
-		int       W, H, D;
-		uint32_t  lut_y, lut_z, words;
-		uint32_t *d_lut;
+		int      W, H, D;
+		uint32_t lut_y, lut_z, words;
+		Table    table;
 	};
-	std::vector<AddrLut> addr_luts;
-	// start-order feedback: per render target and tile schedule, the tile costs the last frame into that target left behind and the
-	// buffer its longest-first order is written to (raymarch.hip, apply_feedback); heap objects, so their addresses stay valid
+	std::vector<AddrLut *> addr_luts;
+	// start-order feedback of the targets registered with vkv_register_target: the tile costs the last measured frame into the target left
+	// behind and the buffer its longest-first order is written to (raymarch.hip, apply_feedback); heap objects, so their addresses stay valid
 	struct TileFeedback
 	{
 		const void *target;
@@ -161,7 +183,6 @@ struct vkv_ctx
 		uint32_t    measured_at = 0; // value of `frames` at the last measured frame
 		uint32_t    period = 8;      // frames until the next measurement (doubles while no frame can use the measured order)
 		uint32_t    used = 0;        // frames since the last measurement that started in its order
-		std::vector<uint32_t> identity;        // 0 .. count - 1: what d_order holds until the first sort (kept: source of an asynchronous copy)
 		float       view_dir[3] = {0, 0, 0}, view_pos[3] = {0, 0, 0};        // central ray and camera position (texture space) of the measured frame
 	};
 	std::vector<TileFeedback *> feedback;
@@ -171,16 +192,21 @@ namespace vkv
 {
 int  set_error(vkv_ctx *ctx, int code, const char *fmt, ...);
 int  check_launch(vkv_ctx *ctx, const char *what);
-// this stream's scratch buffer (allocated on first use, freed by vkv_destroy); nullptr + error set when the allocation fails
-uint8_t *stream_scratch(vkv_ctx *ctx, hipStream_t stream);
+// this stream's scratch block (out of the arena on first use, kept until vkv_release_stream / vkv_destroy); nullptr + error set when
+// there is no room
+uint8_t *stream_scratch(vkv_ctx *ctx, hipStream_t stream, bool setup = false);
 // start order of a tile schedule: entry indices sorted by the distance of the tile's centre from the image centre (device array of
 // `count` uint32, cached per schedule shape); nullptr when the table cannot be allocated (the kernel then takes the tiles in order)
 // Per-axis byte offsets of the packed sampling image: the offset of the footprint whose padded base texel is (bx, by, bz) is
 // X(bx) + Y(by) + Z(bz) (the brick index and the position inside the brick are sums of per-axis terms), each in two levels:
 // in-macro-brick term of b & 31 + macro-brick term of b >> 5.  Layout of the device array (uint32 words): in-macro tables of x, y, z
 // at 0, 32, 64; macro terms of x at 96, of y at *lut_y, of z as 64-bit values at *lut_z (even); nullptr if it cannot be allocated.
-const uint32_t *packed_addr_lut(vkv_ctx *ctx, int W, int H, int D, uint32_t *lut_y, uint32_t *lut_z, uint32_t *words);
-const uint32_t *tile_start_order(vkv_ctx *ctx, uint32_t img_w, uint32_t img_h, uint32_t tile_w, uint32_t tile_h, uint32_t first, uint32_t stride, uint32_t count);
+// Both tables come out of the context's arena and are uploaded on `stream` when new (see vkv_ctx); `setup` = called from a set-up entry
+// point: may fall back to hipMalloc when the arena is full.  nullptr when there is no room: the launch then runs without the table.
+const uint32_t *packed_addr_lut(vkv_ctx *ctx, int W, int H, int D, uint32_t *lut_y, uint32_t *lut_z, uint32_t *words, hipStream_t stream, bool setup = false);
+const uint32_t *tile_start_order(vkv_ctx *ctx, uint32_t img_w, uint32_t img_h, uint32_t tile_w, uint32_t tile_h, uint32_t first, uint32_t stride, uint32_t count,
+                                 hipStream_t stream, bool setup = false);
+VkvTuning tuning_of(vkv_ctx *ctx);        // a copy of the context's tuning block (taken under its mutex)
 constexpr size_t kScratchBytes     = 128 * 1024;
 constexpr size_t kTfBitsOffset     = 0;           // 256*256 bits = 8 KiB: TF bit table of the map update / the voxel count
 constexpr size_t kQueueHeadsOffset = 8192;        // 8 x u32 tile-queue heads of the persistent ray-march scheduler

@@ -283,6 +283,7 @@ int main(int argc, char **argv)
 		target.counts         = device_alloc<uint32_t>(n_pixels * 3);
 
 		const int frames = benchmark ? args.benchmark : 1;
+		subpass.prepare_targets({target});
 		subpass.draw(target);        // warm-up (and the frame the dumps below read)
 		(void) hipStreamSynchronize(stream);
 		{
@@ -314,6 +315,20 @@ int main(int argc, char **argv)
 				for (int i = 0; i < fif; ++i)
 					ltargets[s][i].rgba8 = device_alloc<uint8_t>(n_pixels * 4);
 			}
+			// set-up: tables, scratch and feedback state of every (stream, target) pair, so that the timed loop only enqueues
+			if (batched)
+				for (int s = 0; s < kLaunchStreams; ++s)
+				{
+					dc.stream = lstreams[s];
+					subpass.prepare_targets(ltargets[s]);
+				}
+			else
+				for (int i = 0; i < fif; ++i)
+				{
+					dc.stream = streams[i];
+					subpass.prepare_targets({targets[i]});
+				}
+			dc.stream     = stream;
 			const auto t0 = std::chrono::steady_clock::now();
 			if (batched)
 			{
@@ -340,13 +355,17 @@ int main(int argc, char **argv)
 			std::printf("ran %d frames, averaged %g fps\n", frames, 1000.0 * frames / ms);
 			for (int i = 1; i < fif; ++i)
 			{
+				subpass.forget_targets({targets[i]});
 				(void) hipFree(targets[i].rgba8);
+				(void) vkv_release_stream(ctx, streams[i]);        // all its work has completed (synchronised above)
 				(void) hipStreamDestroy(streams[i]);
 			}
 			for (int s = 1; batched && s < kLaunchStreams; ++s)
 			{
+				subpass.forget_targets(ltargets[s]);
 				for (int i = 0; i < fif; ++i)
 					(void) hipFree(ltargets[s][i].rgba8);
+				(void) vkv_release_stream(ctx, lstreams[s]);
 				(void) hipStreamDestroy(lstreams[s]);
 			}
 		}
@@ -367,6 +386,7 @@ int main(int argc, char **argv)
 			dump(args.dump_rgba8, target.rgba8, n_pixels * 4, stream);
 		if (!args.dump_counts.empty())
 			dump(args.dump_counts, target.counts, n_pixels * 3, stream);
+		subpass.forget_targets({target});
 		(void) hipFree(target.rgba8);
 		(void) hipFree(target.counts);
 		(void) hipStreamDestroy(stream);

@@ -47,6 +47,31 @@ VkvRenderParams VolumeRenderSubpass::make_params(Volume &volume, const RenderTar
 	return p;
 }
 
+void VolumeRenderSubpass::prepare_targets(const std::vector<RenderTarget> &targets, const VkvTileSchedule *tiles)
+{
+	for (const RenderTarget &t : targets)
+	{
+		for (Volume *volume : volumes)
+		{
+			if (!volume->get_packed_volume())
+				volume->pack(dc);
+			const VkvRenderParams p = make_params(*volume, t, tiles, false);
+			if (vkv_prepare_render(dc.ctx, &p, 1, dc.stream) != VKV_OK)
+				throw std::runtime_error(std::string("VolumeRenderSubpass::prepare_targets: ") + vkv_last_error(dc.ctx));
+			const void *id = p.d_out_rgba8 ? (const void *) p.d_out_rgba8 : (const void *) p.d_out_color;
+			if (id && vkv_register_target(dc.ctx, id, p.image_width, p.image_height, &p.tiles) != VKV_OK)
+				throw std::runtime_error(std::string("VolumeRenderSubpass::prepare_targets: ") + vkv_last_error(dc.ctx));
+		}
+	}
+}
+
+void VolumeRenderSubpass::forget_targets(const std::vector<RenderTarget> &targets)
+{
+	for (const RenderTarget &t : targets)
+		if (const void *id = t.rgba8 ? (const void *) t.rgba8 : (const void *) t.color)
+			(void) vkv_forget_target(dc.ctx, id);
+}
+
 void VolumeRenderSubpass::draw(const RenderTarget &target, const VkvTileSchedule *tiles)
 {
 	bool blend = target.blend;

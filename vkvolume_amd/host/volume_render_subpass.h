@@ -62,6 +62,12 @@ class VolumeRenderSubpass
 
 	void prepare();        // nothing to pre-build: kernel variants are compiled ahead of time
 
+	// Set-up for the targets this subpass will draw into on the context's current stream (the counterpart of the reference building its
+	// per-swap-chain-image resources, src/volume_render_subpass.cpp:95-157): vkv_prepare_render + vkv_register_target, so that draw() /
+	// draw_batch() afterwards only enqueue (no allocation, no wait).  forget_targets() before the buffers are freed.
+	void prepare_targets(const std::vector<RenderTarget> &targets, const VkvTileSchedule *tiles = nullptr);
+	void forget_targets(const std::vector<RenderTarget> &targets);
+
 	// src/volume_render_subpass.cpp:159-294: per volume, build the uniforms and march.  `tiles` selects the screen tiles of
 	// this launch (null = the whole frame).
 	void draw(const RenderTarget &target, const VkvTileSchedule *tiles = nullptr);

@@ -18,7 +18,11 @@ EXPORTS = [
     "vkv_compute_distance_map", "vkv_render", "vkv_render_batch", "vkv_scatter_tiles", "vkv_synth_volume",
     "vkv_packed_volume_bytes", "vkv_pack_volume", "vkv_transfer_function_bits", "vkv_transfer_function_tables",
     "vkv_occupied_voxel_count", "vkv_load_header", "vkv_load_data", "vkv_convert_volume", "vkv_gather_tiles", "vkv_assemble_frame",
+    "vkv_assemble_frames", "vkv_get_tuning", "vkv_set_tuning", "vkv_prepare_render", "vkv_register_target", "vkv_forget_target",
+    "vkv_release_stream",
 ]
+# include/vkvolume_amd_debug.h (diagnostics: tools/ and the exhaustive numerics tests)
+DEBUG_EXPORTS = ["vkv_debug_trace", "vkv_debug_tile_orders", "vkv_debug_check"]
 
 
 class VkvError(RuntimeError):
@@ -65,6 +69,16 @@ def load():
     L.vkv_gather_tiles.argtypes = [vp, vp, vp, C.c_size_t, i32, vp, vp]
     L.vkv_assemble_frame.argtypes = [vp, vp, vp, vp] + [C.c_uint32] * 8 + [i32, vp, vp]
     L.vkv_scatter_tiles.argtypes = [vp, vp, vp, u32, u32, u32, u32, u32, u32, u32, vp]
+    L.vkv_assemble_frames.argtypes = [vp, vp, vp, P(vp)] + [u32] * 9 + [i32, vp, vp]
+    L.vkv_get_tuning.argtypes = [vp, P(abi.Tuning)]
+    L.vkv_set_tuning.argtypes = [vp, P(abi.Tuning)]
+    L.vkv_prepare_render.argtypes = [vp, P(abi.RenderParams), u32, vp]
+    L.vkv_register_target.argtypes = [vp, vp, u32, u32, P(abi.TileSchedule)]
+    L.vkv_forget_target.argtypes = [vp, vp]
+    L.vkv_release_stream.argtypes = [vp, vp]
+    L.vkv_debug_trace.argtypes = [vp, vp]
+    L.vkv_debug_tile_orders.argtypes = [vp, vp, u32, u32]
+    L.vkv_debug_check.argtypes = [vp, i32, u32, C.c_uint64, vp, vp]
     L.vkv_synth_volume.argtypes = [vp, vp, abi.Extent3D, u32, u32, vp]
     L.vkv_packed_volume_bytes.argtypes = [abi.Extent3D]
     L.vkv_packed_volume_bytes.restype = C.c_size_t
@@ -75,8 +89,8 @@ def load():
     L.vkv_convert_volume.argtypes = [vp, vp, i32, i32, C.c_float, C.c_float, C.c_uint64, vp, vp]
     L.vkv_load_header.argtypes = [C.c_char_p, P(abi.VolumeHeader)]
     L.vkv_load_data.argtypes = [C.c_char_p, P(abi.VolumeHeader), vp, C.c_size_t]
-    for name in EXPORTS:
-        getattr(L, name)  # AttributeError here means the library does not export what the header declares
+    for name in EXPORTS + DEBUG_EXPORTS:
+        getattr(L, name)  # AttributeError here means the library does not export what the headers declare
     _LIB = L
     return L
 
@@ -144,6 +158,43 @@ class Context:
         """vkv_assemble_frame: ncclGather of the compact tile buffers to `root` + de-interleave there, on `stream`."""
         self.check(self._lib.vkv_assemble_frame(self.handle, d_tiles, d_gathered, d_image, image_size[0], image_size[1], tile_size[0], tile_size[1],
                                                 n_ranks, rank, tiles_per_rank, bytes_per_pixel, root, nccl_comm, stream))
+
+    def assemble_frames(self, d_tiles, d_gathered, d_images, n_frames, image_size, tile_size, n_ranks, rank, tiles_per_rank, bytes_per_pixel, root,
+                        nccl_comm, stream=0):
+        """vkv_assemble_frames: ONE ncclGather for the [frame][tiles] block of a whole launch + one de-interleave kernel on the root
+        (d_images: the root's n_frames image pointers; None elsewhere)."""
+        arr = (C.c_void_p * n_frames)(*d_images) if d_images is not None else None
+        self.check(self._lib.vkv_assemble_frames(self.handle, d_tiles, d_gathered, arr, n_frames, image_size[0], image_size[1], tile_size[0], tile_size[1],
+                                                 n_ranks, rank, tiles_per_rank, bytes_per_pixel, root, nccl_comm, stream))
+
+    # ---- set-up calls ----
+    def get_tuning(self):
+        t = abi.Tuning()
+        self.check(self._lib.vkv_get_tuning(self.handle, C.byref(t)))
+        return t
+
+    def set_tuning(self, **fields):
+        """read-modify-write of the context's VkvTuning block: ctx.set_tuning(scheduler=1)"""
+        t = self.get_tuning()
+        for k, v in fields.items():
+            if not hasattr(t, k):
+                raise AttributeError("VkvTuning has no field %r" % k)
+            setattr(t, k, v)
+        self.check(self._lib.vkv_set_tuning(self.handle, C.byref(t)))
+        return t
+
+    def prepare_render(self, params_list, stream=0):
+        arr = (abi.RenderParams * len(params_list))(*params_list)
+        self.check(self._lib.vkv_prepare_render(self.handle, arr, len(params_list), stream))
+
+    def register_target(self, d_target, image_size, tiles):
+        self.check(self._lib.vkv_register_target(self.handle, d_target, image_size[0], image_size[1], C.byref(tiles)))
+
+    def forget_target(self, d_target):
+        self.check(self._lib.vkv_forget_target(self.handle, d_target))
+
+    def release_stream(self, stream):
+        self.check(self._lib.vkv_release_stream(self.handle, stream))
 
     def render_rc(self, params, stream=0):
         """Like render() but returns the status code instead of raising (error-path tests)."""

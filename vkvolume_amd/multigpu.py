@@ -182,6 +182,35 @@ class NativeExchange:
             self._comm = None
 
 
+class NativeBatchExchange(NativeExchange):
+    """The exchange of a whole vkv_render_batch launch through the C ABI: ``vkv_assemble_frames`` = ONE ``ncclGather`` of the launch's
+    [frame][tiles] block to the launch's owner + ONE de-interleave kernel there, enqueued on a HIP stream; the same launches and the
+    same buffer sets as BatchTileGather, without torch.distributed on the data path."""
+
+    def __init__(self, ctx, dist, rank, world, frame_size, tile=16, bytes_per_pixel=4, frames=8, n_sets=2, any_root=False, rccl_path=None):
+        import torch
+        super().__init__(ctx, dist, rank, world, frame_size, tile, bytes_per_pixel, n_buffers=0, any_root=any_root, rccl_path=rccl_path)
+        fw, fh = frame_size
+        n = self.tiles_per_rank * tile * tile
+        self.frames = frames
+        self.sets = [torch.zeros((frames, n, bytes_per_pixel), dtype=torch.uint8, device="cuda") for _ in range(n_sets)]
+        self.buffers = [s[j] for s in self.sets for j in range(frames)]  # buffer of frame j of set b: buffers[b * frames + j]
+        own = rank == 0 or any_root
+        self.flat = [torch.zeros((world, frames, n, bytes_per_pixel), dtype=torch.uint8, device="cuda") for _ in range(n_sets)] if own else None
+        self.images = [torch.zeros((fh, fw, bytes_per_pixel), dtype=torch.uint8, device="cuda") for _ in range(n_sets * frames)] if own else None
+
+    def assemble(self, b, root, n_frames, stream):
+        """enqueue the exchange of the first n_frames frames of buffer set b on `stream` (a torch stream): the images of the launch land
+        in images[b * frames + j] on `root`.  Every rank passes the same root and count."""
+        if root != 0 and not self.any_root:
+            raise ValueError("NativeBatchExchange was created for rank 0 as the only frame owner")
+        is_root = self.rank == root
+        imgs = [self.images[b * self.frames + j].data_ptr() for j in range(n_frames)] if is_root else None
+        self.ctx.assemble_frames(self.sets[b].data_ptr(), self.flat[b].data_ptr() if is_root else None, imgs, n_frames, self.frame_size,
+                                 (self.tile, self.tile), self.world, self.rank, self.tiles_per_rank, self.bpp, root, self._comm.value, stream.cuda_stream)
+        return stream
+
+
 def deinterleave_reference(flat, frame_size, tile, world):
     """numpy statement of vkv_scatter_tiles (tests only): flat[rank, k*tile*tile + ly*tile + lx, c] -> image[y, x, c]."""
     fw, fh = frame_size
