@@ -147,7 +147,9 @@ def sparse_occupancy(shape_dhw, seed, p):
                                          # 16 | width and 128 < axis <= 256: the 16-byte vector staging of the y / z passes
                                          ((200, 130, 32), 0.0002), ((3, 140, 48), 0.002), ((131, 2, 16), 0.004),
                                          # 8 | width and 256 < axis <= 512: whole-line table with 8-byte vectors
-                                         ((2, 300, 24), 0.001), ((400, 3, 8), 0.001)])
+                                         ((2, 300, 24), 0.001), ((400, 3, 8), 0.001),
+                                         # the wave-per-row x pass: 8 and 16 cells per lane, dword and byte rows, a last lane that is partly / wholly past the row
+                                         ((3, 4, 260), 0.003), ((2, 3, 700), 0.002), ((2, 2, 1023), 0.002), ((4, 3, 512), 0.001), ((2, 5, 61), 0.01), ((3, 2, 1021), 0.0004)])
 def test_distance_map_parity(ctx, shape_dhw, p):
     occ = sparse_occupancy(shape_dhw, 3, p)
     d, h, w = shape_dhw
@@ -159,11 +161,34 @@ def test_distance_map_parity(ctx, shape_dhw, p):
         assert np.array_equal(got, T.brute_force_chebyshev(occ))
 
 
+@pytest.mark.parametrize("shape_dhw", [(6, 7, 50), (3, 5, 260), (2, 3, 1000), (2, 2, 1300), (20, 24, 32), (3, 70, 13)])
+def test_distance_transforms_on_arbitrary_bytes(ctx, shape_dhw):
+    """Stage 0 of both shaders is the recurrence g = min(g_prev + 1, input) (distance_map.comp:57-71, distance_map_anisotropic.comp:44-53),
+    stages 1 / 2 the max-based search - all defined for ANY byte input, not only a 0 / 255 occupancy map.  The kernels follow them there
+    too (the x pass as x + running minimum of g(q) - q): random bytes with a few small values, both transforms against the oracle."""
+    rng = np.random.default_rng(sum(shape_dhw))
+    raw = rng.integers(0, 256, size=shape_dhw, dtype=np.uint8)
+    raw[rng.random(shape_dhw) < 0.7] = 255
+    raw[rng.random(shape_dhw) < 0.01] = 0
+    d, h, w = shape_dhw
+    st = torch.cuda.current_stream().cuda_stream
+    d_map, d_swap = dev(raw), torch.empty(shape_dhw, dtype=torch.uint8, device="cuda")
+    ctx.distance_map(d_map.data_ptr(), d_swap.data_ptr(), abi.Extent3D(w, h, d), st)
+    assert np.array_equal(d_map.cpu().numpy(), O.distance_map(raw))
+    maps = [torch.empty(shape_dhw, dtype=torch.uint8, device="cuda") for _ in range(8)]
+    maps[7].copy_(dev(raw))
+    ctx.distance_map_anisotropic([m.data_ptr() for m in maps], d_swap.data_ptr(), abi.Extent3D(w, h, d), st)
+    expect = O.distance_map_anisotropic(raw)
+    for k in range(8):
+        assert np.array_equal(maps[k].cpu().numpy(), expect[k]), "octant %d" % k
+
+
 @pytest.mark.parametrize("shape_dhw,p", [((16, 16, 16), 0.02), ((9, 10, 13), 0.01), ((5, 70, 3), 0.01), ((40, 33, 130), 0.0005),
                                          ((1, 1, 1), 1.0), ((6, 6, 6), 0.0), ((600, 2, 3), 0.0006), ((2, 700, 1), 0.0015), ((90, 280, 70), 0.00002),
                                          ((2, 3, 1100), 0.002), ((2, 1500, 3), 0.001), ((1300, 2, 17), 0.0004), ((30, 130, 33), 0.001),
                                          ((3, 5, 1024), 0.0008), ((2, 2, 257), 0.004),
-                                         ((200, 130, 32), 0.0002), ((3, 140, 48), 0.002), ((131, 2, 16), 0.004), ((2, 300, 24), 0.001), ((400, 3, 8), 0.001)])
+                                         ((200, 130, 32), 0.0002), ((3, 140, 48), 0.002), ((131, 2, 16), 0.004), ((2, 300, 24), 0.001), ((400, 3, 8), 0.001),
+                                         ((3, 4, 260), 0.003), ((2, 3, 700), 0.002), ((2, 2, 1023), 0.002), ((4, 3, 512), 0.001), ((2, 5, 61), 0.01)])
 def test_distance_map_anisotropic_parity(ctx, shape_dhw, p):
     occ = sparse_occupancy(shape_dhw, 4, p)
     d, h, w = shape_dhw

@@ -261,3 +261,21 @@ def test_c1_sphere_256_plumbing():
     assert np.abs(a - a[:, ::-1]).max() < 0.1 and np.abs(a - a[::-1, :]).max() < 0.1
     assert ((a > 0) != (a[:, ::-1] > 0)).mean() < 2e-3
     assert (r.counts[..., 1] == 0).all() and r.counts[..., 0].max() <= 111  # n_steps_max = ceil(64 * sqrt(3))
+
+
+def test_x_stage_recurrence_has_the_min_plus_closed_form():
+    """Stage 0 of the distance transforms, g = min(g_prev + 1, input) forward and backward (distance_map.comp:57-71), equals
+    out(x) = min over q of (input(q) + |x - q|) for ANY byte input - the closed form the wave-per-row x pass of the HIP build evaluates.
+    Checked on a map of depth and height 1, where stages 1 and 2 are the identity."""
+    rng = np.random.default_rng(17)
+    for w in (1, 2, 7, 64, 300):
+        raw = rng.integers(0, 256, size=(1, 1, w), dtype=np.uint8)
+        raw[rng.random(raw.shape) < 0.5] = 255
+        got = O.distance_map(raw)[0, 0].astype(np.int64)
+        x = np.arange(w)
+        want = (raw[0, 0].astype(np.int64)[None, :] + np.abs(x[:, None] - x[None, :])).min(axis=1)
+        assert np.array_equal(got, want)
+        aniso = O.distance_map_anisotropic(raw)
+        up = np.where(x[None, :] >= x[:, None], raw[0, 0].astype(np.int64)[None, :] + (x[None, :] - x[:, None]), 1 << 30).min(axis=1)
+        dn = np.where(x[None, :] <= x[:, None], raw[0, 0].astype(np.int64)[None, :] + (x[:, None] - x[None, :]), 1 << 30).min(axis=1)
+        assert np.array_equal(aniso[0][0, 0], up) and np.array_equal(aniso[4][0, 0], dn)  # octant bit 4 = dx < 0

@@ -575,6 +575,122 @@ __global__ void __launch_bounds__(64) k_dm_x(const uint8_t *src, uint8_t *dst, i
 	}
 }
 
+// x pass for rows of up to 1024 cells: one WAVE per row, the row in registers (C cells per lane).
+// Stage 0 of both shaders is the min-plus recurrence g = min(g_prev + 1, occ) (distance_map.comp:57-71 forward and backward in place,
+// distance_map_anisotropic.comp:44-53 one-sided), whose closed form is
+//     out(x) = min over q of (g(q) + |x - q|)            (one-sided: q >= x for dir > 0, q <= x for dir < 0),
+// i.e. x + the running minimum of g(q) - q from the left, and the running minimum of g(q) + q from the right minus x: two scans - inside
+// the lane over its C cells, across the lanes with six shuffle steps.  Exact for ANY byte input (not only 0 / 255 occupancy), like the
+// recurrence.  Reads the whole row before it writes: dst may alias src.  MODE 0: two-sided -> dst; +1 / -1: one-sided -> dst;
+// 2: dst = +1 result, dst2 = -1 result.  VEC: rows are dword-aligned (mw % 4 == 0, aligned pointers).
+template <int MODE, int C, bool VEC>
+__global__ void __launch_bounds__(256) k_dm_x_wave(const uint8_t *src, uint8_t *dst, uint8_t *dst2, int mw, uint32_t n_rows)
+{
+	// a wave takes kRows consecutive rows and has the loads of all of them in flight before it scans the first (one row is 256 bytes to 1 KB:
+	// with one row per wave a CU keeps 8 KB in flight and the pass runs at 1.4 TB/s)
+	constexpr int  kRows = C <= 8 ? 4 : 2;
+	const uint32_t row0  = (blockIdx.x * 4u + (threadIdx.x >> 6)) * kRows;
+	if (row0 >= n_rows)
+		return;        // wave-uniform
+	const int     lane = (int) (threadIdx.x & 63u), x0 = lane * C;
+	constexpr int kFar = 1 << 20;        // padding cells past the end of the row: never the minimum
+	uint32_t      raw[kRows][C / 4];
+	uint8_t       rawb[VEC ? 1 : kRows][VEC ? 1 : C];
+#pragma unroll
+	for (int r = 0; r < kRows; ++r)
+	{
+		const size_t ro = (size_t) min(row0 + (uint32_t) r, n_rows - 1u) * (size_t) mw;        // (rows past the end: the last row again, not stored)
+		if (VEC)
+		{
+#pragma unroll
+			for (int j = 0; j < C / 4; ++j)
+				raw[r][j] = x0 + 4 * j < mw ? *reinterpret_cast<const uint32_t *>(src + ro + x0 + 4 * j) : 0u;
+		}
+		else
+		{
+#pragma unroll
+			for (int i = 0; i < C; ++i)
+				rawb[VEC ? 0 : r][VEC ? 0 : i] = x0 + i < mw ? src[ro + x0 + i] : (uint8_t) 0;
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < kRows; ++r)
+	{
+		if (row0 + (uint32_t) r >= n_rows)
+			break;        // wave-uniform
+		const size_t ro = (size_t) (row0 + (uint32_t) r) * (size_t) mw;
+		int          g[C];
+#pragma unroll
+		for (int i = 0; i < C; ++i)
+		{
+			const int v = VEC ? (int) ((raw[r][i / 4] >> (8 * (i & 3))) & 255u) : (int) rawb[VEC ? 0 : r][VEC ? 0 : i];
+			g[i]        = x0 + i < mw ? v : kFar;
+		}
+		// running minimum of g(q) - q over q <= x (left candidates) and of g(q) + q over q >= x (right candidates), inside the lane
+		int pre[C], suf[C];
+		{
+			int m = 2 * kFar;
+#pragma unroll
+			for (int i = 0; i < C; ++i)
+				m = min(m, g[i] - (x0 + i)), pre[i] = m;
+			m = 2 * kFar;
+#pragma unroll
+			for (int i = C - 1; i >= 0; --i)
+				m = min(m, g[i] + (x0 + i)), suf[i] = m;
+		}
+		// exclusive scans over the lanes: `left` = minimum over all lower lanes, `right` = over all higher lanes
+		int left = pre[C - 1], right = suf[0];
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1)
+		{
+			const int l = __shfl_up(left, o), rr = __shfl_down(right, o);
+			left = lane >= o ? min(left, l) : left, right = lane + o < 64 ? min(right, rr) : right;
+		}
+		left = __shfl_up(left, 1), right = __shfl_down(right, 1);
+		if (lane == 0)
+			left = 2 * kFar;
+		if (lane == 63)
+			right = 2 * kFar;
+		uint32_t wa[C / 4], wb[C / 4];
+#pragma unroll
+		for (int j = 0; j < C / 4; ++j)
+		{
+			wa[j] = 0, wb[j] = 0;
+#pragma unroll
+			for (int b = 0; b < 4; ++b)
+			{
+				const int i = 4 * j + b, x = x0 + i;
+				const int L = min(left, pre[i]) + x, R = min(right, suf[i]) - x;        // both <= g[i] <= 255 for cells of the row
+				const int a = MODE == 0 ? min(L, R) : (MODE == -1 ? L : R);
+				wa[j] |= (uint32_t) (a & 255) << (8 * b);
+				wb[j] |= (uint32_t) (L & 255) << (8 * b);
+			}
+		}
+		if (VEC)
+		{
+#pragma unroll
+			for (int j = 0; j < C / 4; ++j)
+				if (x0 + 4 * j < mw)
+				{
+					*reinterpret_cast<uint32_t *>(dst + ro + x0 + 4 * j) = wa[j];
+					if (MODE == 2)
+						*reinterpret_cast<uint32_t *>(dst2 + ro + x0 + 4 * j) = wb[j];
+				}
+		}
+		else
+		{
+#pragma unroll
+			for (int i = 0; i < C; ++i)
+				if (x0 + i < mw)
+				{
+					dst[ro + x0 + i] = (uint8_t) (wa[i / 4] >> (8 * (i & 3)));
+					if (MODE == 2)
+						dst2[ro + x0 + i] = (uint8_t) (wb[i / 4] >> (8 * (i & 3)));
+				}
+		}
+	}
+}
+
 // ---------------------------------------------------------------------------------------------
 // Packed sampling layout (see vkv_device.hpp): one 128-thread half-block per brick, thread = one of the 5^3 texels
 // ---------------------------------------------------------------------------------------------
@@ -668,7 +784,7 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 	// vector in memory and in the LDS layout - one load / store instruction moves what 16 / 4 byte-wide ones would
 	if (vec && !XAXIS)
 	{
-		using vec_t = typename std::conditional<XT == 16, uint4, uint2>::type;        // the XT lines of one cell row
+		using vec_t = typename std::conditional<XT == 16, uint4, typename std::conditional<XT == 8, uint2, uint32_t>::type>::type;        // the XT lines of one cell row
 		for (int p = t; p < n; p += 256)
 			*reinterpret_cast<vec_t *>(s_t + p * XT) = *reinterpret_cast<const vec_t *>(src + base + (size_t) p * axis_stride);
 	}
@@ -827,7 +943,7 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 	__syncthreads();
 	if (vec && !XAXIS)
 	{
-		using vec_t = typename std::conditional<XT == 16, uint4, uint2>::type;
+		using vec_t = typename std::conditional<XT == 16, uint4, typename std::conditional<XT == 8, uint2, uint32_t>::type>::type;
 		for (int p = out0 - seg0 + t; p < out1 - seg0; p += 256)
 		{
 			const size_t o = base + (size_t) p * axis_stride;
@@ -1284,7 +1400,7 @@ static int launch_dm_x(vkv_ctx *ctx, const uint8_t *src, uint8_t *dst, VkvExtent
 }
 
 // axis: 0 = x, 1 = y, 2 = z.  MODE 2 writes the +1 result to dst and the -1 result to dst2.  The x pass may run in place
-// (a workgroup stages whole rows before it writes); rows longer than 1024 cells go to k_dm_x.
+// (a wave holds its whole row before it writes); rows longer than 1024 cells go to k_dm_x.
 template <int MODE>
 static int launch_dm_rmq(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *dst, uint8_t *dst2, VkvExtent3D me, hipStream_t s)
 {
@@ -1292,8 +1408,32 @@ static int launch_dm_rmq(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *ds
 	const int      len     = axis == 0 ? (int) me.width : axis == 1 ? (int) me.height : (int) me.depth;
 	const uint32_t other   = axis == 0 ? 1u : axis == 1 ? me.depth : me.height;
 	const uint32_t n_lines = axis == 0 ? me.height * me.depth : me.width;
-	const size_t   ls = axis == 0 ? sy : 1, as = axis == 0 ? 1 : axis == 1 ? sy : sz, os = axis == 1 ? sz : sy;
-#define VKV_DM_RMQ(XT, SEG, XAXIS)                                                                                                                     \
+	const size_t   as = axis == 0 ? 1 : axis == 1 ? sy : sz, os = axis == 1 ? sz : sy;
+	if (axis == 0)
+	{        // rows of up to 1024 cells: one wave per row, in registers (k_dm_x_wave); longer rows never get here (launch_dm_x)
+		const uint32_t n_rows = me.height * me.depth;
+		const bool     vec    = (me.width & 3u) == 0 && ((((uintptr_t) src) | ((uintptr_t) dst) | ((uintptr_t) dst2)) & 3u) == 0;
+#define VKV_DM_XW(C)                                                                                                                            \
+	do                                                                                                                                          \
+	{                                                                                                                                           \
+		const uint32_t rows_per_wg = 4u * ((C) <= 8 ? 4u : 2u); /* kRows of the kernel */                                                       \
+		const dim3     grid((n_rows + rows_per_wg - 1u) / rows_per_wg);                                                                         \
+		if (vec)                                                                                                                                \
+			hipLaunchKernelGGL((k_dm_x_wave<MODE, C, true>), grid, dim3(256), 0, s, src, dst, dst2, len, n_rows);                                \
+		else                                                                                                                                    \
+			hipLaunchKernelGGL((k_dm_x_wave<MODE, C, false>), grid, dim3(256), 0, s, src, dst, dst2, len, n_rows);                               \
+	} while (0)
+		if (len <= 256)
+			VKV_DM_XW(4);
+		else if (len <= 512)
+			VKV_DM_XW(8);
+		else
+			VKV_DM_XW(16);
+#undef VKV_DM_XW
+		return check_launch(ctx, "distance_map x pass");
+	}
+	const size_t ls = 1;
+#define VKV_DM_RMQ(XT, SEG)                                                                                                                            \
 	do                                                                                                                                                  \
 	{                                                                                                                                                   \
 		const int      ch       = len <= (SEG) ? len : (SEG) -510;                                                                                     \
@@ -1301,26 +1441,20 @@ static int launch_dm_rmq(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *ds
 		if ((uint64_t) chunks_x * chunks_p * other > 0x7fffffffull)                                                                                     \
 			return set_error(ctx, VKV_E_UNSUPPORTED, "distance_map: map too large for one launch");                                                     \
 		const uintptr_t al = (uintptr_t) src | (uintptr_t) dst | (uintptr_t) dst2;                                                                      \
-		const int vec = (XAXIS) ? (chunks_p == 1 && (me.width & 3u) == 0 && (al & 3u) == 0)                                                             \
-		                        : (((XT) == 16 || (XT) == 8) && (me.width & ((XT) -1)) == 0 && (al & ((XT) -1)) == 0);                                   \
-		hipLaunchKernelGGL((k_dm_rmq<MODE, XT, SEG, XAXIS>), dim3(chunks_x * chunks_p * other), dim3(256), 0, s, src, dst, dst2, n_lines, len, ls, as,  \
+		const int vec = (me.width & ((XT) -1)) == 0 && (al & ((XT) -1)) == 0;                                                                           \
+		hipLaunchKernelGGL((k_dm_rmq<MODE, XT, SEG, false>), dim3(chunks_x * chunks_p * other), dim3(256), 0, s, src, dst, dst2, n_lines, len, ls, as,  \
 		                   os, chunks_x, chunks_p, ch, vec);                                                                                            \
 	} while (0)
-	if (axis == 0)
-	{
-		if (len <= 256)
-			VKV_DM_RMQ(16, 256, true);
-		else
-			VKV_DM_RMQ(4, 1024, true);
-	}
-	else if (len <= 128 && me.width > 16)
-		VKV_DM_RMQ(32, 128, false);
-	else if (len <= 256)
-		VKV_DM_RMQ(16, 256, false);
+	// (measured and dropped: resident workgroups marching over several tiles with the next tile's cells prefetched into registers - 38 -> 44 us
+	// per pass on C3; the CU already overlaps one workgroup's loads with the others' table building)
+	if (len <= 128 && me.width > 16)
+		VKV_DM_RMQ(16, 128);
+	else if (len <= 256)        // 8 lines per workgroup: 20 KB of LDS instead of 40 (8 workgroups per CU, not 4) and runs of 8 cells per thread:
+		VKV_DM_RMQ(8, 256);        // C3 42.6 -> 36.8 us per isotropic pass, 63 -> 47 us per anisotropic pass
 	else if (len <= 512)
-		VKV_DM_RMQ(8, 512, false);        // whole line, no halo
+		VKV_DM_RMQ(8, 512);        // whole line, no halo
 	else
-		VKV_DM_RMQ(8, 768, false);
+		VKV_DM_RMQ(8, 768);
 #undef VKV_DM_RMQ
 	return check_launch(ctx, "distance_map axis pass");
 }
