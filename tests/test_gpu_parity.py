@@ -81,6 +81,21 @@ def test_gradient_kernel_shortcuts_are_exact(ctx):
     assert bad.tolist() == [0, 0]
 
 
+def test_ray_setup_divisions_are_correctly_rounded(ctx):
+    """The ray set-up's divisions run through v_rcp_f32 + the refinement the compiler's own IEEE division uses, shared between the quotients
+    of one denominator and without range scaling / special-case fix-up (vkv_device.hpp: recip_exact, div_by).  Checked on the device
+    against the IEEE division for EVERY float as the denominator: (2) all reciprocals, (3) quotients with eight hashed numerators per
+    denominator.  Operands outside [2^-40, 2^40] never reach these functions (ray_setup sends such waves down the IEEE path:
+    the axis-parallel and degenerate-camera cases of test_render_parity_* cover that branch)."""
+    L = ctx._lib
+    bad = torch.zeros(2, dtype=torch.int64, device="cuda")
+    for what in (2, 3):
+        for first in (0, 0x80000000):  # positive and negative patterns, each 2^31 of them
+            ctx.check(L.vkv_debug_check(ctx.handle, what, first, 1 << 31, bad.data_ptr() + 8 * (what - 2), None))
+    torch.cuda.synchronize()
+    assert bad.tolist() == [0, 0]
+
+
 @pytest.mark.parametrize("shape,segment", [((260, 40, 50), 3), ((192, 24, 67), 2), ((132, 9, 33), 10), ((64, 8, 80), 4), ((200, 17, 26), 255)])
 def test_gradient_map_marching_workgroups(ctx, shape, segment):
     """The tiled kernel's workgroups march over `segment` tiles in z with the next tile prefetched; volumes this small run one tile per

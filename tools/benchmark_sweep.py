@@ -7,9 +7,16 @@ MI355X results sit next to scripts/benchmark_results_{0..3}.csv.  It drives `vkv
 the same three log lines the reference harness parses.
 
 The reference's scans (present / stag beetle / kingsnake) are not published, so each preset uses a synthetic uint8
-volume of the same extent (`--synthetic`); pass --assets DIR to use real `<name>` + `<name>.header` files instead.
+volume of the same extent (`--synthetic`) and the `image` column says so: `synthetic_<W>x<H>x<D>` - ellipsoid shells with
+2 - 10 x the occupied-voxel share of the scans, NOT comparable row by row with the reference's CSVs.  Pass --assets DIR to use
+real `<name>` + `<name>.header` files instead (the `image` column then carries the file name).
 
-    python tools/benchmark_sweep.py --out profiles/ [--frames 100] [--quick]
+`--frames-in-flight N` (default 8): vkv_offscreen renders N frames per vkv_render_batch launch (the reference's swap-chain images in
+flight), so `framerate` is batch throughput; `--frames-in-flight 1` is the frame-serial figure (one launch per frame, each waiting for
+the one before: what the reference's benchmark loop measures).  The value is written to the `frames_in_flight` column and to the file
+name (`..._fif<N>.csv`).
+
+    python tools/benchmark_sweep.py --out profiles/ [--frames 100] [--quick] [--frames-in-flight 1]
 """
 import argparse
 import csv
@@ -33,10 +40,19 @@ PRESETS = [
 ]
 
 
-def run(preset, blocksize, skipmode, frames, assets):
+def image_label(preset, assets):
+    """what the `image` column says: the scan's file name only when the real file was rendered"""
+    name, extent = preset[0], preset[1]
+    if assets and os.path.exists(os.path.join(assets, name)):
+        return name
+    return "synthetic_%dx%dx%d" % extent
+
+
+def run(preset, blocksize, skipmode, frames, assets, frames_in_flight):
     name, extent, imin, imax, gmin, gmax = preset
     cmd = [APP, "--width=%d" % WIDTH, "--height=%d" % HEIGHT, "--benchmark=%d" % frames, "--imin=%g" % imin, "--imax=%g" % imax,
-           "--gmin=%g" % gmin, "--gmax=%g" % gmax, "--blocksize=%d" % blocksize, "--skipmode=%d" % skipmode]
+           "--gmin=%g" % gmin, "--gmax=%g" % gmax, "--blocksize=%d" % blocksize, "--skipmode=%d" % skipmode,
+           "--frames-in-flight=%d" % frames_in_flight]
     if assets and os.path.exists(os.path.join(assets, name)):
         cmd.append(os.path.join(assets, name))
     else:
@@ -56,6 +72,7 @@ def main():
     ap.add_argument("--frames", type=int, default=100)
     ap.add_argument("--assets", default=None)
     ap.add_argument("--quick", action="store_true", help="block sizes 2 and 4 only, first and last preset")
+    ap.add_argument("--frames-in-flight", type=int, default=8, help="frames per vkv_render_batch launch (1 = frame-serial, like the reference's loop)")
     args = ap.parse_args()
     presets = [PRESETS[0], PRESETS[-1]] if args.quick else PRESETS
     block_sizes = [2, 4] if args.quick else [2, 3, 4, 5, 6]
@@ -66,13 +83,14 @@ def main():
                 if skipmode == 0 and b != block_sizes[0]:
                     rows.append(dict(rows[-1], blocksize=b))  # the reference repeats the mode-0 row (benchmark.py:71)
                     continue
-                fps, upd, occ = run(p, b, skipmode, args.frames, args.assets)
-                rows.append(dict(image=p[0], skipmode=skipmode, blocksize=b, occupancy=occ, framerate=fps, update=upd,
-                                 imin=p[2], imax=p[3], gmin=p[4], gmax=p[5]))
-                print("\t", p[0], skipmode, b, fps, upd, occ, flush=True)
-        path = os.path.join(args.out, "benchmark_results_%d_mi355x_synthetic.csv" % skipmode)
+                fps, upd, occ = run(p, b, skipmode, args.frames, args.assets, args.frames_in_flight)
+                rows.append(dict(image=image_label(p, args.assets), skipmode=skipmode, blocksize=b, occupancy=occ, framerate=fps, update=upd,
+                                 imin=p[2], imax=p[3], gmin=p[4], gmax=p[5], frames_in_flight=args.frames_in_flight))
+                print("\t", image_label(p, args.assets), skipmode, b, fps, upd, occ, flush=True)
+        path = os.path.join(args.out, "benchmark_results_%d_mi355x_synthetic_fif%d.csv" % (skipmode, args.frames_in_flight))
         with open(path, "w", newline="") as f:
-            w = csv.DictWriter(f, fieldnames=["image", "skipmode", "blocksize", "occupancy", "framerate", "update", "imin", "imax", "gmin", "gmax"])
+            w = csv.DictWriter(f, fieldnames=["image", "skipmode", "blocksize", "occupancy", "framerate", "update", "imin", "imax", "gmin", "gmax",
+                                              "frames_in_flight"])
             w.writeheader()
             w.writerows(rows)
         print("wrote", path)

@@ -55,18 +55,38 @@ __device__ __forceinline__ float sqrt_rn_normal(float x)
 // g * 255 it equals store_unorm8(g_clamp(g, 0, 1)) for every non-NaN float (vkv_debug_check what = 1 runs over all of them).
 __device__ __forceinline__ uint32_t store_unorm8_clamped(float g) { return __builtin_amdgcn_cvt_pk_u8_f32(g * 255.0f, 0u, 0u); }
 
-// what = 0: sqrt_rn_normal vs __builtin_sqrtf; what = 1: store_unorm8_clamped vs store_unorm8(g_clamp(., 0, 1))
+// what = 0: sqrt_rn_normal vs __builtin_sqrtf; what = 1: store_unorm8_clamped vs store_unorm8(g_clamp(., 0, 1));
+// what = 2: recip_exact(x) vs 1.0f / x for every ordinary x (vkv_device.hpp; the others take the IEEE path in ray_setup by construction);
+// what = 3: div_by(a, x, recip_refined(x)) vs a / x with eight hashed ordinary numerators per denominator x
 __global__ void __launch_bounds__(256) k_check_numerics(int what, uint32_t first_bits, uint64_t count, unsigned long long *mismatches)
 {
 	const uint64_t i = (uint64_t) blockIdx.x * 256u + threadIdx.x;
 	if (i >= count)
 		return;
-	const float x = __uint_as_float(first_bits + (uint32_t) i);
-	bool        bad;
+	const uint32_t bits = first_bits + (uint32_t) i;
+	const float    x    = __uint_as_float(bits);
+	bool           bad  = false;
 	if (what == 0)
 		bad = __float_as_uint(sqrt_rn_normal(x)) != __float_as_uint(__builtin_sqrtf(x));
-	else
+	else if (what == 1)
 		bad = (uint8_t) store_unorm8_clamped(x) != store_unorm8(g_clamp(x, 0.0f, 1.0f));
+	else if (what == 2)
+		bad = div_ordinary(x) && __float_as_uint(recip_exact(x)) != __float_as_uint(1.0f / x);
+	else if (div_ordinary(x))
+	{
+		const float r = recip_refined(x);
+		uint32_t    h = bits * 0x9e3779b9u + 0x7f4a7c15u;
+		for (int k = 0; k < 8 && !bad; ++k)
+		{
+			h ^= h >> 15, h *= 0x2c1b3c6du, h ^= h >> 12, h *= 0x297a2d39u, h ^= h >> 15;
+			// sign and mantissa from the hash, exponent 2^-40 .. 2^40 (biased 87 .. 167; the largest only with a zero mantissa)
+			uint32_t a_bits = (h & 0x807fffffu) | ((87u + (h >> 23) % 81u) << 23);
+			if (!div_ordinary(__uint_as_float(a_bits)))
+				a_bits &= 0xff800000u;
+			const float    a      = __uint_as_float(a_bits);
+			bad                   = __float_as_uint(div_by(a, x, r)) != __float_as_uint(a / x);
+		}
+	}
 	if (bad)
 		atomicAdd(mismatches, 1ull);
 }
@@ -1526,7 +1546,7 @@ int launch_check_numerics(vkv_ctx *ctx, int what, uint32_t first_bits, uint64_t 
 {
 	if (count == 0)
 		return VKV_OK;
-	if ((count + 255) / 256 > 0x7fffffffull || what < 0 || what > 1)
+	if ((count + 255) / 256 > 0x7fffffffull || what < 0 || what > 3)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "check_numerics: bad arguments");
 	hipLaunchKernelGGL(k_check_numerics, dim3((uint32_t) ((count + 255) / 256)), dim3(256), 0, s, what, first_bits, count, d_mismatches);
 	return check_launch(ctx, "check_numerics");

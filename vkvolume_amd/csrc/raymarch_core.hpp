@@ -181,11 +181,26 @@ __device__ __forceinline__ void mat4_mul_vec4(const float *m, const float *v, fl
 __device__ __forceinline__ uint8_t quantise_rgba8(float c) { return (uint8_t) __builtin_rintf(g_clamp(c, 0.0f, 1.0f) * 255.0f); }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Correctly rounded fp32 division out of v_rcp_f32 - the sequence the compiler itself emits for `a / b` under
+// -fhip-fp32-correctly-rounded-divide-sqrt, without its range scaling (v_div_scale / v_div_fmas) and special-case fix-up
+// (v_div_fixup), which do nothing for "ordinary" operands (both magnitudes in [2^-40, 2^40], or a zero numerator):
+//     r0 = rcp(d); e = fma(-d, r0, 1); r = fma(e, r0, r0)                          <- depends on the denominator only
+//     q0 = a * r; q1 = fma(fma(-d, q0, a), r, q0); q = fma(fma(-d, q1, a), r, q1)
+// The ray set-up divides three numerators by the same length (twice), by the same step count, takes three reciprocals of a
+// direction ...: 22 divisions per covered ray, 13 % of a C3 frame.  Sharing r between the quotients of one denominator and dropping
+// the scale / fix-up instructions leaves 149 of their 242 instructions, with the same bits: checked on the device against the IEEE
+// division for every float as denominator (vkv_debug_check what = 2: reciprocals; what = 3: quotients with hashed numerators).
+// Operands outside the ordinary range (axis-parallel rays: 1 / 0; NaNs of a degenerate camera) send the whole wave through the
+// plain IEEE set-up (ray_setup below), so the fast path never has to be right about them.
+// ---------------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------------
 // Ray generation + frag:147-210.  Returns true when the ray has to be marched; false when the pixel is finished
 // already (not covered, grazing-ray early-out, or a RayEntry / RayExit test output) with its result in R.
+// FAST: divisions through div_by / recip_exact; `ok` comes back false when an operand was outside their range (the caller then
+// repeats the set-up with FAST = false for the whole wave).
 // ---------------------------------------------------------------------------------------------------------------
-template <int SKIP>
-__device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, uint32_t py, Ray &R)
+template <int SKIP, bool FAST>
+__device__ __forceinline__ bool ray_setup_impl(const RayMarchArgs &A, uint32_t px, uint32_t py, Ray &R, bool &ok)
 {
 	R.r = R.g = R.b = R.a = 0.0f;        // out_color = vec4(0) (frag:120)
 	R.depth = 0.0f;                      // gl_FragDepth = 0 (frag:140)
@@ -201,7 +216,14 @@ __device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, ui
 	float       dz = __builtin_fmaf(fy, A.ddy[2], __builtin_fmaf(fx, A.ddx[2], A.dir00[2]));
 	{
 		const float len = __builtin_sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
-		dx /= len, dy /= len, dz /= len;
+		if (FAST)
+		{
+			ok = ok && div_ordinary(len) && div_ordinary_num(dx) && div_ordinary_num(dy) && div_ordinary_num(dz);
+			const float r = recip_refined(len);
+			dx = div_by(dx, len, r), dy = div_by(dy, len, r), dz = div_by(dz, len, r);
+		}
+		else
+			dx /= len, dy /= len, dz /= len;
 	}
 	const float ox = A.cam[0], oy = A.cam[1], oz = A.cam[2];
 	float       t_near = -INFINITY, t_far = INFINITY;
@@ -218,7 +240,14 @@ __device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, ui
 			}
 			else
 			{
-				const float inv = 1.0f / dv[a];
+				float inv;
+				if (FAST)
+				{
+					ok  = ok && div_ordinary(dv[a]);
+					inv = recip_exact(dv[a]);
+				}
+				else
+					inv = 1.0f / dv[a];
 				const float ta = (0.0f - ov[a]) * inv, tb = (1.0f - ov[a]) * inv;
 				t_near = g_max(t_near, g_min(ta, tb));
 				t_far  = g_min(t_far, g_max(ta, tb));
@@ -231,7 +260,14 @@ __device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, ui
 	const float Bp = __builtin_fmaf(A.plane_tex[2], dz, __builtin_fmaf(A.plane_tex[1], dy, A.plane_tex[0] * dx));
 	if (!(Bp > 0.0f))
 		return false;
-	const float t_plane = (0.0f - Ap) / Bp;
+	float t_plane;
+	if (FAST)
+	{
+		ok      = ok && div_ordinary(Bp) && div_ordinary_num(0.0f - Ap);
+		t_plane = div_by(0.0f - Ap, Bp, recip_refined(Bp));
+	}
+	else
+		t_plane = (0.0f - Ap) / Bp;
 	const float t0      = g_max(t_near, t_plane);
 	if (!(t0 < t_far))
 		return false;
@@ -262,11 +298,25 @@ __device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, ui
 	{
 		const float vx = ex - ox, vy = ey - oy, vz = ez - oz;
 		const float len = __builtin_sqrtf(__builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx)));
-		rdx = vx / len, rdy = vy / len, rdz = vz / len;
+		if (FAST)
+		{
+			ok = ok && div_ordinary(len) && div_ordinary_num(vx) && div_ordinary_num(vy) && div_ordinary_num(vz);
+			const float r = recip_refined(len);
+			rdx = div_by(vx, len, r), rdy = div_by(vy, len, r), rdz = div_by(vz, len, r);
+		}
+		else
+			rdx = vx / len, rdy = vy / len, rdz = vz / len;
 	}
 	float xx, xy, xz, ray_distance;        // ray_exit
 	{
-		const float ix = 1.0f / rdx, iy = 1.0f / rdy, iz = 1.0f / rdz;
+		float ix, iy, iz;
+		if (FAST)
+		{
+			ok = ok && div_ordinary(rdx) && div_ordinary(rdy) && div_ordinary(rdz);
+			ix = recip_exact(rdx), iy = recip_exact(rdy), iz = recip_exact(rdz);
+		}
+		else
+			ix = 1.0f / rdx, iy = 1.0f / rdy, iz = 1.0f / rdz;
 		const float tminx = -ex * ix, tminy = -ey * iy, tminz = -ez * iz;
 		const float tmaxx = (1.0f - ex) * ix, tmaxy = (1.0f - ey) * iy, tmaxz = (1.0f - ez) * iz;
 		const float t2x = g_max(tminx, tmaxx), t2y = g_max(tminy, tmaxy), t2z = g_max(tminz, tmaxz);
@@ -308,7 +358,18 @@ __device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, ui
 	const float nf      = __builtin_ceilf((float) dim_max * ray_distance * A.sampling_factor);
 	if (!(nf >= 2.0f && nf <= 16777216.0f))
 		return false;
-	const float sx = (rdx * ray_distance) / (nf - 1.0f), sy = (rdy * ray_distance) / (nf - 1.0f), sz = (rdz * ray_distance) / (nf - 1.0f);
+	float sx, sy, sz;
+	{
+		const float den = nf - 1.0f, nx = rdx * ray_distance, ny = rdy * ray_distance, nz = rdz * ray_distance;
+		if (FAST)
+		{
+			ok = ok && div_ordinary_num(nx) && div_ordinary_num(ny) && div_ordinary_num(nz);        // den is 1 .. 2^24
+			const float r = recip_refined(den);
+			sx = div_by(nx, den, r), sy = div_by(ny, den, r), sz = div_by(nz, den, r);
+		}
+		else
+			sx = nx / den, sy = ny / den, sz = nz / den;
+	}
 	{
 		const float qx = ex + sx, qy = ey + sy, qz = ez + sz;
 		if (qx <= 0.0f || qy <= 0.0f || qz <= 0.0f || qx >= 1.0f || qy >= 1.0f || qz >= 1.0f)
@@ -322,9 +383,23 @@ __device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, ui
 	R.dmap                = nullptr;
 	if (SKIP != VKV_SKIP_NONE)
 	{
-		R.six = 1.0f / ((sx * (float) W) / A.block_size[0]);
-		R.siy = 1.0f / ((sy * (float) H) / A.block_size[1]);
-		R.siz = 1.0f / ((sz * (float) D) / A.block_size[2]);
+		if (FAST)
+		{
+			const float nx = sx * (float) W, ny = sy * (float) H, nz = sz * (float) D;
+			ok = ok && div_ordinary(A.block_size[0]) && div_ordinary(A.block_size[1]) && div_ordinary(A.block_size[2]) && div_ordinary_num(nx) &&
+			     div_ordinary_num(ny) && div_ordinary_num(nz);
+			const float tx = div_by(nx, A.block_size[0], recip_refined(A.block_size[0]));
+			const float ty = div_by(ny, A.block_size[1], recip_refined(A.block_size[1]));
+			const float tz = div_by(nz, A.block_size[2], recip_refined(A.block_size[2]));
+			ok    = ok && div_ordinary(tx) && div_ordinary(ty) && div_ordinary(tz);
+			R.six = recip_exact(tx), R.siy = recip_exact(ty), R.siz = recip_exact(tz);
+		}
+		else
+		{
+			R.six = 1.0f / ((sx * (float) W) / A.block_size[0]);
+			R.siy = 1.0f / ((sy * (float) H) / A.block_size[1]);
+			R.siz = 1.0f / ((sz * (float) D) / A.block_size[2]);
+		}
 		if (SKIP == VKV_SKIP_ANISOTROPIC_DISTANCE)
 			R.dmap = A.maps[(rdz < 0 ? 1 : 0) + (rdy < 0 ? 2 : 0) + (rdx < 0 ? 4 : 0)];
 		else
@@ -334,6 +409,19 @@ __device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, ui
 	R.occupied  = true;
 	R.first_hit = R.n_steps;
 	return true;
+}
+
+// The set-up every kernel calls: the fast divisions when every operand of every lane of the wave is ordinary, else (axis-parallel
+// rays, degenerate cameras) the plain IEEE ones for the whole wave - the same bits either way.
+template <int SKIP>
+__device__ __forceinline__ bool ray_setup(const RayMarchArgs &A, uint32_t px, uint32_t py, Ray &R)
+{
+	bool       ok      = true;
+	const bool marched = ray_setup_impl<SKIP, true>(A, px, py, R, ok);
+	if (__builtin_amdgcn_ballot_w64(!ok) == 0ull)
+		return marched;
+	bool unused = true;
+	return ray_setup_impl<SKIP, false>(A, px, py, R, unused);
 }
 
 // the state ray_setup leaves behind for a pixel the volume's box does not cover
@@ -2035,7 +2123,7 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 }
 
 template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF>
-__global__ void __launch_bounds__(256) k_raymarch_lean(const RayMarchArgs A)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) k_raymarch_lean(const RayMarchArgs A)
 {
 	RmLds &L = lean_lds();
 	lean_block<SKIP, ERT, GRAD, PACKED, LF>(A, blockIdx.x, L);
@@ -2046,7 +2134,7 @@ __global__ void __launch_bounds__(256) k_raymarch_lean(const RayMarchArgs A)
 // of the others — what a renderer with frames in flight gets from several queues, without depending on queue scheduling.
 // The argument blocks live in device memory (n x 1.7 KB does not fit the kernel-argument segment).
 template <int SKIP, bool ERT, int GRAD, uint32_t LF>
-__global__ void __launch_bounds__(256) k_raymarch_lean_batch(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t groups_per_frame)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) k_raymarch_lean_batch(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t groups_per_frame)
 {
 	RmLds &        L = lean_lds();
 	const uint32_t g = blockIdx.x >> 3;

@@ -62,6 +62,38 @@ __device__ __forceinline__ float gradient_on_the_fly(const uint8_t *__restrict__
 	return gradient_from_taps(v1, v2, v3, v4, modifier);
 }
 
+// ---- correctly rounded fp32 division out of v_rcp_f32 (the ray set-up's 22 divisions per ray; see raymarch_core.hpp, ray_setup) ----
+__device__ __forceinline__ bool div_ordinary(float x)
+{
+	const float m = __builtin_fabsf(x);
+	return m >= 0x1p-40f && m <= 0x1p40f;        // false for 0, denormals, huge values, inf and NaN
+}
+__device__ __forceinline__ bool div_ordinary_num(float x)
+{        // (a zero numerator is NOT ordinary: the refinement loses the sign of -0 / d)
+	return div_ordinary(x);
+}
+__device__ __forceinline__ float recip_refined(float d)
+{
+	const float r0 = __builtin_amdgcn_rcpf(d);
+	const float e  = __builtin_fmaf(-d, r0, 1.0f);
+	return __builtin_fmaf(e, r0, r0);
+}
+// a / d given r = recip_refined(d)
+__device__ __forceinline__ float div_by(float a, float d, float r)
+{
+	const float q0 = a * r;
+	const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, a), r, q0);
+	return __builtin_fmaf(__builtin_fmaf(-d, q1, a), r, q1);
+}
+// 1 / d (the same sequence with a = 1: q0 = r)
+__device__ __forceinline__ float recip_exact(float d)
+{
+	const float r  = recip_refined(d);
+	const float q1 = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+	return __builtin_fmaf(__builtin_fmaf(-d, q1, 1.0f), r, q1);
+}
+
+
 // R8_UNORM store: round to nearest even.
 __device__ __forceinline__ uint8_t store_unorm8(float g) { return (uint8_t) __builtin_rintf(g * 255.0f); }
 
