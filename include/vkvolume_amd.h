@@ -203,6 +203,8 @@ typedef struct VkvTuning
 	int32_t  screen_cull;              /* 1 = pixels outside the screen bound of the volume's box skip the ray set-up (default)   VKV_RAYMARCH_CULL=0 */
 	int32_t  feedback;                 /* 1 = registered targets start their tiles in the order their last measured frame suggests (default)   VKV_RAYMARCH_FEEDBACK=0 */
 	uint32_t feedback_period;          /* frames between two cost measurements of a target (8)                            VKV_RAYMARCH_FEEDBACK_PERIOD */
+	int32_t  ray_order;                /* experiment, 0 = off (default): 1 = the rays of a 16x16 block are dealt to its waves by the events their pixels
+	                                      took in the last frame into the (registered) target                            VKV_RAYMARCH_RAY_ORDER=1 */
 	float    tile_mix_heavy;           /* experiment: central share of the tiles spread over the first tile_mix_spread of the order (0 = off)   VKV_RAYMARCH_TILE_MIX=h,s */
 	float    tile_mix_spread;
 	uint32_t gradient_segment;         /* vkv_gradient_map: tiles a workgroup marches in z; 0 = automatic                 VKV_GRADIENT_SEGMENT */
@@ -322,8 +324,8 @@ int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_transfer_function,
  * plain tile order / address arithmetic in registers, same bits) - vkv_prepare_render only moves that work to set-up time. */
 int vkv_prepare_render(vkv_ctx *ctx, const VkvRenderParams *params, uint32_t count, void *stream);
 
-/* Start-order feedback needs device state per render target (one uint32 cost and one uint32 order entry per tile of the schedule): a
- * renderer draws into the same swap-chain images again and again with a camera that moves little, so the tiles that took longest in the
+/* Start-order and ray-order feedback need device state per render target (one uint32 cost and one uint32 order entry per tile of the
+ * schedule, one byte per pixel): a renderer draws into the same swap-chain images again and again with a camera that moves little, so the tiles that took longest in the
  * last measured frame are started first in the next ones (any order renders the same bits).
  * vkv_register_target - set-up call: allocates and initialises that state for frames of image_width x image_height pixels rendered with
  *   tile schedule `tiles` into `d_target` (the d_out_rgba8 or, without one, d_out_color pointer of the parameter block).  Targets that

@@ -197,7 +197,7 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 	a.nblocks     = (uint32_t) nb;
 	a.test        = P->options.test;
 	a.queue_heads = nullptr;        // persistent scheduler: set at launch (per-stream scratch)
-	a.tile_cost = nullptr, a.order_out = nullptr;        // start-order feedback: attached by the launchers
+	a.tile_cost = nullptr, a.order_out = nullptr, a.pixel_cost = nullptr;        // start-order / ray-order feedback: attached by the launchers
 	a.trace       = reinterpret_cast<unsigned long long *>(ctx->d_trace);
 	a.back        = (int) std::ceil(P->transfer_function.sampling_factor);
 	a.addr_lut = nullptr, a.lut_y = a.lut_z = a.lut_words = 0;
@@ -237,6 +237,8 @@ static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a, hipStream_t s)
 		}
 	if (!f)
 		return false;        // not registered (or registered for another schedule): centre-first
+	if (ctx->tuning.ray_order && f->compact == a.compact)
+		a.pixel_cost = f->d_pixel;        // read (sort key of this frame) and written (key of the next) by every frame into the target
 	// the view of this frame: central ray (normalised) and camera position in texture space.  Costs measured on a view that was more
 	// than ~12 degrees away (or from a camera that has moved by more than a fifth of its distance to the volume's centre) say little
 	// about this frame - an order sorted by them scatters the heavy tiles (measured: -3 % for targets that alternate between views

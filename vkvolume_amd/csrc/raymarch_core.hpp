@@ -68,6 +68,9 @@ struct RayMarchArgs
 	// buffer tile_order then points to).  Both null when unused.
 	uint32_t *      tile_cost;
 	uint32_t *      order_out;
+	// ray order feedback: one byte per output pixel of the target - min(events of the pixel's ray in the last frame / 4, 63) - by which the
+	// 256 rays of a 16x16 block are dealt to its four waves, longest first (lean_block); null when unused
+	uint8_t *       pixel_cost;
 	float           alpha_lut[256];     // opacity correction keyed by the TF alpha byte (frag:283)
 };
 
@@ -2061,7 +2064,46 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 		return;        // never with a well-formed order; keeps a damaged one (a target shared by two streams without an event) from becoming a wild address
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t       px, py, o;
-	const bool     inside = block_pixel<1>(A, k * A.blocks_per_tile + sb, (part * WPB + wave) * 64u + lane, px, py, o);
+	uint32_t       rb = (part * WPB + wave) * 64u + lane;        // ray of the block this lane marches: by default the lane's own pixel of its 8x8 quadrant
+	if (WPB == 4 && A.pixel_cost)
+	{
+		// Ray order feedback: a wave runs until its LAST ray has ended, and a block execution costs the SIMD the same for 1 or 64 active lanes,
+		// so a wave should hold rays that end together.  The rays of a 16x16 block are dealt to its four waves sorted by the number of events
+		// the same pixel's ray took in the previous frame into this target (a counting sort over 64 bins in the LDS the tables will occupy
+		// later; any permutation renders the same frame - a fresh cost buffer is all zeros and sorts to the identity).  On the oracle's
+		// traces an exact key saves 18 % of the block executions of a C3 frame (tools/sched_policies_sim.py).
+		uint32_t *hist = reinterpret_cast<uint32_t *>(&L), *perm = hist + 64;
+		uint32_t       npx, npy, no;
+		const bool     nin = block_pixel<1>(A, k * A.blocks_per_tile + sb, threadIdx.x, npx, npy, no);
+		const uint32_t key = nin ? min((uint32_t) A.pixel_cost[no], 63u) : 0u;
+		if (__syncthreads_or(key != 0u))
+		{
+			if (threadIdx.x < 64)
+				hist[threadIdx.x] = 0u;
+			__syncthreads();
+			const uint32_t bin = 63u - key;        // longest first
+			atomicAdd(&hist[bin], 1u);
+			__syncthreads();
+			if (threadIdx.x < 64)
+			{        // exclusive prefix over the 64 bins by one wave
+				const uint32_t v    = hist[threadIdx.x];
+				uint32_t       incl = v;
+				for (int o2 = 1; o2 < 64; o2 <<= 1)
+				{
+					const uint32_t up = (uint32_t) __shfl_up((int) incl, o2);
+					if ((int) threadIdx.x >= o2)
+						incl += up;
+				}
+				hist[threadIdx.x] = incl - v;
+			}
+			__syncthreads();
+			perm[atomicAdd(&hist[bin], 1u)] = threadIdx.x;
+			__syncthreads();
+			rb = perm[threadIdx.x];
+			// (the tables are staged behind the __syncthreads_or below: every lane has read its entry by then)
+		}
+	}
+	const bool     inside = block_pixel<1>(A, k * A.blocks_per_tile + sb, rb, px, py, o);
 	Ray R;
 	R.o = o;
 	const unsigned long long t_start = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -2104,6 +2146,8 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 	}
 	if (!inside)
 		return;
+	if (WPB == 4 && A.pixel_cost)
+		A.pixel_cost[o] = (uint8_t) min((R.n_vol + R.n_dist + 3u) >> 2, 63u);        // this frame's events of the pixel: the next frame's sort key
 	ray_finish(A, R, marched);
 	if (A.trace)
 	{        // diagnostic only: per-wave timeline (100 MHz clock); the values never feed an output
