@@ -195,8 +195,7 @@ typedef struct VkvTuning
 {
 	uint32_t struct_size;              /* sizeof(VkvTuning): set by vkv_get_tuning, checked by vkv_set_tuning                       */
 	int32_t  scheduler;                /* 0 lane = ray on static tiles (default); 1 persistent waves with lane re-fill   VKV_RAYMARCH_SCHEDULER=persistent */
-	int32_t  batch_mode;               /* vkv_render_batch: 0 workgroup per 16x16 block (default); 1 resident workgroups pulling 8x8 units from global
-	                                      counters; 2 workgroups that own a region of sixteen 8x8 units                  VKV_RAYMARCH_BATCH=pull|region */
+	int32_t  batch_mode;               /* vkv_render_batch: 0 workgroup per tile (default); 1 resident workgroups pulling 8x8 units   VKV_RAYMARCH_BATCH=pull */
 	int32_t  batch_sequential;         /* vkv_render_batch: 1 = frames one after the other instead of interleaved       VKV_RAYMARCH_BATCH_ORDER=sequential */
 	int32_t  tile_order_linear;        /* 1 = tiles start in schedule order instead of centre-of-image first             VKV_RAYMARCH_TILE_ORDER=linear */
 	int32_t  address_tables;           /* packed image: 0 none, 1 two-level LDS tables, 2 + one entry per voxel index (default)   VKV_RAYMARCH_LUT=0|2(two-level)|1 */

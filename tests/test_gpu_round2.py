@@ -312,22 +312,6 @@ def test_render_batch_pull_kernel_equals_single_launches(ctx, skipping_type):
     for i, (a, b) in enumerate(zip(single, pulled)):
         for k in a:
             assert torch.equal(a[k], b[k]), "frame %d: %s differs between the pull kernel and the single launch" % (i, k)
-    # batch_mode = 2: workgroups that own a region of sixteen 8x8 units (k_raymarch_lean_region)
-    region = outputs()
-    plist = []
-    for p, o in zip(params, region):
-        q = abi.RenderParams.from_buffer_copy(p)
-        point(q, o)
-        plist.append(q)
-    ctx.set_tuning(batch_mode=2)
-    try:
-        ctx.render_batch(plist, st)
-        torch.cuda.synchronize()
-    finally:
-        ctx.set_tuning(batch_mode=0)
-    for i, (a, b) in enumerate(zip(single, region)):
-        for k in a:
-            assert torch.equal(a[k], b[k]), "frame %d: %s differs between the region kernel and the single launch" % (i, k)
 
 
 @pytest.mark.gpu
@@ -457,7 +441,7 @@ def test_tuning_block_switches_render_the_same_bits():
         ref = frames()
         assert int(ref[0][1].sum().item()) > 0
         for fields in (dict(address_tables=0), dict(address_tables=1), dict(full_table_lds_limit=0), dict(screen_cull=0), dict(tile_order_linear=1),
-                       dict(batch_sequential=1), dict(batch_mode=1), dict(batch_mode=2), dict(scheduler=1), dict(feedback=0), dict(tile_mix_heavy=0.3, tile_mix_spread=0.6)):
+                       dict(batch_sequential=1), dict(batch_mode=1), dict(scheduler=1), dict(feedback=0), dict(tile_mix_heavy=0.3, tile_mix_spread=0.6)):
             c.set_tuning(**fields)
             got = frames()
             reset = {k: getattr(t0, k) for k in fields}

@@ -284,7 +284,7 @@ static void default_tuning(VkvTuning &t)
 	if (const char *e = env("VKV_RAYMARCH_SCHEDULER"))
 		t.scheduler = e[0] == 'p';
 	if (const char *e = env("VKV_RAYMARCH_BATCH"))
-		t.batch_mode = e[0] == 'p' ? 1 : (e[0] == 'r' ? 2 : 0);
+		t.batch_mode = e[0] == 'p';
 	if (const char *e = env("VKV_RAYMARCH_BATCH_ORDER"))
 		t.batch_sequential = e[0] == 's';
 	if (const char *e = env("VKV_RAYMARCH_TILE_ORDER"))
@@ -399,7 +399,7 @@ int vkv_set_tuning(vkv_ctx *ctx, const VkvTuning *tuning)
 		return VKV_E_INVALID_ARGUMENT;
 	if (!tuning || tuning->struct_size != sizeof(VkvTuning))
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "set_tuning: struct_size must be sizeof(VkvTuning) = %zu (start from vkv_get_tuning)", sizeof(VkvTuning));
-	if (tuning->scheduler < 0 || tuning->scheduler > 1 || tuning->batch_mode < 0 || tuning->batch_mode > 2 || tuning->address_tables < 0 ||
+	if (tuning->scheduler < 0 || tuning->scheduler > 1 || tuning->batch_mode < 0 || tuning->batch_mode > 1 || tuning->address_tables < 0 ||
 	    tuning->address_tables > 2 || tuning->feedback_period == 0 || tuning->gradient_segment > 255u ||
 	    (tuning->pack_tile != 0 && tuning->pack_tile != 2 && tuning->pack_tile != 4))
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "set_tuning: field out of range");

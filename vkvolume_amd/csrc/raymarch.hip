@@ -410,42 +410,6 @@ static uint32_t launch_pull_ert(vkv_ctx *ctx, bool ert, int grad, const RayMarch
 	                 : (grad == 1 ? launch_pull_kind<SKIP, false, 1>(ctx, c, d_frames, n, d_heads, units, s) : launch_pull_kind<SKIP, false, 2>(ctx, c, d_frames, n, d_heads, units, s));
 }
 
-// ---- the same, with workgroups that own a region of kRegionUnits units (k_raymarch_lean_region) ----------------------------------
-template <int SKIP, bool ERT, int GRAD>
-static void launch_region_kind(LeanChoice c, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, hipStream_t s)
-{
-	if constexpr (GRAD != 2)
-	{
-		if (c.kind == 2)
-			hipLaunchKernelGGL((k_raymarch_lean_region<SKIP, ERT, GRAD, kLfFull>), dim3(grid), dim3(256), c.lds, s, d_frames, n);
-		else if (c.kind == 1)
-			hipLaunchKernelGGL((k_raymarch_lean_region<SKIP, ERT, GRAD, kLfLut>), dim3(grid), dim3(256), c.lds, s, d_frames, n);
-		if (c.kind != 0)
-			return;
-	}
-	hipLaunchKernelGGL((k_raymarch_lean_region<SKIP, ERT, GRAD, kLfPlain>), dim3(grid), dim3(256), sizeof(RmLds), s, d_frames, n);
-}
-
-template <int SKIP>
-static void launch_region_ert(bool ert, int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, LeanChoice c, hipStream_t s)
-{
-#define VKV_REGION(E)                                                                                   \
-	do                                                                                                  \
-	{                                                                                                   \
-		if (grad == 0)                                                                                  \
-			launch_region_kind<SKIP, E, 0>(c, d_frames, n, grid, s);                                    \
-		else if (grad == 1)                                                                             \
-			launch_region_kind<SKIP, E, 1>(c, d_frames, n, grid, s);                                    \
-		else                                                                                            \
-			launch_region_kind<SKIP, E, 2>(c, d_frames, n, grid, s);                                    \
-	} while (0)
-	if (ert)
-		VKV_REGION(true);
-	else
-		VKV_REGION(false);
-#undef VKV_REGION
-}
-
 int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, const float *alpha_luts, hipStream_t s)
 {
 	// the argument blocks go through this stream's scratch buffer: an earlier batch on the same stream has finished with it by the
@@ -511,24 +475,6 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 		const RayMarchArgs &a = host[i], &b = host[0];
 		pull = a.packed == b.packed && a.tf_bits == b.tf_bits && a.tf == b.tf && a.addr_lut == b.addr_lut && a.W == b.W && a.H == b.H && a.D == b.D &&
 		       std::memcmp(a.alpha_lut, b.alpha_lut, sizeof(a.alpha_lut)) == 0;
-	}
-	if (T.batch_mode == 2 && !sequential)
-	{        // workgroups that own a region of kRegionUnits units (k_raymarch_lean_region)
-		const uint32_t upt = host[0].blocks_per_tile * 4u, tpr = std::max(1u, kRegionUnits / upt);
-		const uint64_t regions = ((uint64_t) host[0].tile_count + tpr - 1) / tpr, rgrid = ((regions + 7u) / 8u) * 8u * n;
-		if (rgrid > 0x7fffffffull)
-			return set_error(ctx, VKV_E_UNSUPPORTED, "render_batch: too many workgroups for one launch");
-		switch (P[0].options.skipping_type)
-		{
-			case VKV_SKIP_NONE: launch_region_ert<VKV_SKIP_NONE>(ert, grad, d_frames, n, (uint32_t) rgrid, choice, s); break;
-			case VKV_SKIP_BLOCK: launch_region_ert<VKV_SKIP_BLOCK>(ert, grad, d_frames, n, (uint32_t) rgrid, choice, s); break;
-			case VKV_SKIP_DISTANCE: launch_region_ert<VKV_SKIP_DISTANCE>(ert, grad, d_frames, n, (uint32_t) rgrid, choice, s); break;
-			case VKV_SKIP_ANISOTROPIC_DISTANCE: launch_region_ert<VKV_SKIP_ANISOTROPIC_DISTANCE>(ert, grad, d_frames, n, (uint32_t) rgrid, choice, s); break;
-			default: return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: bad skipping_type %d", P[0].options.skipping_type);
-		}
-		if (any_sort)
-			hipLaunchKernelGGL(k_tile_orders_from_cost, dim3(n), dim3(256), 0, s, d_frames);
-		return check_launch(ctx, "render_batch");
 	}
 	if (pull)
 	{

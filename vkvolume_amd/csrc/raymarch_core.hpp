@@ -2297,110 +2297,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_raymarch_lean_region - the batch launch with workgroups that own a REGION: kRegionUnits 8x8 units = a run of consecutive entries of the
-// tile start order (four 16x16 tiles), handed to the workgroup's four waves one unit at a time through a counter in LDS.
-//   * A workgroup of the tile-per-workgroup kernel lives as long as its longest wave while the other three wave slots (and its LDS) idle:
-//     20 of a CU's 32 wave slots are busy on average.  Here a wave that has finished its unit takes the region's next one, so the four
-//     slots of a workgroup stay busy until the region runs dry - without the failure of the globally pulling kernel (k_raymarch_lean_pull),
-//     whose last, longest tiles ended up with their four units on four different CUs: a region's units never leave their CU.
-//   * Tables are staged once per region (four tiles) and only by regions that touch the screen bound of the volume's box.
-//   * Units are taken in start order (with the measured order: the region's tiles have similar costs, the dearest regions start first).
-// Same frames, bit for bit: a unit is marched by lean_march exactly as in lean_block.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kRegionUnits = 16;
-
-template <int SKIP, bool ERT, int GRAD, uint32_t LF, bool SEP>
-__device__ __forceinline__ void region_units(const RayMarchArgs &A, uint32_t r0, uint32_t units_total, uint32_t upt, uint32_t *s_next, const RmLds &L)
-{
-	const uint32_t lane = threadIdx.x & 63u;
-	uint32_t       u    = threadIdx.x >> 6;        // the first four units need no ticket
-	while (u < units_total)
-	{
-		const uint32_t j = u / upt, w = u % upt, rank = r0 + j;
-		const uint32_t k = A.tile_order ? A.tile_order[rank] : rank;
-		if (k < A.tile_count)
-		{        // (always, unless the order is damaged: see lean_block)
-			uint32_t   px, py, o;
-			const bool inside = block_pixel<1>(A, k * A.blocks_per_tile + (w >> 2), (w & 3u) * 64u + lane, px, py, o);
-			Ray        R      = {};        // every field defined per unit: nothing of the previous unit's ray is carried round the loop
-			R.o = o;
-			bool marched = false;
-			if (inside)
-			{
-				if (px >= A.cull_x0 && px <= A.cull_x1 && py >= A.cull_y0 && py <= A.cull_y1)
-					marched = ray_setup<SKIP>(A, px, py, R);
-				else
-					ray_clear(R);
-			}
-			uint32_t iter = 0;
-			if (marched)
-				lean_march<SKIP, ERT, GRAD, true, SEP, LF>(A, R, L, iter);
-			__builtin_amdgcn_s_setprio(0);        // lean_march raises the priority of a long wave: back to normal for the next unit
-			if (A.tile_cost)
-			{
-				uint32_t it = iter;
-				for (int o2 = 32; o2 > 0; o2 >>= 1)
-					it = max(it, (uint32_t) __shfl_xor((int) it, o2));
-				if (it != 0u && lane == 0u)
-					atomicMax(&A.tile_cost[k], it);
-			}
-			if (inside)
-				ray_finish(A, R, marched);
-		}
-		uint32_t v = 0;
-		if (lane == 0)
-			v = atomicAdd(s_next, 1u);
-		u = __builtin_amdgcn_readfirstlane(v);
-	}
-}
-
-template <int SKIP, bool ERT, int GRAD, uint32_t LF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) k_raymarch_lean_region(const RayMarchArgs *__restrict__ frames, uint32_t n)
-{
-	__shared__ uint32_t s_next;
-	RmLds &             L = lean_lds();
-	const uint32_t      g = blockIdx.x >> 3;
-	const RayMarchArgs &A = frames[g % n];        // frames interleaved in groups of eight workgroups, like k_raymarch_lean_batch
-	// XCD x = id & 7 takes the regions x, x + 8, ... of the frame
-	const uint32_t q   = (g / n) * 8u + (blockIdx.x & 7u);
-	const uint32_t upt = A.blocks_per_tile * 4u, tpr = max(1u, kRegionUnits / upt);        // 8x8 units per tile, tiles per region
-	const uint32_t r0  = q * tpr;
-	if (r0 >= A.tile_count)
-		return;
-	const uint32_t nt = min(tpr, A.tile_count - r0);
-	// does any tile of the region touch the screen bound of the volume's box?  (only then can a ray march, only then are the tables needed)
-	bool touch = false;
-	if (threadIdx.x < nt)
-	{
-		const uint32_t rank = r0 + threadIdx.x, k = A.tile_order ? A.tile_order[rank] : rank;
-		if (k < A.tile_count)
-		{
-			const uint32_t t  = A.tile_first + k * A.tile_stride;
-			const uint32_t x0 = (t % A.tiles_x) * A.tile_w, y0 = (t / A.tiles_x) * A.tile_h;
-			touch = x0 <= A.cull_x1 && x0 + A.tile_w > A.cull_x0 && y0 <= A.cull_y1 && y0 + A.tile_h > A.cull_y0;
-		}
-	}
-	if (threadIdx.x == 0)
-		s_next = 4u;
-	bool sep = false;
-	if (__syncthreads_or(touch ? 1 : 0))
-	{
-		if ((LF & kLeanLut) != 0 && GRAD != 2)
-		{        // before the barrier of stage_tables_er
-			if ((LF & kLeanFull) != 0 && tf_is_separable(A))
-				stage_full_lut(A, L);
-			else
-				stage_addr_lut(A);
-		}
-		sep = stage_tables_er(A, L);
-	}
-	if (sep)
-		region_units<SKIP, ERT, GRAD, LF, true>(A, r0, nt * upt, upt, &s_next, L);
-	else
-		region_units<SKIP, ERT, GRAD, LF, false>(A, r0, nt * upt, upt, &s_next, L);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // Start order from measured costs: one workgroup per frame sorts the schedule entries 0 .. count - 1 by the cost the previous frame
 // into the same target left in tile_cost, longest first (a counting sort over min(cost, 1023); entries of equal cost keep no
 // particular order: any permutation renders the same frame, and tie orders measured the same), writes the order to order_out and
