@@ -604,6 +604,9 @@ def main():
                 # measured with 8 frames per launch: scaled to this run's average launch
                 out["roofline"]["traffic"] = int(tr["traffic_bytes_per_launch"] * out["roofline"]["frames_per_launch"] / tr.get("frames_per_launch", 8))
                 out["roofline"]["traffic_source"] = tr["source"]
+                if tr.get("valu_busy") is not None:
+                    # the binding limit: share of the SIMD cycles of that launch in which a VALU instruction was executing (PMC pass, same file)
+                    out["roofline"]["valu_busy"] = tr["valu_busy"]
             else:
                 out["roofline"]["traffic_source"] = "withheld: %s was measured on other integrator sources than this tree's" % os.path.basename(TRAFFIC_FILE)
     except (OSError, ValueError, KeyError):

@@ -23,6 +23,8 @@ run_pmc single WRITE_SIZE --frames-per-launch 1
 # instruction mix of the ray-march kernels (SQ block, one pass): VALU / SALU / LDS / VMEM instructions, wave cycles and their wait shares
 run_pmc batch8 SQ_WAVES,SQ_WAVE_CYCLES,SQ_BUSY_CU_CYCLES,SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_ANY,SQ_INSTS_VALU,SQ_INSTS_SALU --batch-streams 1
 run_pmc batch8 SQ_INSTS_VMEM_RD,SQ_INSTS_LDS,SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_THREAD_CYCLES_VALU,SQ_INSTS_VALU_CVT,SQ_INSTS_VALU_FMA_F32,SQ_INSTS_VALU_INT32 --batch-streams 1
+# VALU busy of the ray-march kernel (the binding limit next to the HBM fraction): SQ_ACTIVE_INST_VALU * 4 / (SIMDs * GRBM_GUI_ACTIVE)
+run_pmc batch8 SQ_ACTIVE_INST_VALU,SQ_BUSY_CYCLES,GRBM_GUI_ACTIVE --batch-streams 1
 run_stats dense_batch8 --skip none --no-ert --steps 16 --warmup 8 --batch-streams 1
 for w in c2 c3cube c4 c5; do timeout 300 python3 $R/bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null; done
 timeout 600 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_driver_like.json 2> $O/bench_driver_like.err
@@ -35,9 +37,10 @@ cd $R
   done
   python3 tools/summarize_profile.py "${tag}_pmc_batch8" /nonexistent $O/pmc_batch8_FETCH_SIZE $O/pmc_batch8_WRITE_SIZE
   python3 tools/summarize_profile.py "${tag}_pmc_single" /nonexistent $O/pmc_single_FETCH_SIZE $O/pmc_single_WRITE_SIZE
-  python3 tools/summarize_profile.py "${tag}_pmc_sq_batch8" /nonexistent $O/pmc_batch8_SQ_WAVES* $O/pmc_batch8_SQ_INSTS_VMEM_RD*
+  python3 tools/summarize_profile.py "${tag}_pmc_sq_batch8" /nonexistent $O/pmc_batch8_SQ_WAVES* $O/pmc_batch8_SQ_INSTS_VMEM_RD* $O/pmc_batch8_SQ_ACTIVE_INST_VALU*
   python3 tools/summarize_profile.py "${tag}_dense_batch8" $O/stats_dense_batch8
   echo "bench line (dense_batch8):"; cat $O/bench_dense_batch8.json; echo
   echo "# commit: $(cat $R/.commit_id 2>/dev/null)"
 } > $O/${tag}_rocprof.txt
+python3 tools/make_traffic_json.py $O ${tag%%_*} > $O/${tag%%_*}_traffic.json; cat $O/${tag%%_*}_traffic.json
 ls -la $O | head -30

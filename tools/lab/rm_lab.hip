@@ -34,6 +34,7 @@ int launch_lean(const RayMarchArgs &a, hipStream_t s)
 template <int SKIP, bool ERT, int GRAD, uint32_t LF, int WPB>
 __global__ void __launch_bounds__(WPB * 64) k_lab_lean_wpb(const RayMarchArgs A)
 {
+	lean_lds_check();
 	lean_block<SKIP, ERT, GRAD, true, LF, WPB>(A, blockIdx.x, lean_lds());
 }
 

@@ -349,7 +349,7 @@ static void launch_batch_kind(LeanChoice c, const RayMarchArgs *d_frames, uint32
 		if (c.kind != 0)
 			return;
 	}
-	hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfPlain>), dim3(grid), dim3(256), sizeof(RmLds), s, d_frames, n, gpf);
+	hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfPlain>), dim3(grid), dim3(256), lean_lds_bytes(0, 0, 0, 0, 0), s, d_frames, n, gpf);
 }
 
 template <int SKIP, bool ERT>
@@ -396,7 +396,7 @@ static uint32_t launch_pull_kind(vkv_ctx *ctx, LeanChoice c, const RayMarchArgs 
 		if (c.kind == 1)
 			return launch_pull_one<SKIP, ERT, GRAD, kLfLut>(ctx, d_frames, n, d_heads, c.lds, units, s);
 	}
-	return launch_pull_one<SKIP, ERT, GRAD, kLfPlain>(ctx, d_frames, n, d_heads, sizeof(RmLds), units, s);
+	return launch_pull_one<SKIP, ERT, GRAD, kLfPlain>(ctx, d_frames, n, d_heads, lean_lds_bytes(0, 0, 0, 0, 0), units, s);
 }
 
 template <int SKIP>

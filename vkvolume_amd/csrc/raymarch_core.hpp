@@ -1542,17 +1542,47 @@ __device__ __forceinline__ void packed_filter_g(uint32_t q00, uint32_t q10, uint
 
 // The LDS of the lean kernels is ONE dynamic segment whose layout the launcher sizes (lean_lds_bytes): RmLds at its start, behind it
 // either the two-level address tables (kLeanLut) or, starting inside RmLds behind the separable transfer-function tables, the
-// per-voxel-index tables (kLeanFull).  Nothing here depends on where the compiler puts static __shared__ objects (the workgroup
-// reduction behind __syncthreads_or owns 256 bytes of them).
+// per-voxel-index tables (kLeanFull).  The kernels have NO static LDS object, so the segment starts at LDS address 0 - RmLds sits at
+// kLdsBase = 16 (address 0 would be a null pointer to the compiler) - and every table address is a compile-time constant that folds into the offset field of its ds_read (with a relocatable base the march loop carried five
+// more VALU additions per iteration: 443 -> 455 priced cycles, 0.1143 -> 0.1155 ms per C3 frame).  lean_lds_check() stops a kernel whose
+// segment does not start at 0 (a compiler or an inlined helper that brings a static __shared__ object - __syncthreads_or does: its
+// workgroup reduction owns 256 static bytes, hence wg_any below), instead of letting it read the wrong tables.
 extern __shared__ __align__(16) uint32_t s_lean_lds[];
 static_assert(sizeof(RmLds) % 16 == 0, "the address tables behind RmLds are read as 64-bit words");
 
-__device__ __forceinline__ RmLds &lean_lds() { return *reinterpret_cast<RmLds *>(s_lean_lds); }
+typedef __attribute__((address_space(3))) RmLds *   lds_rmlds_ptr;
+typedef __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+
+constexpr uintptr_t kLdsBase = 16;
+__device__ __forceinline__ RmLds &lean_lds() { return *(RmLds *) (lds_rmlds_ptr) kLdsBase; }
+
+__device__ __forceinline__ void lean_lds_check()
+{        // (through an empty asm: the compiler must not reason about the comparison)
+	uint32_t base = (uint32_t) reinterpret_cast<uintptr_t>(s_lean_lds);
+	asm volatile("" : "+s"(base));
+	if (base != 0u)
+		__builtin_trap();
+}
+
+// workgroup-wide "any": one flag word per wave at the start of the segment (before the tables are staged there), two barriers
+__device__ __forceinline__ bool wg_any(bool pred)
+{
+	uint32_t *flags = (uint32_t *) (lds_u32_ptr) kLdsBase;
+	const bool mine = __builtin_amdgcn_ballot_w64(pred) != 0ull;
+	if ((threadIdx.x & 63u) == 0u)
+		flags[threadIdx.x >> 6] = mine ? 1u : 0u;
+	__syncthreads();
+	const uint32_t nw  = blockDim.x >> 6;        // 4 in the product; the lab builds workgroups of 1 and 2 waves
+	const uint4    f   = *reinterpret_cast<const uint4 *>(flags);
+	const bool     any = (f.x | (nw > 1u ? f.y : 0u) | (nw > 2u ? f.z : 0u) | (nw > 3u ? f.w : 0u)) != 0u;
+	__syncthreads();
+	return any;
+}
 
 // LDS copy of the two-level per-axis address tables (behind RmLds; ~1.5 KB):
 // words [0, 32) x position inside a macro-brick, [32, 64) y, [64, 96) z; then the macro-brick terms: x at word 96, y at A.lut_y,
 // z (64-bit, already an address inside the packed image) at A.lut_z.
-#define s_addr_lut (s_lean_lds + sizeof(RmLds) / 4)
+#define s_addr_lut ((uint32_t *) (lds_u32_ptr) (kLdsBase + sizeof(RmLds)))
 constexpr uint32_t kLutXm = 96;
 
 __device__ __forceinline__ void stage_addr_lut(const RayMarchArgs &A)
@@ -1605,12 +1635,12 @@ __host__ __device__ __forceinline__ size_t full_lut_bytes(int W, int H, int D) {
 // transfer function is not separable)
 __host__ __forceinline__ size_t lean_lds_bytes(int kind, uint32_t lut_words, int W, int H, int D)
 {
-	const size_t two_level = sizeof(RmLds) + (size_t) lut_words * 4;
+	const size_t two_level = kLdsBase + sizeof(RmLds) + (size_t) lut_words * 4;
 	if (kind == 0)
-		return sizeof(RmLds);
+		return kLdsBase + sizeof(RmLds);
 	if (kind == 1)
 		return two_level;
-	const size_t full_end = (size_t) kFullLutWord * 4 + full_lut_bytes(W, H, D);
+	const size_t full_end = kLdsBase + (size_t) kFullLutWord * 4 + full_lut_bytes(W, H, D);
 	return two_level > full_end ? two_level : full_end;
 }
 
@@ -2076,7 +2106,7 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 		uint32_t       npx, npy, no;
 		const bool     nin = block_pixel<1>(A, k * A.blocks_per_tile + sb, threadIdx.x, npx, npy, no);
 		const uint32_t key = nin ? min((uint32_t) A.pixel_cost[no], 63u) : 0u;
-		if (__syncthreads_or(key != 0u))
+		if (wg_any(key != 0u))
 		{
 			if (threadIdx.x < 64)
 				hist[threadIdx.x] = 0u;
@@ -2118,7 +2148,7 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 	}
 	uint32_t iter = 0;
 	// 60 % of the workgroups of a frame hold no ray that enters the volume: they skip the LDS tables (and their barrier) altogether
-	if (__syncthreads_or(marched ? 1 : 0))
+	if (wg_any(marched))
 	{
 		if ((LF & kLeanLut) != 0 && PACKED && GRAD != 2)
 		{        // before the barrier of stage_tables_er
@@ -2166,9 +2196,12 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 	}
 }
 
+// (the single-frame kernel is not held to 64 VGPRs like the batch kernel below: one frame at a time is bound by the longest wave's
+// dependent chain, not by the number of resident waves, and at 64 the march loop of some instantiations spills)
 template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) k_raymarch_lean(const RayMarchArgs A)
+__global__ void __launch_bounds__(256) k_raymarch_lean(const RayMarchArgs A)
 {
+	lean_lds_check();
 	RmLds &L = lean_lds();
 	lean_block<SKIP, ERT, GRAD, PACKED, LF>(A, blockIdx.x, L);
 }
@@ -2177,9 +2210,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) k
 // frames advance side by side and the long tail of each (a few waves with hundreds of dependent events) is covered by the bulk
 // of the others — what a renderer with frames in flight gets from several queues, without depending on queue scheduling.
 // The argument blocks live in device memory (n x 1.7 KB does not fit the kernel-argument segment).
+// held to 64 VGPRs = 8 waves per SIMD (the fast ray set-up first came out at 66: seven waves, 10 % slower with frames in flight); the
+// on-the-fly gradient variant (five trilinear taps per sample, ~100 VGPRs) keeps its registers
 template <int SKIP, bool ERT, int GRAD, uint32_t LF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) k_raymarch_lean_batch(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t groups_per_frame)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD == 2 ? 4 : 8))) k_raymarch_lean_batch(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t groups_per_frame)
 {
+	lean_lds_check();
 	RmLds &        L = lean_lds();
 	const uint32_t g = blockIdx.x >> 3;
 	// groups_per_frame == 0: frames interleaved in groups of eight workgroups; otherwise one frame after the other (A/B switch of the launcher)
@@ -2281,6 +2317,7 @@ __device__ __forceinline__ void pull_units(const RayMarchArgs *__restrict__ fram
 template <int SKIP, bool ERT, int GRAD, uint32_t LF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_raymarch_lean_pull(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t *__restrict__ heads)
 {
+	lean_lds_check();
 	RmLds &             L  = lean_lds();
 	const RayMarchArgs &A0 = frames[0];
 	if ((LF & kLeanLut) != 0 && GRAD != 2)
