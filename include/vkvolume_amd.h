@@ -321,7 +321,9 @@ int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_transfer_function,
  * launch takes from the context: the stream's scratch block, the address tables of the packed image's extent, the tile start order of the
  * schedule; uploads are waited for before it returns.  A launch that finds one of them missing still creates it on the fly out of the
  * arena with an asynchronous upload on its own stream (no device-wide wait; if the arena is exhausted the launch runs without the table:
- * plain tile order / address arithmetic in registers, same bits) - vkv_prepare_render only moves that work to set-up time. */
+ * plain tile order / address arithmetic in registers, same bits) - vkv_prepare_render only moves that work to set-up time.  Call it
+ * before capturing `stream` into a hipGraph: a launch that still has to create a table records and queries an event, which a capture
+ * does not allow. */
 int vkv_prepare_render(vkv_ctx *ctx, const VkvRenderParams *params, uint32_t count, void *stream);
 
 /* Start-order and ray-order feedback need device state per render target (one uint32 cost and one uint32 order entry per tile of the
@@ -331,7 +333,8 @@ int vkv_prepare_render(vkv_ctx *ctx, const VkvRenderParams *params, uint32_t cou
  *   tile schedule `tiles` into `d_target` (the d_out_rgba8 or, without one, d_out_color pointer of the parameter block).  Targets that
  *   were never registered are rendered in the centre-first order: vkv_render never allocates.  Registering a target again replaces
  *   its state (waits for the device first, like vkv_forget_target).
- * vkv_forget_target - set-up call: waits for the device (launches that still use the state), then frees it. */
+ * vkv_forget_target - set-up call: waits for the device (launches that still use the state), then frees it.  Like freeing the target
+ *   itself, it must not run concurrently with a render into that target from another thread. */
 int vkv_register_target(vkv_ctx *ctx, const void *d_target, uint32_t image_width, uint32_t image_height, const VkvTileSchedule *tiles);
 int vkv_forget_target(vkv_ctx *ctx, const void *d_target);
 

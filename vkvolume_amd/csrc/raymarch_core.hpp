@@ -2210,10 +2210,12 @@ __global__ void __launch_bounds__(256) k_raymarch_lean(const RayMarchArgs A)
 // frames advance side by side and the long tail of each (a few waves with hundreds of dependent events) is covered by the bulk
 // of the others — what a renderer with frames in flight gets from several queues, without depending on queue scheduling.
 // The argument blocks live in device memory (n x 1.7 KB does not fit the kernel-argument segment).
-// held to 64 VGPRs = 8 waves per SIMD (the fast ray set-up first came out at 66: seven waves, 10 % slower with frames in flight); the
-// on-the-fly gradient variant (five trilinear taps per sample, ~100 VGPRs) keeps its registers
+// held to 64 VGPRs = 8 waves per SIMD (the fast ray set-up first came out at 66: seven waves, 10 % slower with frames in flight: 0.1246
+// against 0.1101 ms per C3 frame).  Not the on-the-fly gradient variant (five trilinear taps per sample, ~100 VGPRs: it would spill) and
+// not the kernels without empty-space skipping (45 VGPRs anyway, but the occupancy target changes their schedule: dense sampling with 8
+// frames per launch 2.63 against 2.14 ms per frame)
 template <int SKIP, bool ERT, int GRAD, uint32_t LF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GRAD == 2 ? 4 : 8))) k_raymarch_lean_batch(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t groups_per_frame)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((GRAD == 2 || SKIP == VKV_SKIP_NONE) ? 1 : 8))) k_raymarch_lean_batch(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t groups_per_frame)
 {
 	lean_lds_check();
 	RmLds &        L = lean_lds();
