@@ -1,4 +1,4 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3d; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_precompute; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_pre -- python3 $R/tools/time_precompute.py ${1:-c3} > $O/precompute_${1:-c3}.txt 2>&1
 cat $O/precompute_${1:-c3}.txt | tail -14
