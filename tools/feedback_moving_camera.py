@@ -18,6 +18,9 @@ sp = V.VolumeRenderSubpass(ctx, v, abi.RenderOptions(skipping_type=skip, clip_di
 streams = [torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()]
 n, launches = 7, 120
 bufs = [[torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(n)] for _ in range(3)]
+for row in bufs:
+    for t in row:
+        ctx.register_target(t.data_ptr(), (fw, fh), abi.full_frame_tiles(fw, fh))  # the per-target feedback state (vkv_render* never allocate)
 # parameter blocks prepared ahead (the uniforms are host work outside the timed loop)
 plists = []
 for l in range(launches):

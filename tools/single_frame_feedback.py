@@ -12,6 +12,8 @@ radius = 1.5 * 0.5 * math.sqrt(sum(float(np.linalg.norm(m[:, i])) ** 2 for i in 
 proj = camera.perspective_vulkan(60.0, fw / fh, 0.1, 1000.0)
 sp = V.VolumeRenderSubpass(ctx, v, abi.RenderOptions(skipping_type=skip, clip_distance=1.0, early_ray_termination=True), (fw, fh))
 bufs = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(8)]
+for _t in bufs:
+    ctx.register_target(_t.data_ptr(), (fw, fh), abi.full_frame_tiles(fw, fh))  # feedback state of the targets
 ps = []
 for j in range(8):
     q = sp.make_params(camera.orbit_camera(45.0 * j, 20.0, radius), proj)

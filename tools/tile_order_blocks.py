@@ -60,6 +60,8 @@ def timed(orders_by_view, reps=150):
 
 # costs per view from traced 8-frame launches of the 8 views
 bufs8 = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(8)]
+for _t in bufs8:
+    ctx.register_target(_t.data_ptr(), (fw, fh), abi.full_frame_tiles(fw, fh))  # feedback state of the targets (the library-feedback rows)
 p8 = []
 for j in range(8):
     q = sp.make_params(*views[j])
