@@ -216,6 +216,8 @@ def main():
     ap.add_argument("--verify-cpu", action="store_true", help="(default since round 3; kept for old command lines) compare the CPU oracle's pixels with the device's")
     ap.add_argument("--no-verify-cpu", action="store_true", help="do not compare the pixels the CPU baseline rendered (counters + RGBA8) with the device's frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-depth-block", action="store_true", help="skip the extra block that also writes gl_FragDepth (ms_per_step_with_depth): the rocprofv3 "
+                    "passes of tools/collect_profiles.sh use it so that the kernel's averages hold the headline launches only")
     ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 without WORLD_SIZE: print the torch.distributed.run command line the "
                     "parent would start, and exit")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
@@ -340,7 +342,7 @@ def main():
     # the same parameter blocks with gl_FragDepth written as well (frag:315-321; the reference's subpass always writes depth): timed in a
     # block of its own after the headline blocks, reported as ms_per_step_with_depth
     depth_bufs, batch_params_depth = None, None
-    if submit == "batch" and not use_gather:
+    if submit == "batch" and not use_gather and not args.no_depth_block:
         depth_bufs = [torch.zeros((fh, fw), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
         batch_params_depth = []
         for view_i in range(N_VIEWS):
