@@ -137,8 +137,10 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
 	}
 	const uint32_t *vol32 = reinterpret_cast<const uint32_t *>(vol);
 	const size_t    plane = (size_t) H * (size_t) wd;
-	uint32_t        v[kIter];
-	auto            fetch_edge = [&](uint32_t k) {
+	// TWO tiles of loads are in flight (register sets va, vb): the tile after next is requested as soon as the current one has been
+	// staged, so a load has two tiles' worth of arithmetic (~2 x 5 us) to come back instead of one
+	uint32_t        va[kIter], vb[kIter];
+	auto            fetch_edge = [&](uint32_t k, uint32_t(&v)[kIter]) {
 #pragma unroll
 		for (int j = 0; j < kIter; ++j)
 		{
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
 	for (int j = 0; j < kIter; ++j)
 		voff[j] = (uint32_t) (((size_t) (rz[j] + 1) * plane + (size_t) off_xy[j]) * 4u);
 	const bool inner_x = x0 > 0 && x0 + kGradTileX + 4 <= W;
-	auto       fetch   = [&](uint32_t k) {
+	auto       fetch   = [&](uint32_t k, uint32_t(&v)[kIter]) {
         if (inner_x && k > 0 && (int) (k + 1) * kGradTileZ < D)
         {
             const uint8_t *base = vol + ((size_t) k * kGradTileZ - 1) * plane * 4u;
@@ -168,25 +170,26 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
             }
         }
         else
-            fetch_edge(k);
+            fetch_edge(k, v);
 	};
-	fetch(k0);
+	fetch(k0, va);
+	if (k0 + 1 < k1)
+		fetch(k0 + 1, vb);
 	const int      lx = threadIdx.x & 63, x = x0 + lx, ly0 = (int) (threadIdx.x >> 6) * 2;        // lane = x, each wave two y rows, all z
 	const uint32_t off = (uint32_t) (y0 + ly0) * (uint32_t) W + (uint32_t) x, off1 = off + (uint32_t) W;        // inside one z slice (< 2^32 voxels)
 	constexpr int  sy = kGradPitch, sz = (kGradTileY + 2) * kGradPitch;
 	// position of texel i of a row in the tile (0, 2, 1, 3 within every four), for the lane's x - 1 and x + 1; texel x sits at column x - x0 + 4
 	auto      column = [](int i) { return (i & ~3) | ((i & 1) << 1) | ((i >> 1) & 1); };
 	const int cm = column(4 + lx - 1), cp = column(4 + lx + 1);
-	for (uint32_t k = k0; k < k1; ++k)
-	{
+	auto      tile = [&](uint32_t k, uint32_t(&v)[kIter]) {
 		__syncthreads();        // the previous tile has been read by everyone
 #pragma unroll
 		for (int j = 0; j < kIter; ++j)
 			if ((int) threadIdx.x + 256 * j < kRows * kCols)
 				reinterpret_cast<uint2 *>(s_tile)[threadIdx.x + 256 * j] = make_uint2((v[j] & 0x00ff00ffu) << 2, (v[j] & 0xff00ff00u) >> 6);
 		__syncthreads();
-		if (k + 1 < k1)
-			fetch(k + 1);        // in flight during the arithmetic below
+		if (k + 2 < k1)
+			fetch(k + 2, v);        // this register set is free again: the tile after next, in flight during two tiles of arithmetic
 		const int z0 = (int) k * kGradTileZ;
 		// the four taps of TWO voxels (rows ly0, ly0 + 1 of slice lz; k.xyy, k.yyx, k.yxy, k.xxx of get_gradient_compute.glsl:8-11): all reads
 		// of a stage are issued before the first is used
@@ -241,6 +244,12 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
 					gz[off1] = (uint8_t) finish(b);
 				gz += (size_t) W * (size_t) H;
 			}
+	};
+	for (uint32_t k = k0; k < k1; k += 2)
+	{
+		tile(k, va);
+		if (k + 1 < k1)
+			tile(k + 1, vb);
 	}
 }
 
