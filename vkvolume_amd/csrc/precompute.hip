@@ -100,6 +100,8 @@ __device__ __forceinline__ void store_u8_uniform_base(uint8_t *base, uint32_t of
 	asm volatile("global_store_byte %0, %1, %2" : : "v"(off), "v"(value), "s"(base) : "memory");
 }
 
+// (Measured in round 3 and dropped: TWO tiles of loads in flight - the tile after next requested as soon as the current one is staged:
+// 0.670 against 0.654 ms on C3, 6.88 against 6.84 on C4: the loads are not what the arithmetic waits for.)
 // A workgroup MARCHES along z over `seg` consecutive tiles with the next tile's dwords already in flight (held in registers) while the
 // current one is computed: a workgroup that loads, waits, computes and leaves keeps too few bytes in flight per CU to cover the HBM
 // latency (measured on the one-tile-per-workgroup kernel: neither the VALU nor the LDS busy more than half the time; 0.96 -> 0.85 ms
@@ -137,10 +139,8 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
 	}
 	const uint32_t *vol32 = reinterpret_cast<const uint32_t *>(vol);
 	const size_t    plane = (size_t) H * (size_t) wd;
-	// TWO tiles of loads are in flight (register sets va, vb): the tile after next is requested as soon as the current one has been
-	// staged, so a load has two tiles' worth of arithmetic (~2 x 5 us) to come back instead of one
-	uint32_t        va[kIter], vb[kIter];
-	auto            fetch_edge = [&](uint32_t k, uint32_t(&v)[kIter]) {
+	uint32_t        v[kIter];
+	auto            fetch_edge = [&](uint32_t k) {
 #pragma unroll
 		for (int j = 0; j < kIter; ++j)
 		{
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
 	for (int j = 0; j < kIter; ++j)
 		voff[j] = (uint32_t) (((size_t) (rz[j] + 1) * plane + (size_t) off_xy[j]) * 4u);
 	const bool inner_x = x0 > 0 && x0 + kGradTileX + 4 <= W;
-	auto       fetch   = [&](uint32_t k, uint32_t(&v)[kIter]) {
+	auto       fetch   = [&](uint32_t k) {
         if (inner_x && k > 0 && (int) (k + 1) * kGradTileZ < D)
         {
             const uint8_t *base = vol + ((size_t) k * kGradTileZ - 1) * plane * 4u;
@@ -170,26 +170,25 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
             }
         }
         else
-            fetch_edge(k, v);
+            fetch_edge(k);
 	};
-	fetch(k0, va);
-	if (k0 + 1 < k1)
-		fetch(k0 + 1, vb);
+	fetch(k0);
 	const int      lx = threadIdx.x & 63, x = x0 + lx, ly0 = (int) (threadIdx.x >> 6) * 2;        // lane = x, each wave two y rows, all z
 	const uint32_t off = (uint32_t) (y0 + ly0) * (uint32_t) W + (uint32_t) x, off1 = off + (uint32_t) W;        // inside one z slice (< 2^32 voxels)
 	constexpr int  sy = kGradPitch, sz = (kGradTileY + 2) * kGradPitch;
 	// position of texel i of a row in the tile (0, 2, 1, 3 within every four), for the lane's x - 1 and x + 1; texel x sits at column x - x0 + 4
 	auto      column = [](int i) { return (i & ~3) | ((i & 1) << 1) | ((i >> 1) & 1); };
 	const int cm = column(4 + lx - 1), cp = column(4 + lx + 1);
-	auto      tile = [&](uint32_t k, uint32_t(&v)[kIter]) {
+	for (uint32_t k = k0; k < k1; ++k)
+	{
 		__syncthreads();        // the previous tile has been read by everyone
 #pragma unroll
 		for (int j = 0; j < kIter; ++j)
 			if ((int) threadIdx.x + 256 * j < kRows * kCols)
 				reinterpret_cast<uint2 *>(s_tile)[threadIdx.x + 256 * j] = make_uint2((v[j] & 0x00ff00ffu) << 2, (v[j] & 0xff00ff00u) >> 6);
 		__syncthreads();
-		if (k + 2 < k1)
-			fetch(k + 2, v);        // this register set is free again: the tile after next, in flight during two tiles of arithmetic
+		if (k + 1 < k1)
+			fetch(k + 1);        // in flight during the arithmetic below
 		const int z0 = (int) k * kGradTileZ;
 		// the four taps of TWO voxels (rows ly0, ly0 + 1 of slice lz; k.xyy, k.yyx, k.yxy, k.xxx of get_gradient_compute.glsl:8-11): all reads
 		// of a stage are issued before the first is used
@@ -244,12 +243,6 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
 					gz[off1] = (uint8_t) finish(b);
 				gz += (size_t) W * (size_t) H;
 			}
-	};
-	for (uint32_t k = k0; k < k1; k += 2)
-	{
-		tile(k, va);
-		if (k + 1 < k1)
-			tile(k + 1, vb);
 	}
 }
 
