@@ -2130,7 +2130,7 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 			perm[atomicAdd(&hist[bin], 1u)] = threadIdx.x;
 			__syncthreads();
 			rb = perm[threadIdx.x];
-			// (the tables are staged behind the __syncthreads_or below: every lane has read its entry by then)
+			// (the tables are staged behind the barriers of wg_any(marched) below: every lane has read its entry by then)
 		}
 	}
 	const bool     inside = block_pixel<1>(A, k * A.blocks_per_tile + sb, rb, px, py, o);
