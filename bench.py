@@ -130,12 +130,18 @@ B_OUT = 4  # bytes per ray of the RGBA8 frame
 
 
 def kernel_source_digest():
-    """sha256 over the integrator's source files: ties profiles/*_traffic.json to the kernel it was measured on"""
+    """sha256 over the integrator's source files with comments and whitespace removed: ties profiles/*_traffic.json to the kernel CODE it
+    was measured on (a comment edit does not invalidate a measurement)"""
     import hashlib
+    import re
     h = hashlib.sha256()
     for name in ("raymarch_core.hpp", "raymarch.hip", "vkv_device.hpp", "Makefile"):
-        with open(os.path.join(ROOT, "vkvolume_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, "vkvolume_amd", "csrc", name), "r", errors="replace") as f:
+            text = f.read()
+        if not name.endswith("Makefile"):
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", "", text)
+        h.update(re.sub(r"\s+", "", text).encode())
     return h.hexdigest()
 
 

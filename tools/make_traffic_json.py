@@ -10,7 +10,7 @@ GRBM_GUI_ACTIVE over the 8 XCDs).  It prices every wave instruction at 4 cycles;
 in 2.4 - 2.9 (tools/micro/valu_mix.hip), so the figure is an upper bound of the SIMDs' busy share - read it as "the VALU is the pipe that
 is full", next to SQ_INSTS_VALU per launch.
 The file names the integrator sources it was measured on (sha256 over raymarch_core.hpp, raymarch.hip, vkv_device.hpp, Makefile: bench.py
-recomputes it and withholds the figures when the tree differs)."""
+recomputes it and withholds the figures when the tree differs; comments and whitespace do not count)."""
 import collections
 import csv
 import glob
@@ -36,10 +36,8 @@ def main():
     out_dir, rnd = sys.argv[1], sys.argv[2]
     kernel = "k_raymarch_lean_batch"
     avg, n = averages(os.path.join(out_dir, "pmc_batch8_*"), kernel)
-    import hashlib
-    h = hashlib.sha256()
-    for name in ("raymarch_core.hpp", "raymarch.hip", "vkv_device.hpp", "Makefile"):
-        h.update(open(os.path.join(ROOT, "vkvolume_amd", "csrc", name), "rb").read())
+    import bench
+    digest = bench.kernel_source_digest()
     commit = open(os.path.join(ROOT, ".commit_id")).read().strip() if os.path.exists(os.path.join(ROOT, ".commit_id")) else None
     fetch, write = avg.get("FETCH_SIZE"), avg.get("WRITE_SIZE")
     valu = None
@@ -52,7 +50,7 @@ def main():
         "traffic_bytes_per_launch": int((fetch * 2 + write) * 1024) if fetch and write else None,
         "valu_busy": round(valu, 4) if valu else None,
         "counters_avg": {k: round(v, 1) for k, v in sorted(avg.items())}, "launches_averaged": n,
-        "kernel_source_sha256": h.hexdigest(), "commit": commit,
+        "kernel_source_sha256": digest, "commit": commit,
         "source": "profiles/%s_rocprof.txt" % os.path.basename(out_dir.rstrip("/")),
     }, indent=1))
 
