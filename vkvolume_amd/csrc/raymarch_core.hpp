@@ -1507,16 +1507,19 @@ __device__ __forceinline__ float cvt_ubyte3(uint32_t q) { float f; asm("v_cvt_f3
 // packed_filter with every byte converted by v_cvt_f32_ubyteN and the differences taken in float (exact either way: both operands are
 // integers below 256): the compiler's integer-subtract + v_cvt_f32_i32 form costs two half-rate instructions per difference, this one
 // a half-rate conversion and a full-rate subtraction
-template <bool WANT_G>
+// TABLE: the results come out as value * 1024 (byte offset scale of the 256-entry float tables) - ONE multiplication by kInv255 * 1024,
+// which is the same float as (x * kInv255) * 1024: scaling by a power of two is exact and nothing here is near the subnormal range
+template <bool WANT_G, bool TABLE = false>
 __device__ __forceinline__ void packed_filter_cvt(uint32_t q00, uint32_t q10, uint32_t q01, uint32_t q11, float wx, float wy, float wz, float &out_v, float &out_g)
 {
+	constexpr float kScale = TABLE ? kInv255 * 1024.0f : kInv255;
 	{
 		const float b000 = cvt_ubyte0(q00), b100 = cvt_ubyte2(q00), b010 = cvt_ubyte0(q10), b110 = cvt_ubyte2(q10);
 		const float b001 = cvt_ubyte0(q01), b101 = cvt_ubyte2(q01), b011 = cvt_ubyte0(q11), b111 = cvt_ubyte2(q11);
 		const float c00 = __builtin_fmaf(wx, b100 - b000, b000), c10 = __builtin_fmaf(wx, b110 - b010, b010);
 		const float c01 = __builtin_fmaf(wx, b101 - b001, b001), c11 = __builtin_fmaf(wx, b111 - b011, b011);
 		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
-		out_v = __builtin_fmaf(wz, c1 - c0, c0) * kInv255;
+		out_v = __builtin_fmaf(wz, c1 - c0, c0) * kScale;
 	}
 	if (WANT_G)
 	{
@@ -1525,19 +1528,21 @@ __device__ __forceinline__ void packed_filter_cvt(uint32_t q00, uint32_t q10, ui
 		const float c00 = __builtin_fmaf(wx, b100 - b000, b000), c10 = __builtin_fmaf(wx, b110 - b010, b010);
 		const float c01 = __builtin_fmaf(wx, b101 - b001, b001), c11 = __builtin_fmaf(wx, b111 - b011, b011);
 		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
-		out_g = __builtin_fmaf(wz, c1 - c0, c0) * kInv255;
+		out_g = __builtin_fmaf(wz, c1 - c0, c0) * kScale;
 	}
 }
 
 // the gradient channel alone (bytes 1 and 3 of the x-pair dwords)
+template <bool TABLE = false>
 __device__ __forceinline__ void packed_filter_g(uint32_t q00, uint32_t q10, uint32_t q01, uint32_t q11, float wx, float wy, float wz, float &out_g)
 {
+	constexpr float kScale = TABLE ? kInv255 * 1024.0f : kInv255;
 	const float b000 = cvt_ubyte1(q00), b100 = cvt_ubyte3(q00), b010 = cvt_ubyte1(q10), b110 = cvt_ubyte3(q10);
 	const float b001 = cvt_ubyte1(q01), b101 = cvt_ubyte3(q01), b011 = cvt_ubyte1(q11), b111 = cvt_ubyte3(q11);
 	const float c00 = __builtin_fmaf(wx, b100 - b000, b000), c10 = __builtin_fmaf(wx, b110 - b010, b010);
 	const float c01 = __builtin_fmaf(wx, b101 - b001, b001), c11 = __builtin_fmaf(wx, b111 - b011, b011);
 	const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
-	out_g = __builtin_fmaf(wz, c1 - c0, c0) * kInv255;
+	out_g = __builtin_fmaf(wz, c1 - c0, c0) * kScale;
 }
 
 // The LDS of the lean kernels is ONE dynamic segment whose layout the launcher sizes (lean_lds_bytes): RmLds at its start, behind it
@@ -1864,18 +1869,18 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			const char *ai_tab = reinterpret_cast<const char *>(L.s.ai), *ag_tab = reinterpret_cast<const char *>(L.s.ag);
 			float       g_unused;
 			if (GRAD == 1 && !kGradSkip)
-				packed_filter_cvt<true>(q00, q10, q01, q11, wx, wy, wz, intensity, gradient);
+				packed_filter_cvt<true, true>(q00, q10, q01, q11, wx, wy, wz, intensity, gradient);
 			else
-				packed_filter_cvt<false>(q00, q10, q01, q11, wx, wy, wz, intensity, g_unused);
-			const float ai = *reinterpret_cast<const float *>(ai_tab + ((uint32_t) (int) (intensity * 1024.0f) & ~3u));
+				packed_filter_cvt<false, true>(q00, q10, q01, q11, wx, wy, wz, intensity, g_unused);
+			const float ai = *reinterpret_cast<const float *>(ai_tab + ((uint32_t) (int) intensity & ~3u));        // intensity, gradient: * 1024 here
 			float       ag = GRAD == 0 ? L.s.ag[255] : 0.0f;
 			// most samples behind a probe are still empty voxels (intensity below the window): when that holds for every sampling lane of
 			// the wave the gradient channel is not needed (ai == 0 makes the alpha byte 0 whatever ag is)
 			if (GRAD == 1 && (!kGradSkip || __builtin_amdgcn_ballot_w64(ai > 0.0f) != 0ull))
 			{
 				if (kGradSkip)
-					packed_filter_g(q00, q10, q01, q11, wx, wy, wz, gradient);
-				ag = *reinterpret_cast<const float *>(ag_tab + ((uint32_t) (int) (gradient * 1024.0f) & ~3u));
+					packed_filter_g<true>(q00, q10, q01, q11, wx, wy, wz, gradient);
+				ag = *reinterpret_cast<const float *>(ag_tab + ((uint32_t) (int) gradient & ~3u));
 			}
 			ab              = (uint32_t) ((ai * ag) * 255.0f);        // <= 255: ai, ag <= 1 (k_tf_tables_init)
 			const float2 pr = L.s.pair[ab];
