@@ -72,6 +72,8 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 		case 20: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb>(a, s);
 		case 21: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI>(a, s);
 		case 22: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanFloatCell>(a, s);
+		case 24: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanFmt>(a, s);
+		case 25: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanFmt | kLeanFmtVec>(a, s);
 		case 23: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanPrefetch>(a, s);
 		case 17: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanFull>(a, s);
 		case 6: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanLut | kLeanBranch | kLeanCvt>(a, s);
@@ -130,5 +132,7 @@ extern "C" int vkv_lab_render(vkv_ctx *ctx, const VkvRenderParams *P, int varian
 		return dispatch<VKV_SKIP_DISTANCE, true, 1>(a, variant, (hipStream_t) stream);
 	if (P->options.skipping_type == VKV_SKIP_NONE && !ert)
 		return dispatch<VKV_SKIP_NONE, false, 1>(a, variant, (hipStream_t) stream);
+	if (P->options.skipping_type == VKV_SKIP_BLOCK && ert)
+		return dispatch<VKV_SKIP_BLOCK, true, 1>(a, variant, (hipStream_t) stream);
 	return -102;
 }

@@ -1451,6 +1451,18 @@ __device__ __forceinline__ T undefined_value()
 	return x;
 }
 
+// A wave-uniform float the march loop reads in every iteration, kept in a SCALAR register: v_readfirstlane moves it there and the empty asm
+// stops the compiler from re-deriving it in the loop (in the batch kernel the arguments sit in memory: it would re-load and re-convert
+// them).  A VALU instruction reads one scalar operand for free, and the ten or so uniform operands of the loop then stop counting
+// against the 64 vector registers that 8 waves per SIMD allow.
+__device__ __forceinline__ float uniform_f32(float x)
+{        // the empty asm hides from the compiler that x is uniform already (it would fold the readfirstlane away and leave the value in
+	 // its VGPR); the move itself is the builtin, so that the compiler's own hazard and wait-count tracking covers it (a v_readfirstlane
+	 // written as inline asm rendered BLOCK-mode frames wrong, differently from run to run)
+	asm volatile("" : "+v"(x));
+	return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+
 __device__ __forceinline__ float max_f32_raw(float a, float b)
 {        // v_max_f32 without the canonicalisation fmaxf puts in front of it (both operands are ordinary numbers here)
 	float r;
@@ -1494,6 +1506,11 @@ constexpr uint32_t kLeanFloatCell = 8192u;   // cell coordinates clamped in floa
 constexpr uint32_t kLeanPrefetch = 16384u;   // a lane that samples position i while its previous sample was occupied also requests the footprint of i + 1 (the
                                              // next event if this sample is occupied too); used an iteration later if the prediction held, dropped otherwise.
                                              // Shortens the dependent chain of one wave, costs address arithmetic for every wrong prediction
+constexpr uint32_t kLeanFmt     = 32768u;    // with kLeanFull + kLeanTf: the x-pair rows come through FORMAT loads (buffer_load_format_d16_xyzw, 8_8_8_8 USCALED: the
+                                             // texture path hands back the four bytes as f16, exact at any byte alignment and cheaper on the address path than a dword
+                                             // gather - tools/micro/typed_gather.hip) and the x stage of the filter is v_pk_add_f16 + v_fma_mix_f32: 12 instructions
+                                             // where the byte conversions took 24.  The packed image must be below 4 GiB (32-bit buffer offsets)
+constexpr uint32_t kLeanFmtVec  = 65536u;    // kLeanFmt with the uniform loop operands left in vector registers (the kernels that are not held to 64 VGPRs)
 constexpr uint32_t kLeanDefault = 1u | 8u | 16u;        // kLeanUniform | kLeanBranch | kLeanCvt: what the product launches (+ kLeanLut when the tables fit)
 constexpr size_t   kMaxLutBytes = 8 * 1024;           // LDS budget of the address tables (1.2 KB at 1024 voxels per axis, 1.9 KB at 2048)
 constexpr uint32_t kLeanCvt     = 16u;       // cost-aware instruction selection (tools/micro/valu_mix.hip): float subtraction of two converted bytes
@@ -1543,6 +1560,59 @@ __device__ __forceinline__ void packed_filter_g(uint32_t q00, uint32_t q10, uint
 	const float c01 = __builtin_fmaf(wx, b101 - b001, b001), c11 = __builtin_fmaf(wx, b111 - b011, b011);
 	const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
 	out_g = __builtin_fmaf(wz, c1 - c0, c0) * kScale;
+}
+
+// ---- kLeanFmt: rows as f16 quadruples (v0, g0, v1, g1) from a buffer FORMAT load ---------------------------------------------------
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef int      int4v __attribute__((ext_vector_type(4)));
+__device__ half4v vkv_buffer_load_format_h4(int4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f16");
+
+// buffer resource of the packed image: raw (stride 0), 4 GiB window, dst_sel RGBA, USCALED 8_8_8_8 (gfx9 V# word 3)
+__device__ __forceinline__ int4v packed_rows_rsrc(const uint8_t *base)
+{
+	const uint64_t a = reinterpret_cast<uint64_t>(base);
+	int4v          r;
+	r.x = __builtin_amdgcn_readfirstlane((int) (uint32_t) a);
+	r.y = __builtin_amdgcn_readfirstlane((int) (uint32_t) ((a >> 32) & 0xffffu));
+	r.z = -1;
+	r.w = (int) (0xFACu | (2u << 12) | (10u << 15));
+	return r;
+}
+
+// One channel pair of the x stage: d = (v1 - v0, g1 - g0) in f16 (integers below 256: exact), then c = fma(wx, d, b) with the f16
+// operands widened inside the instruction - the same real numbers the fp32 path multiplies and adds, rounded once: bit-identical.
+__device__ __forceinline__ float fma_mix_lo(float w, half2v d, half2v b)
+{        // fma(w, float(d.x), float(b.x)); the compiler forms it from the plain expression for the low halves only
+	float r;
+	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(d), "v"(b));
+	return r;
+}
+__device__ __forceinline__ float fma_mix_hi(float w, half2v d, half2v b)
+{        // fma(w, float(d.y), float(b.y))
+	float r;
+	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(d), "v"(b));
+	return r;
+}
+
+template <bool WANT_V, bool WANT_G, bool TABLE>
+__device__ __forceinline__ void packed_filter_fmt(half4v h00, half4v h10, half4v h01, half4v h11, float wx, float wy, float wz, float &out_v, float &out_g)
+{
+	constexpr float kScale = TABLE ? kInv255 * 1024.0f : kInv255;
+	const half2v    b00 = {h00.x, h00.y}, b10 = {h10.x, h10.y}, b01 = {h01.x, h01.y}, b11 = {h11.x, h11.y};
+	const half2v    d00 = half2v{h00.z, h00.w} - b00, d10 = half2v{h10.z, h10.w} - b10, d01 = half2v{h01.z, h01.w} - b01, d11 = half2v{h11.z, h11.w} - b11;
+	if (WANT_V)
+	{
+		const float c00 = fma_mix_lo(wx, d00, b00), c10 = fma_mix_lo(wx, d10, b10), c01 = fma_mix_lo(wx, d01, b01), c11 = fma_mix_lo(wx, d11, b11);
+		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
+		out_v = __builtin_fmaf(wz, c1 - c0, c0) * kScale;
+	}
+	if (WANT_G)
+	{
+		const float c00 = fma_mix_hi(wx, d00, b00), c10 = fma_mix_hi(wx, d10, b10), c01 = fma_mix_hi(wx, d01, b01), c11 = fma_mix_hi(wx, d11, b11);
+		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
+		out_g = __builtin_fmaf(wz, c1 - c0, c0) * kScale;
+	}
 }
 
 // The LDS of the lean kernels is ONE dynamic segment whose layout the launcher sizes (lean_lds_bytes): RmLds at its start, behind it
@@ -1673,6 +1743,7 @@ struct FullLutConsts
 	const uint8_t *base;        // the packed image
 };
 
+template <bool SCALAR>
 __device__ __forceinline__ FullLutConsts full_lut_consts(const RayMarchArgs &A)
 {
 	FullLutConsts c;
@@ -1680,7 +1751,10 @@ __device__ __forceinline__ FullLutConsts full_lut_consts(const RayMarchArgs &A)
 	c.base = A.packed;
 	c.oy = (float) (4 * (A.W + 2) + 4);
 	c.oz = (float) (4 * (A.W + 2 + A.H + 2) + 4);
-	asm volatile("" : "+v"(c.w), "+v"(c.h), "+v"(c.d), "+v"(c.oy), "+v"(c.oz));
+	if (SCALAR)        // kLeanFmt: its rows take four more vector registers, the uniform operands move to scalar ones
+		c.w = uniform_f32(c.w), c.h = uniform_f32(c.h), c.d = uniform_f32(c.d), c.oy = uniform_f32(c.oy), c.oz = uniform_f32(c.oz);
+	else
+		asm volatile("" : "+v"(c.w), "+v"(c.h), "+v"(c.d), "+v"(c.oy), "+v"(c.oz));
 	return c;
 }
 
@@ -1697,6 +1771,21 @@ __device__ __forceinline__ const uint8_t *packed_footprint_full(const FullLutCon
 	const uint32_t xo = *reinterpret_cast<const uint32_t *>(lut + tx), yo = *reinterpret_cast<const uint32_t *>(lut + ty);
 	const uint32_t zo = *reinterpret_cast<const uint32_t *>(lut + tz);
 	return C.base + ((uint64_t) ((xo + yo) + zo) << 1);        // the terms are in units of two bytes
+}
+
+// the same footprint as a 32-bit byte offset into the packed image (kLeanFmt: images below 4 GiB)
+__device__ __forceinline__ uint32_t packed_footprint_full_offset(const FullLutConsts &C, const RmLds &L, float px, float py, float pz, float &wx, float &wy, float &wz)
+{
+	const float cx = __builtin_fmaf(px, C.w, -0.5f), cy = __builtin_fmaf(py, C.h, -0.5f), cz = __builtin_fmaf(pz, C.d, -0.5f);
+	const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy), fz = __builtin_floorf(cz);
+	wx = cx - fx, wy = cy - fy, wz = cz - fz;
+	const int      tx = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fx, -1.0f, C.w), 4.0f, 4.0f);
+	const int      ty = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fy, -1.0f, C.h), 4.0f, C.oy);
+	const int      tz = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fz, -1.0f, C.d), 4.0f, C.oz);
+	const char *   lut = reinterpret_cast<const char *>(full_lut_base(L));
+	const uint32_t xo = *reinterpret_cast<const uint32_t *>(lut + tx), yo = *reinterpret_cast<const uint32_t *>(lut + ty);
+	const uint32_t zo = *reinterpret_cast<const uint32_t *>(lut + tz);
+	return ((xo + yo) + zo) << 1;
 }
 
 // A footprint address that comes out of the LDS address tables is an integer: tell the compiler it points to global memory, or it emits
@@ -1727,11 +1816,14 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	constexpr bool kUni = (LF & kLeanUniform) != 0, kNt = (LF & kLeanNt) != 0, kLut = (LF & kLeanLut) != 0, kBranch = (LF & kLeanBranch) != 0,
 	               kCvt = (LF & kLeanCvt) != 0, kNest = (LF & kLeanNest) != 0 && kBranch, kKeep = (LF & kLeanKeep) != 0, kScalar = (LF & kLeanScalar) != 0, kFull = (LF & kLeanFull) != 0 && SEP, kTf = (LF & kLeanTf) != 0 && SEP && kHoist && kCvt,
 	               kGradSkip = (LF & kLeanGradSkip) != 0 && kTf && GRAD == 1, kFloatI = (LF & kLeanFloatI) != 0 && kBranch, kWb = (LF & kLeanWb) != 0,
-	               kFloatCell = (LF & kLeanFloatCell) != 0 && SKIP != VKV_SKIP_NONE, kPrefetch = (LF & kLeanPrefetch) != 0 && kHoist && kNest;
+	               kFloatCell = (LF & kLeanFloatCell) != 0 && SKIP != VKV_SKIP_NONE, kPrefetch = (LF & kLeanPrefetch) != 0 && kHoist && kNest,
+	               kFmt = (LF & kLeanFmt) != 0 && kFull && kTf && !kPrefetch, kFmtScalar = kFmt && (LF & kLeanFmtVec) == 0;
 	using idx_t = std::conditional_t<kFloatI, float, int>;
 	const int   W = A.W, H = A.H, D = A.D;
-	const float kx = SKIP != VKV_SKIP_NONE ? (float) W / A.block_size[0] : 0.0f, ky = SKIP != VKV_SKIP_NONE ? (float) H / A.block_size[1] : 0.0f,
-	            kz = SKIP != VKV_SKIP_NONE ? (float) D / A.block_size[2] : 0.0f;
+	float kx = SKIP != VKV_SKIP_NONE ? (float) W / A.block_size[0] : 0.0f, ky = SKIP != VKV_SKIP_NONE ? (float) H / A.block_size[1] : 0.0f,
+	      kz = SKIP != VKV_SKIP_NONE ? (float) D / A.block_size[2] : 0.0f;
+	if (kFmtScalar && SKIP != VKV_SKIP_NONE)
+		kx = uniform_f32(kx), ky = uniform_f32(ky), kz = uniform_f32(kz);
 	const int   mw1 = A.mw - 1, mh1 = A.mh - 1, md1 = A.md - 1;
 	const float fmw1 = (float) mw1, fmh1 = (float) mh1, fmd1 = (float) md1, fmw = (float) A.mw, fmh = (float) A.mh;
 	float    grey = 0.0f;
@@ -1741,9 +1833,15 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	const float ofx = R.six > 0.0f ? 0.0f : 1.0f, ofy = R.siy > 0.0f ? 0.0f : 1.0f, ofz = R.siz > 0.0f ? 0.0f : 1.0f;
 	FullLutConsts fullc = {};
 	if (kFull)
-		fullc = full_lut_consts(A);
+		fullc = full_lut_consts<kFmtScalar>(A);
+	int4v rows = {};
+	if (kFmt)
+		rows = packed_rows_rsrc(A.packed);
 	idx_t       li = (idx_t) R.i, li_min = (idx_t) R.i_min, lfirst = (idx_t) R.first_hit;
-	const idx_t ln = (idx_t) R.n_steps, lback = (idx_t) A.back;
+	const idx_t ln = (idx_t) R.n_steps;
+	idx_t       lback = (idx_t) A.back;
+	if constexpr (kFloatI && kFmtScalar)
+		lback = uniform_f32(lback);
 	uint32_t pq00 = 0, pq10 = 0, pq01 = 0, pq11 = 0;        // kPrefetch: the footprint of position pf_i, requested one iteration ahead
 	float    pwx = 0, pwy = 0, pwz = 0;
 	idx_t    pf_i = (idx_t) -1;
@@ -1779,6 +1877,9 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 
 		// ---- loads: probe byte first, then the footprint of the sampling lanes ----------------------------------------
 		uint32_t dist = 0, q00 = 0, q10 = 0, q01 = 0, q11 = 0;
+		half4v   h00 = {}, h10 = {}, h01 = {}, h11 = {};
+		if (kFmt)
+			h00 = undefined_value<half4v>(), h10 = undefined_value<half4v>(), h01 = undefined_value<half4v>(), h11 = undefined_value<half4v>();
 		float    wx = 0, wy = 0, wz = 0;
 		if (kNest)
 		{        // every use sits under the predicate of its load: the values of the other lanes are left undefined (no moves)
@@ -1794,7 +1895,15 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		};
 		if (kHoist && !probe)
 		{
-			if (kPrefetch && pf_i == i)
+			if (kFmt)
+			{
+				const int bo = (int) packed_footprint_full_offset(fullc, L, posx, posy, posz, wx, wy, wz);
+				h00 = vkv_buffer_load_format_h4(rows, bo, 0, 0);
+				h10 = vkv_buffer_load_format_h4(rows, bo + 10, 0, 0);
+				h01 = vkv_buffer_load_format_h4(rows, bo + 50, 0, 0);
+				h11 = vkv_buffer_load_format_h4(rows, bo + 60, 0, 0);
+			}
+			else if (kPrefetch && pf_i == i)
 				q00 = pq00, q10 = pq10, q01 = pq01, q11 = pq11, wx = pwx, wy = pwy, wz = pwz;        // requested an iteration ago
 			else
 			{
@@ -1868,7 +1977,14 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		{        // separable transfer function, table addresses straight from the filtered values
 			const char *ai_tab = reinterpret_cast<const char *>(L.s.ai), *ag_tab = reinterpret_cast<const char *>(L.s.ag);
 			float       g_unused;
-			if (GRAD == 1 && !kGradSkip)
+			if (kFmt)
+			{
+				if (GRAD == 1 && !kGradSkip)
+					packed_filter_fmt<true, true, true>(h00, h10, h01, h11, wx, wy, wz, intensity, gradient);
+				else
+					packed_filter_fmt<true, false, true>(h00, h10, h01, h11, wx, wy, wz, intensity, g_unused);
+			}
+			else if (GRAD == 1 && !kGradSkip)
 				packed_filter_cvt<true, true>(q00, q10, q01, q11, wx, wy, wz, intensity, gradient);
 			else
 				packed_filter_cvt<false, true>(q00, q10, q01, q11, wx, wy, wz, intensity, g_unused);
@@ -1878,7 +1994,9 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			// the wave the gradient channel is not needed (ai == 0 makes the alpha byte 0 whatever ag is)
 			if (GRAD == 1 && (!kGradSkip || __builtin_amdgcn_ballot_w64(ai > 0.0f) != 0ull))
 			{
-				if (kGradSkip)
+				if (kGradSkip && kFmt)
+					packed_filter_fmt<false, true, true>(h00, h10, h01, h11, wx, wy, wz, g_unused, gradient);
+				else if (kGradSkip)
 					packed_filter_g<true>(q00, q10, q01, q11, wx, wy, wz, gradient);
 				ag = *reinterpret_cast<const float *>(ag_tab + ((uint32_t) (int) gradient & ~3u));
 			}
