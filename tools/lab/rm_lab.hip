@@ -74,6 +74,7 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 		case 22: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanFloatCell>(a, s);
 		case 24: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanFmt>(a, s);
 		case 25: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanFmt | kLeanFmtVec>(a, s);
+		case 26: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanStamp>(a, s);
 		case 23: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanPrefetch>(a, s);
 		case 17: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanFull>(a, s);
 		case 6: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanLut | kLeanBranch | kLeanCvt>(a, s);

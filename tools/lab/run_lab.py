@@ -171,3 +171,41 @@ if "--stamps" in flags:
         print("  us per iteration (waves >= 32 it): median %.3f" % np.median(dur_us[m] / it[m]))
         print("  cycles per iteration, mean over those waves: addresses %.0f | load issue %.0f | memory wait %.0f | evaluate (filter, TF, skip length) %.0f | replay %.0f" % tuple(ph.mean(0)))
         print("  same, waves with >= 150 iterations:", (t[it >= 150][:, [8, 4, 5, 6, 7]].astype(np.float64) / it[it >= 150, None]).mean(0).round(0) if (it >= 150).any() else None)
+
+if "--lean-stamps" in flags:
+    # variant 26 = the shipped single-frame kernel + s_memtime at the top of every iteration: cycles per iteration by kind, per wave
+    for vi in range(len(params)):
+        p = params[vi]
+        b = bufs()
+        set_outputs(p, b, only_rgba8=True)
+        nwaves = ((p.tiles.tile_count + 7) // 8) * 8 * 4 * 4
+        trace = torch.zeros((nwaves, 10), dtype=torch.int64, device="cuda")
+        for _ in range(2):
+            launch(26, p, cur)
+        torch.cuda.synchronize()
+        L.vkv_debug_trace(ctx.handle, trace.data_ptr())
+        launch(26, p, cur)
+        torch.cuda.synchronize()
+        L.vkv_debug_trace(ctx.handle, None)
+        t = trace.cpu().numpy().astype(np.uint64)
+        t = t[t[:, 1] > 0]
+        it = t[:, 2].astype(np.int64)
+        real_us = (t[:, 1] - t[:, 0]).astype(np.float64) / 100.0
+        clk = (t[:, 7] - t[:, 6]).astype(np.float64)
+        long_ = it >= 32
+        mhz = np.median(clk[long_] / real_us[long_])
+        out = {"view": vi, "waves": int(len(t)), "longest_wave_iterations": int(it.max()), "kernel_span_us": round(float((t[:, 1].max() - t[:, 0].min()) / 100.0), 1),
+               "s_memtime_MHz": round(float(mhz), 1)}
+        for name, col in (("probe_only", 4), ("sample_only", 5), ("mixed", 8)):
+            sums = (t[:, col] & np.uint64(0xffffffff)).astype(np.float64)
+            cnts = (t[:, col] >> np.uint64(32)).astype(np.float64)
+            out[name] = {"iterations": int(cnts.sum()), "ticks_per_iteration_all_waves": round(float(sums.sum() / max(cnts.sum(), 1)), 1),
+                         "ticks_per_iteration_waves_ge_150": round(float(sums[it >= 150].sum() / max(cnts[it >= 150].sum(), 1)), 1) if (it >= 150).any() else None,
+                         "ticks_per_iteration_longest_1pct_waves": round(float(sums[it >= np.percentile(it, 99)].sum() / max(cnts[it >= np.percentile(it, 99)].sum(), 1)), 1)}
+        top = it >= np.percentile(it, 99)
+        out["longest_1pct_waves"] = {"waves": int(top.sum()), "iterations_mean": round(float(it[top].mean()), 1), "ticks_per_iteration_whole_wave": round(float((clk[top] / it[top]).mean()), 1),
+                                     "start_us_after_kernel_start_mean": round(float(((t[top, 0] - t[:, 0].min()).astype(np.float64) / 100.0).mean()), 1)}
+        tot_s = sum((t[:, c] & np.uint64(0xffffffff)).astype(np.float64) for c in (4, 5, 8)); tot_c = sum((t[:, c] >> np.uint64(32)).astype(np.float64) for c in (4, 5, 8))
+        out["check_longest_1pct"] = {"sum_of_counts_over_iterations": round(float((tot_c[top] / it[top]).mean()), 3), "sum_of_ticks_over_wave_ticks": round(float((tot_s[top] / clk[top]).mean()), 3),
+                                     "kind_shares_of_iterations": [round(float(((t[top, c] >> np.uint64(32)).astype(np.float64).sum()) / tot_c[top].sum()), 3) for c in (4, 5, 8)]}
+        print(json.dumps(out), flush=True)

@@ -1511,6 +1511,8 @@ constexpr uint32_t kLeanFmt     = 32768u;    // with kLeanFull + kLeanTf: the x-
                                              // gather - tools/micro/typed_gather.hip) and the x stage of the filter is v_pk_add_f16 + v_fma_mix_f32: 12 instructions
                                              // where the byte conversions took 24.  The packed image must be below 4 GiB (32-bit buffer offsets)
 constexpr uint32_t kLeanFmtVec  = 65536u;    // kLeanFmt with the uniform loop operands left in vector registers (the kernels that are not held to 64 VGPRs)
+constexpr uint32_t kLeanStamp   = 131072u;   // (lab, with the trace buffer) s_memtime at the top of every iteration, summed per wave by the iteration's kind: only
+                                             // probing lanes / only sampling lanes / both (tools/lab/run_lab.py --lean-stamps)
 constexpr uint32_t kLeanDefault = 1u | 8u | 16u;        // kLeanUniform | kLeanBranch | kLeanCvt: what the product launches (+ kLeanLut when the tables fit)
 constexpr size_t   kMaxLutBytes = 8 * 1024;           // LDS budget of the address tables (1.2 KB at 1024 voxels per axis, 1.9 KB at 2048)
 constexpr uint32_t kLeanCvt     = 16u;       // cost-aware instruction selection (tools/micro/valu_mix.hip): float subtraction of two converted bytes
@@ -1809,9 +1811,16 @@ __device__ __forceinline__ uint32_t load_row(const uint8_t *p)
 	return *g;
 }
 
-template <int SKIP, bool ERT, int GRAD, bool PACKED, bool SEP, uint32_t LF>
-__device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const RmLds &L, uint32_t &iter)
+struct LeanStamp
 {
+	uint32_t sum[3], cnt[3];        // shader-clock cycles and iterations of this wave by kind: 0 probe lanes only, 1 sample lanes only, 2 both
+};
+
+template <int SKIP, bool ERT, int GRAD, bool PACKED, bool SEP, uint32_t LF>
+__device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const RmLds &L, uint32_t &iter, LeanStamp &stamp)
+{
+	constexpr bool kStamp = (LF & kLeanStamp) != 0;
+	uint32_t       stamp_prev = 0, stamp_kind = 3;
 	constexpr bool kHoist = PACKED && GRAD != 2;
 	constexpr bool kUni = (LF & kLeanUniform) != 0, kNt = (LF & kLeanNt) != 0, kLut = (LF & kLeanLut) != 0, kBranch = (LF & kLeanBranch) != 0,
 	               kCvt = (LF & kLeanCvt) != 0, kNest = (LF & kLeanNest) != 0 && kBranch, kKeep = (LF & kLeanKeep) != 0, kScalar = (LF & kLeanScalar) != 0, kFull = (LF & kLeanFull) != 0 && SEP, kTf = (LF & kLeanTf) != 0 && SEP && kHoist && kCvt,
@@ -1874,6 +1883,21 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			}
 		}
 		const bool probe = SKIP != VKV_SKIP_NONE && !occ && cell != ul;        // frag:224
+		if (kStamp)
+		{
+			const uint32_t now = (uint32_t) __builtin_amdgcn_s_memtime();
+			const uint32_t dt  = __builtin_amdgcn_readfirstlane(now - stamp_prev);
+			// (readfirstlane: wave-level values, not per-lane copies that stop when their lane's ray ends; no indexing by a variable)
+			if (stamp_kind == 0u)
+				stamp.sum[0] = __builtin_amdgcn_readfirstlane(stamp.sum[0] + dt), stamp.cnt[0] = __builtin_amdgcn_readfirstlane(stamp.cnt[0] + 1u);
+			else if (stamp_kind == 1u)
+				stamp.sum[1] = __builtin_amdgcn_readfirstlane(stamp.sum[1] + dt), stamp.cnt[1] = __builtin_amdgcn_readfirstlane(stamp.cnt[1] + 1u);
+			else if (stamp_kind == 2u)
+				stamp.sum[2] = __builtin_amdgcn_readfirstlane(stamp.sum[2] + dt), stamp.cnt[2] = __builtin_amdgcn_readfirstlane(stamp.cnt[2] + 1u);
+			stamp_prev = now;
+			const bool any_p = __builtin_amdgcn_ballot_w64(probe) != 0ull, any_s = __builtin_amdgcn_ballot_w64(!probe) != 0ull;
+			stamp_kind       = __builtin_amdgcn_readfirstlane(any_p ? (any_s ? 2u : 0u) : 1u);
+		}
 
 		// ---- loads: probe byte first, then the footprint of the sampling lanes ----------------------------------------
 		uint32_t dist = 0, q00 = 0, q10 = 0, q01 = 0, q11 = 0;
@@ -2189,6 +2213,16 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		if (__builtin_amdgcn_readfirstlane(++iter) == 48u)
 			__builtin_amdgcn_s_setprio(3);
 	}
+	if (kStamp)
+	{        // (all lanes of the wave that entered are back here, each with the stamp of ITS last iteration: per lane, no readfirstlane)
+		const uint32_t dt = (uint32_t) __builtin_amdgcn_s_memtime() - stamp_prev;
+		if (stamp_kind == 0u)
+			stamp.sum[0] += dt, ++stamp.cnt[0];
+		else if (stamp_kind == 1u)
+			stamp.sum[1] += dt, ++stamp.cnt[1];
+		else if (stamp_kind == 2u)
+			stamp.sum[2] += dt, ++stamp.cnt[2];
+	}
 	R.i = (int) li, R.i_min = (int) li_min, R.first_hit = (int) lfirst;
 	if (SEP)
 		R.r = grey, R.g = grey, R.b = grey;
@@ -2269,7 +2303,8 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 		else
 			ray_clear(R);
 	}
-	uint32_t iter = 0;
+	uint32_t  iter  = 0;
+	LeanStamp stamp = {};
 	// 60 % of the workgroups of a frame hold no ray that enters the volume: they skip the LDS tables (and their barrier) altogether
 	if (wg_any(marched))
 	{
@@ -2284,9 +2319,9 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 		if (marched)
 		{
 			if (sep)
-				lean_march<SKIP, ERT, GRAD, PACKED, true, LF>(A, R, L, iter);
+				lean_march<SKIP, ERT, GRAD, PACKED, true, LF>(A, R, L, iter, stamp);
 			else
-				lean_march<SKIP, ERT, GRAD, PACKED, false, LF>(A, R, L, iter);
+				lean_march<SKIP, ERT, GRAD, PACKED, false, LF>(A, R, L, iter, stamp);
 		}
 	}
 	if (A.tile_cost)
@@ -2308,13 +2343,22 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 		for (int o2 = 32; o2 > 0; o2 >>= 1)
 			it = max(it, (uint32_t) __shfl_xor((int) it, o2));
 		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+		if ((LF & kLeanStamp) != 0 && iter == it && lane == (uint32_t) __builtin_ctzll(__ballot(iter == it)))
+		{        // the stamps of the lane whose ray lived through every iteration of the wave (the others stop counting when their ray ends)
+			unsigned long long *rec = A.trace + ((size_t) blockIdx.x * WPB + wave) * kTraceWords;
+			rec[4] = ((unsigned long long) stamp.cnt[0] << 32) | stamp.sum[0], rec[5] = ((unsigned long long) stamp.cnt[1] << 32) | stamp.sum[1];
+			rec[8] = ((unsigned long long) stamp.cnt[2] << 32) | stamp.sum[2];
+		}
+		else if ((LF & kLeanStamp) == 0 && lane == (uint32_t) __builtin_ctzll(__ballot(1)))
+		{
+			unsigned long long *rec = A.trace + ((size_t) blockIdx.x * WPB + wave) * kTraceWords;
+			rec[4] = 0, rec[5] = 0, rec[8] = 0;
+		}
 		if (lane == (uint32_t) __builtin_ctzll(__ballot(1)))
 		{
 			unsigned long long *rec = A.trace + ((size_t) blockIdx.x * WPB + wave) * kTraceWords;        // per launch (a batch: all its frames)
 			rec[0] = t_start, rec[1] = t_end, rec[2] = it, rec[3] = ((unsigned long long) __builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (k * A.blocks_per_tile + sb);
-			rec[4] = 0, rec[5] = 0, rec[6] = c_start, rec[7] = __builtin_amdgcn_s_memtime();
-			for (int w = 8; w < kTraceWords; ++w)
-				rec[w] = 0;
+			rec[6] = c_start, rec[7] = __builtin_amdgcn_s_memtime(), rec[9] = 0;
 		}
 	}
 }
@@ -2407,8 +2451,9 @@ __device__ __forceinline__ void pull_units(const RayMarchArgs *__restrict__ fram
 		}
 		uint32_t                 iter    = 0;
 		const unsigned long long t_setup = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+		LeanStamp                unused_stamp = {};
 		if (marched)
-			lean_march<SKIP, ERT, GRAD, true, SEP, LF>(A, R, L, iter);
+			lean_march<SKIP, ERT, GRAD, true, SEP, LF>(A, R, L, iter, unused_stamp);
 		const unsigned long long t_march = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 		__builtin_amdgcn_s_setprio(0);        // lean_march raises the priority of a long wave: back to normal for the next unit
 		if (A.tile_cost)
