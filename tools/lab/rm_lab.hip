@@ -38,13 +38,18 @@ __global__ void __launch_bounds__(WPB * 64) k_lab_lean_wpb(const RayMarchArgs A)
 	lean_block<SKIP, ERT, GRAD, true, LF, WPB>(A, blockIdx.x, lean_lds());
 }
 
-template <int SKIP, bool ERT, int GRAD, int WPB>
+template <int SKIP, bool ERT, int GRAD, int WPB, uint32_t LF = kLeanDefault | kLeanLut>
 int launch_wpb(const RayMarchArgs &a, hipStream_t s)
 {
 	const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile * (4 / WPB);
-	hipLaunchKernelGGL((k_lab_lean_wpb<SKIP, ERT, GRAD, kLeanDefault | kLeanLut, WPB>), dim3(grid), dim3(WPB * 64), lean_lds_bytes(1, a.lut_words, a.W, a.H, a.D), s, a);
+	if (!a.addr_lut || (size_t) a.lut_words * 4 > 48 * 1024)
+		return -103;
+	hipLaunchKernelGGL((k_lab_lean_wpb<SKIP, ERT, GRAD, LF, WPB>), dim3(grid), dim3(WPB * 64), lean_lds_bytes((LF & kLeanFull) ? 2 : 1, a.lut_words, a.W, a.H, a.D), s, a);
 	return (int) hipGetLastError();
 }
+// the product's flag sets (vkvolume_amd/csrc/raymarch.hip)
+constexpr uint32_t kLabLut  = kLeanDefault | kLeanNest | kLeanKeep | kLeanTf | kLeanWb | kLeanFloatI | kLeanScalar | kLeanLut;
+constexpr uint32_t kLabFull = kLabLut | kLeanFull;
 
 template <int SKIP, bool ERT, int GRAD>
 int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
@@ -62,6 +67,11 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 			return (int) hipGetLastError();
 		}
 #endif
+		case 111: return launch_wpb<SKIP, ERT, GRAD, 1, kLabLut>(a, s);        // workgroups of 1 / 2 / 4 waves with the two-level tables (5.3 KB of LDS per workgroup)
+		case 112: return launch_wpb<SKIP, ERT, GRAD, 2, kLabLut>(a, s);
+		case 114: return launch_wpb<SKIP, ERT, GRAD, 4, kLabLut>(a, s);
+		case 122: return launch_wpb<SKIP, ERT, GRAD, 2, kLabFull>(a, s);       // ... with the per-index tables (15.5 KB: 10 workgroups per CU)
+		case 124: return launch_wpb<SKIP, ERT, GRAD, 4, kLabFull>(a, s);
 		case 8: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar>(a, s);
 		case 10: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest>(a, s);
 		case 13: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep>(a, s);
