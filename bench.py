@@ -687,8 +687,15 @@ def cpu_baseline(ctx, sp, v, params, frame, target_seconds, verify_cpu, out):
                 raise SystemExit("verify-cpu failed: view %d: the frag counters differ from the oracle's" % i)
             if not np.array_equal(rgba8.cpu().numpy()[sel], last[i].rgba8[sel]):
                 raise SystemExit("verify-cpu failed: view %d: RGBA8 differs from the oracle's" % i)
+            # the timed steps ask for RGBA8 only, which selects the integrator without the per-pixel counters: its frame is checked as well
+            rgba8.zero_()
+            sp.draw(p, rgba8=rgba8)
+            torch.cuda.synchronize()
+            if not np.array_equal(rgba8.cpu().numpy()[sel], last[i].rgba8[sel]):
+                raise SystemExit("verify-cpu failed: view %d: RGBA8 of the launch without counters differs from the oracle's" % i)
             n += last[i].counts[sel].shape[0] * last[i].counts[sel].shape[1]
-        out["verified_against_cpu"] = {"views": len(params), "pixels": n, "pixel_stride": stride, "what": "3 counters + RGBA8 per pixel, bit-exact"}
+        out["verified_against_cpu"] = {"views": len(params), "pixels": n, "pixel_stride": stride,
+                                       "what": "3 counters + RGBA8 per pixel, bit-exact; RGBA8 again from the launch without counters (the timed configuration)"}
         print("verify-cpu ok: %d pixels of %d views match the oracle (counters + RGBA8)" % (n, len(params)), file=sys.stderr)
     # the same port on ONE thread (SURVEY.md §8d asks for both figures): view 0 on a sparser sample, about two seconds
     s1 = max(stride, int(math.ceil(math.sqrt(frame[0] * frame[1] / max(rate / cores * 2.0, 1.0)))))

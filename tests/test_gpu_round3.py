@@ -299,3 +299,56 @@ def test_arena_exhaustion_degrades_to_table_free_launches(monkeypatch):
         finally:
             c.close()
     assert int(frames[0].to(torch.int64).sum().item()) > 0 and torch.equal(frames[0], frames[1])
+
+
+@pytest.mark.parametrize("skipping_type", [abi.SKIP_BLOCK, abi.SKIP_DISTANCE, abi.SKIP_ANISOTROPIC_DISTANCE])
+def test_launch_without_counters_renders_the_same_frame(ctx, skipping_type):
+    """A launch without d_out_counts (what a renderer submits: the reference keeps the per-pixel sample counters only in its test modes,
+    src/volume_render_subpass.h Test::NumTextureSamples) runs the integrator WITHOUT the three counters (kLeanNoCounts).  Its float
+    colour, depth and RGBA8 must be the counted launch's bits - through vkv_render and through vkv_render_batch - and the oracle's."""
+    opt = abi.VolumeOptions(**T.APP_TF)
+    scene = T.OracleScene(O.synth_volume((88, 72, 64), 1, 0x5EED0003), opt, 4)
+    v, tf = make_gpu_volume(ctx, scene)
+    V.ComputeDistanceMap(ctx).compute(v, tf, skipping_type)
+    size = (160, 96)
+    ro = abi.RenderOptions(skipping_type=skipping_type, clip_distance=1.0, early_ray_termination=True)
+    st = torch.cuda.current_stream().cuda_stream
+    plist = []
+    for az in (10.0, 77.0, 200.0):
+        view, proj = T.orbit(az, image_size=size)
+        plist.append(V.VolumeRenderSubpass(ctx, v, ro, size).bind(scene.params(view, proj, size, ro)))
+
+    def outputs(with_counts):
+        return [dict(color=torch.full((size[1], size[0], 4), -1.0, dtype=torch.float32, device="cuda"),
+                     depth=torch.full((size[1], size[0]), -1.0, dtype=torch.float32, device="cuda"),
+                     rgba8=torch.full((size[1], size[0], 4), 7, dtype=torch.uint8, device="cuda"),
+                     counts=torch.full((size[1], size[0], 3), 9, dtype=torch.int32, device="cuda") if with_counts else None) for _ in plist]
+
+    def point(p, o):
+        q = abi.RenderParams.from_buffer_copy(p)
+        q.d_out_color, q.d_out_depth, q.d_out_rgba8 = o["color"].data_ptr(), o["depth"].data_ptr(), o["rgba8"].data_ptr()
+        q.d_out_counts = o["counts"].data_ptr() if o["counts"] is not None else None
+        return q
+
+    counted = outputs(True)
+    for p, o in zip(plist, counted):
+        ctx.render(point(p, o), st)
+    torch.cuda.synchronize()
+    assert int(counted[0]["counts"][..., 0].sum().item()) > 0 and int(counted[0]["counts"][..., 1].sum().item()) > 0
+    try:
+        for tables in (2, 1):        # one table entry per voxel index / the two-level tables: each has its own kernel without counters
+            ctx.set_tuning(address_tables=tables)
+            single, batch = outputs(False), outputs(False)
+            for p, o in zip(plist, single):
+                ctx.render(point(p, o), st)
+            ctx.render_batch([point(p, o) for p, o in zip(plist, batch)], st)
+            torch.cuda.synchronize()
+            for i in range(len(plist)):
+                for k in ("color", "depth", "rgba8"):
+                    assert torch.equal(counted[i][k], single[i][k]), "tables %d frame %d: %s of the launch without counters differs" % (tables, i, k)
+                    assert torch.equal(counted[i][k], batch[i][k]), "tables %d frame %d: %s of the batch launch without counters differs" % (tables, i, k)
+    finally:
+        ctx.set_tuning(address_tables=2)
+    ref = scene.render(plist[1], want_rgba8=True)
+    assert np.array_equal(single[1]["rgba8"].cpu().numpy(), ref.rgba8), "RGBA8 of the launch without counters differs from the oracle's"
+    assert np.array_equal(counted[1]["counts"].cpu().numpy().astype(np.uint32), ref.counts)

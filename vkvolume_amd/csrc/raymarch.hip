@@ -23,6 +23,8 @@ enum Scheduler
 constexpr uint32_t kLfPlain = kLeanDefault | kLeanNest | kLeanKeep | kLeanTf | kLeanWb | kLeanFloatI;        // footprint address worked out in registers: any volume, any map
 constexpr uint32_t kLfLut   = kLfPlain | kLeanScalar | kLeanLut;           // two-level address tables in LDS (volumes up to ~2500 voxels per axis)
 constexpr uint32_t kLfFull  = kLfLut | kLeanFull;                          // + one entry per voxel index with the separable transfer function
+constexpr uint32_t kLfFullNc = kLfFull | kLeanNoCounts;                    // the same without the per-pixel counters (no d_out_counts: what a renderer launches)
+constexpr uint32_t kLfLutNc  = kLfLut | kLeanNoCounts;
 
 struct LeanChoice
 {
@@ -75,7 +77,20 @@ static int launch_one(vkv_ctx *ctx, int sched, const VkvTuning &T, RayMarchArgs 
 		if constexpr (PACKED && GRAD != 2)
 		{
 			const LeanChoice c = choose_lean(a, T);
-			if (c.kind == 2)
+			bool no_counts = false;
+			if constexpr (SKIP != VKV_SKIP_NONE && ERT && GRAD == 1)
+				no_counts = c.kind != 0 && !a.out_counts && !a.pixel_cost;        // the common configuration only: every further instantiation costs build time
+			if (no_counts)
+			{
+				if constexpr (SKIP != VKV_SKIP_NONE && ERT && GRAD == 1)
+				{
+					if (c.kind == 2)
+						hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfFullNc>), dim3(grid), dim3(256), c.lds, s, a);
+					else
+						hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfLutNc>), dim3(grid), dim3(256), c.lds, s, a);
+				}
+			}
+			else if (c.kind == 2)
 				hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfFull>), dim3(grid), dim3(256), c.lds, s, a);
 			else if (c.kind == 1)
 				hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfLut>), dim3(grid), dim3(256), c.lds, s, a);
@@ -338,10 +353,21 @@ int prepare_render(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, hipStream
 
 // ---- several frames in one launch --------------------------------------------------------------------------------
 template <int SKIP, bool ERT, int GRAD>
-static void launch_batch_kind(LeanChoice c, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, hipStream_t s)
+static void launch_batch_kind(LeanChoice c, bool no_counts, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, hipStream_t s)
 {
 	if constexpr (GRAD != 2)
 	{
+		if constexpr (SKIP != VKV_SKIP_NONE && ERT && GRAD == 1)
+		{
+			if (c.kind != 0 && no_counts)
+			{
+				if (c.kind == 2)
+					hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfFullNc>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
+				else
+					hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfLutNc>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
+				return;
+			}
+		}
 		if (c.kind == 2)
 			hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfFull>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
 		else if (c.kind == 1)
@@ -353,24 +379,24 @@ static void launch_batch_kind(LeanChoice c, const RayMarchArgs *d_frames, uint32
 }
 
 template <int SKIP, bool ERT>
-static void launch_batch_grad(int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, LeanChoice c, hipStream_t s)
+static void launch_batch_grad(int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, LeanChoice c, bool no_counts, hipStream_t s)
 {
 	// c.kind > 0: every frame of the batch has address tables of that size (same volume extent) and they fit the LDS budget
 	if (grad == 0)
-		launch_batch_kind<SKIP, ERT, 0>(c, d_frames, n, grid, gpf, s);
+		launch_batch_kind<SKIP, ERT, 0>(c, no_counts, d_frames, n, grid, gpf, s);
 	else if (grad == 1)
-		launch_batch_kind<SKIP, ERT, 1>(c, d_frames, n, grid, gpf, s);
+		launch_batch_kind<SKIP, ERT, 1>(c, no_counts, d_frames, n, grid, gpf, s);
 	else
-		launch_batch_kind<SKIP, ERT, 2>(c, d_frames, n, grid, gpf, s);
+		launch_batch_kind<SKIP, ERT, 2>(c, no_counts, d_frames, n, grid, gpf, s);
 }
 
 template <int SKIP>
-static void launch_batch_ert(bool ert, int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, LeanChoice c, hipStream_t s)
+static void launch_batch_ert(bool ert, int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, LeanChoice c, bool no_counts, hipStream_t s)
 {
 	if (ert)
-		launch_batch_grad<SKIP, true>(grad, d_frames, n, grid, gpf, c, s);
+		launch_batch_grad<SKIP, true>(grad, d_frames, n, grid, gpf, c, no_counts, s);
 	else
-		launch_batch_grad<SKIP, false>(grad, d_frames, n, grid, gpf, c, s);
+		launch_batch_grad<SKIP, false>(grad, d_frames, n, grid, gpf, c, no_counts, s);
 }
 
 // ---- the same, with resident workgroups whose waves pull their units ------------------------------------------------
@@ -457,6 +483,9 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	const bool        sequential = T.batch_sequential != 0;
 	const uint32_t    gpf        = sequential ? (uint32_t) (grid / n / 8) : 0u;
 	LeanChoice        choice     = choose_lean(host[0], T);
+	bool              no_counts  = true;        // no frame wants the per-pixel counters (or sorts its rays by them): the loop without them
+	for (uint32_t i = 0; i < n; ++i)
+		no_counts = no_counts && !host[i].out_counts && !host[i].pixel_cost;
 	for (uint32_t i = 1; i < n; ++i)
 	{        // one kernel for all frames: the most general choice any of them needs
 		const LeanChoice c = choose_lean(host[i], T);
@@ -495,10 +524,10 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	}
 	switch (P[0].options.skipping_type)
 	{
-		case VKV_SKIP_NONE: launch_batch_ert<VKV_SKIP_NONE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, s); break;
-		case VKV_SKIP_BLOCK: launch_batch_ert<VKV_SKIP_BLOCK>(ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, s); break;
-		case VKV_SKIP_DISTANCE: launch_batch_ert<VKV_SKIP_DISTANCE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, s); break;
-		case VKV_SKIP_ANISOTROPIC_DISTANCE: launch_batch_ert<VKV_SKIP_ANISOTROPIC_DISTANCE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, s); break;
+		case VKV_SKIP_NONE: launch_batch_ert<VKV_SKIP_NONE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, no_counts, s); break;
+		case VKV_SKIP_BLOCK: launch_batch_ert<VKV_SKIP_BLOCK>(ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, no_counts, s); break;
+		case VKV_SKIP_DISTANCE: launch_batch_ert<VKV_SKIP_DISTANCE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, no_counts, s); break;
+		case VKV_SKIP_ANISOTROPIC_DISTANCE: launch_batch_ert<VKV_SKIP_ANISOTROPIC_DISTANCE>(ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, no_counts, s); break;
 		default: return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: bad skipping_type %d", P[0].options.skipping_type);
 	}
 	// behind the render, on the same stream: the costs it measured become the start order of the next frames into these targets (the

@@ -1513,6 +1513,9 @@ constexpr uint32_t kLeanFmt     = 32768u;    // with kLeanFull + kLeanTf: the x-
 constexpr uint32_t kLeanFmtVec  = 65536u;    // kLeanFmt with the uniform loop operands left in vector registers (the kernels that are not held to 64 VGPRs)
 constexpr uint32_t kLeanStamp   = 131072u;   // (lab, with the trace buffer) s_memtime at the top of every iteration, summed per wave by the iteration's kind: only
                                              // probing lanes / only sampling lanes / both (tools/lab/run_lab.py --lean-stamps)
+constexpr uint32_t kLeanNoCounts = 262144u;  // the three per-pixel counters (volume samples, map probes, empty samples) are not kept: for launches without
+                                             // d_out_counts - the reference keeps them only in its test modes (Test::NumTextureSamples) - two additions and
+                                             // the EXEC-masked else-branch of the empty sample leave the loop
 constexpr uint32_t kLeanDefault = 1u | 8u | 16u;        // kLeanUniform | kLeanBranch | kLeanCvt: what the product launches (+ kLeanLut when the tables fit)
 constexpr size_t   kMaxLutBytes = 8 * 1024;           // LDS budget of the address tables (1.2 KB at 1024 voxels per axis, 1.9 KB at 2048)
 constexpr uint32_t kLeanCvt     = 16u;       // cost-aware instruction selection (tools/micro/valu_mix.hip): float subtraction of two converted bytes
@@ -1819,7 +1822,7 @@ struct LeanStamp
 template <int SKIP, bool ERT, int GRAD, bool PACKED, bool SEP, uint32_t LF>
 __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const RmLds &L, uint32_t &iter, LeanStamp &stamp)
 {
-	constexpr bool kStamp = (LF & kLeanStamp) != 0;
+	constexpr bool kStamp = (LF & kLeanStamp) != 0, kCounts = (LF & kLeanNoCounts) == 0;
 	uint32_t       stamp_prev = 0, stamp_kind = 3;
 	constexpr bool kHoist = PACKED && GRAD != 2;
 	constexpr bool kUni = (LF & kLeanUniform) != 0, kNt = (LF & kLeanNt) != 0, kLut = (LF & kLeanLut) != 0, kBranch = (LF & kLeanBranch) != 0,
@@ -2126,7 +2129,8 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			{
 				if (kNest)
 					probe_outcome();        // an empty side is skipped by the branch the compiler puts around it (s_cbranch_execz)
-				++R.n_dist;
+				if (kCounts)
+					++R.n_dist;
 				if (dist > 0u)
 					li = i + skip;        // frag:244-247
 				else
@@ -2141,7 +2145,8 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			{
 				if (kNest)
 					sample_outcome();
-				++R.n_vol;
+				if (kCounts)
+					++R.n_vol;
 				occ        = ab > 0u;        // frag:276
 				bool ended = false;
 				if (occ)
@@ -2165,7 +2170,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 						ended = true;
 					}
 				}
-				else
+				else if (kCounts)
 					++R.n_empty;
 				if (!ended)
 				{
@@ -2184,9 +2189,12 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		const bool p_occ  = probe && dist == 0u;       // frag:248-262
 		const bool occ_s  = ab > 0u;                   // frag:276
 		const bool hit    = smp && occ_s;
-		R.n_dist += probe ? 1u : 0u;
-		R.n_vol += smp ? 1u : 0u;
-		R.n_empty += (smp && !occ_s) ? 1u : 0u;
+		if (kCounts)
+		{
+			R.n_dist += probe ? 1u : 0u;
+			R.n_vol += smp ? 1u : 0u;
+			R.n_empty += (smp && !occ_s) ? 1u : 0u;
+		}
 		const float om = 1.0f - R.a;        // frag:287
 		const float na = __builtin_fmaf(om, a, R.a);
 		if (SEP)
