@@ -167,7 +167,7 @@ typedef struct VkvRenderParams
 	const uint32_t *           d_transfer_function_bits;   /* optional: vkv_transfer_function_tables() of d_transfer_function; NULL = fetch the texel */
 	float *                    d_out_color;                /* RGBA32F premultiplied, or NULL */
 	uint8_t *                  d_out_rgba8;                /* RGBA8 round-to-nearest of the above, or NULL */
-	uint32_t *                 d_out_counts;               /* 3 x u32 per pixel: volume samples, distance probes, empty samples; or NULL */
+	uint32_t *                 d_out_counts;               /* 3 x u32 per pixel: volume samples, distance probes, empty samples; or NULL (the integrator then does not count) */
 	float *                    d_out_depth;                /* gl_FragDepth (reverse-Z, 0 = far), or NULL */
 	const float *              d_in_depth;                 /* options.depth_attachment: the scene depth the subpass reads as input attachment 0
 	                                                          (frag:26, 122-165; reverse-Z), indexed like the outputs */
