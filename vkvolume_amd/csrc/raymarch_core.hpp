@@ -2131,14 +2131,15 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 					probe_outcome();        // an empty side is skipped by the branch the compiler puts around it (s_cbranch_execz)
 				if (kCounts)
 					++R.n_dist;
-				if (dist > 0u)
-					li = i + skip;        // frag:244-247
-				else
-				{        // frag:253-261
-					occ = true;
-					ul  = cell;
-					li  = kFloatI ? (idx_t) max_f32_raw((float) (i - lback), (float) li_min) : (idx_t) max((int) (i - lback), (int) li_min);
-				}
+				// frag:244-247 (dist > 0: skip) and frag:253-261 (occupied cell: step back).  The step-back side is three instructions: as
+				// selects next to the skip side's EXEC-masked block, not as a block of its own (one region and one branch less per probe)
+				const idx_t back_to = kFloatI ? (idx_t) max_f32_raw((float) (i - lback), (float) li_min) : (idx_t) max((int) (i - lback), (int) li_min);
+				const bool  hit     = dist == 0u;
+				li                  = back_to;
+				if (!hit)
+					li = i + skip;
+				occ = hit ? true : occ;
+				ul  = hit ? cell : ul;
 				done = li >= ln;
 			}
 			else
@@ -2164,10 +2165,10 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 					R.a = __builtin_fmaf(om, a, R.a);
 					if (a > 0.0f)
 						lfirst = i;
-					if (ERT && R.a > 0.99f)
-					{        // frag:293-299
-						R.a   = 1.0f;
-						ended = true;
+					if (ERT)
+					{        // frag:293-299, as selects (the block form costs a save / restore of EXEC around two moves)
+						ended = R.a > 0.99f;
+						R.a   = ended ? 1.0f : R.a;
 					}
 				}
 				else if (kCounts)
