@@ -132,7 +132,38 @@ def classes(vw, per_octave=1):
     return centre[np.argsort(-cls, kind="stable")]
 
 
+def xcd_groups(vw, key):
+    """Position p of the order runs on XCD p & 7 (own L2): give every XCD ONE spatial group of tiles - the tiles sorted by `key` (an angle
+    around the screen centre, or x) and cut into 8 runs of equal total cost - longest first inside the group."""
+    o = np.argsort(key, kind="stable")
+    c = np.maximum(cost[vw][o], 1).astype(np.float64)        # tiles without a marching ray still cost a launch
+    cuts = np.searchsorted(np.cumsum(c), np.linspace(0, c.sum(), 9)[1:-1])
+    groups = np.split(o, cuts)
+    groups = [g[np.argsort(-cost[vw][g], kind="stable")] for g in groups]
+    n = max(len(g) for g in groups)
+    out = np.full((n, 8), -1, np.int64)
+    for x, g in enumerate(groups):
+        out[:len(g), x] = g
+    flat = out.reshape(-1)
+    # the kernel needs a permutation of all tiles in `tiles` positions: holes of shorter groups are filled from the longest groups' tails
+    spare = [t for t in flat[tiles:] if t >= 0]
+    flat = flat[:tiles].copy()
+    holes = np.nonzero(flat < 0)[0]
+    assert len(holes) == len(spare), (len(holes), len(spare))
+    flat[holes] = spare
+    assert len(set(flat.tolist())) == tiles
+    return flat
+
+
+angle = np.arctan2(cy, cx)
 print("fenced blocks of 20 frames (7 + 7 + 6 on three streams), ms per frame:")
+if os.environ.get("XCD_GROUPS"):
+    print("  longest first, ties centre-first      %.4f" % timed([lpt_centre_ties(vw) for vw in range(8)]))
+    print("  one angular sector per XCD            %.4f" % timed([xcd_groups(vw, angle) for vw in range(8)]))
+    print("  one vertical stripe per XCD           %.4f" % timed([xcd_groups(vw, cx) for vw in range(8)]))
+    print("  one horizontal stripe per XCD         %.4f" % timed([xcd_groups(vw, cy) for vw in range(8)]))
+    print("  longest first, ties centre-first      %.4f" % timed([lpt_centre_ties(vw) for vw in range(8)]))
+    sys.exit(0)
 print("  log2 cost classes, centre-first inside  %.4f" % timed([classes(vw) for vw in range(8)]))
 print("  half-octave classes                     %.4f" % timed([classes(vw, 2) for vw in range(8)]))
 print("  quarter-octave classes                  %.4f" % timed([classes(vw, 4) for vw in range(8)]))
