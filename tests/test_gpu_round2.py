@@ -475,7 +475,6 @@ def test_render_start_order_feedback_against_the_oracle(ctx):
     counts = torch.empty((size[1], size[0], 3), dtype=torch.int32, device="cuda")
     depth = torch.empty((size[1], size[0]), dtype=torch.float32, device="cuda")
     ctx.register_target(color.data_ptr(), size, views[0].tiles)  # the feedback state of this target (vkv_render itself never allocates)
-    ctx.set_tuning(ray_order=1)  # + the rays of every 16x16 block dealt to its waves by the last frame's events per pixel (experiment, off by default)
     for frame in range(19):
         k = (frame // 3) % 2
         color.fill_(-1.0), counts.fill_(0xFFFF), depth.fill_(-1.0)
@@ -483,8 +482,6 @@ def test_render_start_order_feedback_against_the_oracle(ctx):
         torch.cuda.synchronize()
         got = (color.cpu().numpy(), counts.cpu().numpy().astype(np.uint32), depth.cpu().numpy(), None)
         compare_render(got, refs[k], "frame %d (view %d)" % (frame, k))
-        if frame == 9:
-            ctx.set_tuning(ray_order=0)
     ctx.forget_target(color.data_ptr())
 
 

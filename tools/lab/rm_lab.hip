@@ -4,7 +4,7 @@
 #include <cmath>
 #include <cstdio>
 
-#include "../../vkvolume_amd/csrc/raymarch_core.hpp"
+#include "raymarch_lab.hpp"
 
 namespace
 {
@@ -17,17 +17,38 @@ int launch_er(const RayMarchArgs &a, hipStream_t s)
 }
 
 template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF>
-int launch_lean(const RayMarchArgs &a, hipStream_t s)
+__global__ void __launch_bounds__(256) k_lab_lean(const RayMarchArgs A)
+{
+	lean_lds_check();
+	lab_lean_block<SKIP, ERT, GRAD, PACKED, LF>(A, blockIdx.x, lean_lds());
+}
+
+// the PRODUCT's kernel with flags the product does not instantiate (the stamp build): cycles per iteration by kind of the shipped loop
+template <int SKIP, bool ERT, int GRAD, uint32_t LF>
+int launch_product_lean(const RayMarchArgs &a, hipStream_t s)
 {
 	const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile;
-	if ((LF & kLeanLut) && (!a.addr_lut || (size_t) a.lut_words * 4 > 48 * 1024))
+	if ((LF & kLeanLut) && (!a.addr_lut || (size_t) a.lut_words * 4 > kMaxLutBytes || !map_fits_u24((uint32_t) a.mw, (uint32_t) a.mh, (uint32_t) a.md)))
 		return -103;
 	if ((LF & kLeanFull) != 0 && kFullLutWord * 4 + full_lut_bytes(a.W, a.H, a.D) > 48 * 1024)
 		return -104;
 	const size_t lds = lean_lds_bytes((LF & kLeanFull) ? 2 : ((LF & kLeanLut) ? 1 : 0), a.lut_words, a.W, a.H, a.D);
-	if ((LF & kLeanScalar) != 0 && !map_fits_u24((uint32_t) a.mw, (uint32_t) a.mh, (uint32_t) a.md))
+	hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, true, LF>), dim3(grid), dim3(256), lds, s, a);
+	return (int) hipGetLastError();
+}
+
+template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF>
+int launch_lean(const RayMarchArgs &a, hipStream_t s)
+{
+	const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile;
+	if ((LF & kLabLut) && (!a.addr_lut || (size_t) a.lut_words * 4 > 48 * 1024))
+		return -103;
+	if ((LF & kLabFull) != 0 && kFullLutWord * 4 + full_lut_bytes(a.W, a.H, a.D) > 48 * 1024)
+		return -104;
+	const size_t lds = lean_lds_bytes((LF & kLabFull) ? 2 : ((LF & kLabLut) ? 1 : 0), a.lut_words, a.W, a.H, a.D);
+	if ((LF & kLabScalar) != 0 && !map_fits_u24((uint32_t) a.mw, (uint32_t) a.mh, (uint32_t) a.md))
 		return -105;
-	hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, LF>), dim3(grid), dim3(256), lds, s, a);
+	hipLaunchKernelGGL((k_lab_lean<SKIP, ERT, GRAD, PACKED, LF>), dim3(grid), dim3(256), lds, s, a);
 	return (int) hipGetLastError();
 }
 
@@ -35,21 +56,21 @@ template <int SKIP, bool ERT, int GRAD, uint32_t LF, int WPB>
 __global__ void __launch_bounds__(WPB * 64) k_lab_lean_wpb(const RayMarchArgs A)
 {
 	lean_lds_check();
-	lean_block<SKIP, ERT, GRAD, true, LF, WPB>(A, blockIdx.x, lean_lds());
+	lab_lean_block<SKIP, ERT, GRAD, true, LF, WPB>(A, blockIdx.x, lean_lds());
 }
 
-template <int SKIP, bool ERT, int GRAD, int WPB, uint32_t LF = kLeanDefault | kLeanLut>
+template <int SKIP, bool ERT, int GRAD, int WPB, uint32_t LF = kLabDefault | kLabLut>
 int launch_wpb(const RayMarchArgs &a, hipStream_t s)
 {
 	const uint32_t grid = ((a.tile_count + 7u) / 8u) * 8u * a.blocks_per_tile * (4 / WPB);
 	if (!a.addr_lut || (size_t) a.lut_words * 4 > 48 * 1024)
 		return -103;
-	hipLaunchKernelGGL((k_lab_lean_wpb<SKIP, ERT, GRAD, LF, WPB>), dim3(grid), dim3(WPB * 64), lean_lds_bytes((LF & kLeanFull) ? 2 : 1, a.lut_words, a.W, a.H, a.D), s, a);
+	hipLaunchKernelGGL((k_lab_lean_wpb<SKIP, ERT, GRAD, LF, WPB>), dim3(grid), dim3(WPB * 64), lean_lds_bytes((LF & kLabFull) ? 2 : 1, a.lut_words, a.W, a.H, a.D), s, a);
 	return (int) hipGetLastError();
 }
 // the product's flag sets (vkvolume_amd/csrc/raymarch.hip)
-constexpr uint32_t kLabLut  = kLeanDefault | kLeanNest | kLeanKeep | kLeanTf | kLeanWb | kLeanFloatI | kLeanScalar | kLeanLut;
-constexpr uint32_t kLabFull = kLabLut | kLeanFull;
+constexpr uint32_t kLabSetLut  = kLabDefault | kLabNest | kLabKeep | kLabTf | kLabWb | kLabFloatI | kLabScalar | kLabLut;
+constexpr uint32_t kLabSetFull = kLabSetLut | kLabFull;
 
 template <int SKIP, bool ERT, int GRAD>
 int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
@@ -67,34 +88,37 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 			return (int) hipGetLastError();
 		}
 #endif
-		case 111: return launch_wpb<SKIP, ERT, GRAD, 1, kLabLut>(a, s);        // workgroups of 1 / 2 / 4 waves with the two-level tables (5.3 KB of LDS per workgroup)
-		case 112: return launch_wpb<SKIP, ERT, GRAD, 2, kLabLut>(a, s);
-		case 114: return launch_wpb<SKIP, ERT, GRAD, 4, kLabLut>(a, s);
-		case 122: return launch_wpb<SKIP, ERT, GRAD, 2, kLabFull>(a, s);       // ... with the per-index tables (15.5 KB: 10 workgroups per CU)
-		case 124: return launch_wpb<SKIP, ERT, GRAD, 4, kLabFull>(a, s);
-		case 8: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar>(a, s);
-		case 10: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest>(a, s);
-		case 13: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep>(a, s);
-		case 15: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanFull>(a, s);
-		case 16: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull>(a, s);
-		case 18: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf>(a, s);
-		case 19: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanGradSkip>(a, s);
-		case 20: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb>(a, s);
-		case 21: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI>(a, s);
-		case 22: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanFloatCell>(a, s);
-		case 24: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanFmt>(a, s);
-		case 25: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanFmt | kLeanFmtVec>(a, s);
-		case 26: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanStamp>(a, s);
-		case 23: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanScalar | kLeanNest | kLeanKeep | kLeanFull | kLeanTf | kLeanWb | kLeanFloatI | kLeanPrefetch>(a, s);
-		case 17: return launch_lean<SKIP, ERT, GRAD, true, kLeanDefault | kLeanLut | kLeanFull>(a, s);
-		case 6: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanLut | kLeanBranch | kLeanCvt>(a, s);
+		case 111: return launch_wpb<SKIP, ERT, GRAD, 1, kLabSetLut>(a, s);        // workgroups of 1 / 2 / 4 waves with the two-level tables (5.3 KB of LDS per workgroup)
+		case 112: return launch_wpb<SKIP, ERT, GRAD, 2, kLabSetLut>(a, s);
+		case 114: return launch_wpb<SKIP, ERT, GRAD, 4, kLabSetLut>(a, s);
+		case 122: return launch_wpb<SKIP, ERT, GRAD, 2, kLabSetFull>(a, s);       // ... with the per-index tables (15.5 KB: 10 workgroups per CU)
+		case 124: return launch_wpb<SKIP, ERT, GRAD, 4, kLabSetFull>(a, s);
+		case 8: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar>(a, s);
+		case 10: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest>(a, s);
+		case 13: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep>(a, s);
+		case 15: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabFull>(a, s);
+		case 16: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull>(a, s);
+		case 18: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf>(a, s);
+		case 19: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabGradSkip>(a, s);
+		case 20: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb>(a, s);
+		case 21: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI>(a, s);
+		case 22: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabFloatCell>(a, s);
+		case 24: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabFmt>(a, s);
+		case 25: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabFmt | kLabFmtVec>(a, s);
+		case 26: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabStamp>(a, s);
+		case 23: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabPrefetch>(a, s);
+		case 17: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabFull>(a, s);
+		// the product's lean_march (raymarch_core.hpp), instantiated here: 30 = kLeanLut | kLeanFull as shipped, 31 = + per-iteration stamps
+		case 30: return launch_product_lean<SKIP, ERT, GRAD, kLeanLut | kLeanFull>(a, s);
+		case 31: return launch_product_lean<SKIP, ERT, GRAD, kLeanLut | kLeanFull | kLeanStamp>(a, s);
+		case 6: return launch_lean<SKIP, ERT, GRAD, true, kLabUniform | kLabLut | kLabBranch | kLabCvt>(a, s);
 #ifdef LAB_ALL
 		case 1: return launch_lean<SKIP, ERT, GRAD, true, 0>(a, s);
-		case 2: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform>(a, s);
-		case 3: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanLut>(a, s);
-		case 4: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanBranch>(a, s);
-		case 5: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanCvt>(a, s);
-		case 7: return launch_lean<SKIP, ERT, GRAD, true, kLeanUniform | kLeanLut | kLeanCvt>(a, s);
+		case 2: return launch_lean<SKIP, ERT, GRAD, true, kLabUniform>(a, s);
+		case 3: return launch_lean<SKIP, ERT, GRAD, true, kLabUniform | kLabLut>(a, s);
+		case 4: return launch_lean<SKIP, ERT, GRAD, true, kLabUniform | kLabBranch>(a, s);
+		case 5: return launch_lean<SKIP, ERT, GRAD, true, kLabUniform | kLabCvt>(a, s);
+		case 7: return launch_lean<SKIP, ERT, GRAD, true, kLabUniform | kLabLut | kLabCvt>(a, s);
 		case 211: return launch_er<SKIP, ERT, GRAD, true, 1, 0>(a, s);
 		case 212: return launch_er<SKIP, ERT, GRAD, true, 2, 0>(a, s);
 		case 214: return launch_er<SKIP, ERT, GRAD, true, 4, 0>(a, s);

@@ -23,7 +23,7 @@ from vkvolume_amd import abi, lib, volume as V  # noqa: E402
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 flags = [a for a in sys.argv[1:] if a.startswith("--")]
 name = args[0] if args else "c3"
-variants = [int(x) for x in args[1].split(",")] if len(args) > 1 else [0, 13, 16, 21, 23]  # older ids need -DLAB_ALL (tools/lab/Makefile)
+variants = [int(x) for x in args[1].split(",")] if len(args) > 1 else [0, 30, 21, 13]  # 30 = the product loop instantiated in the lab, 21 = round 3's flag set; older ids need -DLAB_ALL (tools/lab/Makefile)
 dense = "--dense" in flags
 
 torch.cuda.set_device(0)
@@ -173,7 +173,9 @@ if "--stamps" in flags:
         print("  same, waves with >= 150 iterations:", (t[it >= 150][:, [8, 4, 5, 6, 7]].astype(np.float64) / it[it >= 150, None]).mean(0).round(0) if (it >= 150).any() else None)
 
 if "--lean-stamps" in flags:
-    # variant 26 = the shipped single-frame kernel + s_memtime at the top of every iteration: cycles per iteration by kind, per wave
+    # variant 31 = the product's single-frame kernel (raymarch_core.hpp, kLeanLut | kLeanFull) + s_memtime at the top of every iteration: cycles per
+    # iteration by kind, per wave (LAB_STAMP_VARIANT=26: round 3's lab copy of the same loop)
+    stamp_variant = int(os.environ.get("LAB_STAMP_VARIANT", "31"))
     for vi in range(len(params)):
         p = params[vi]
         b = bufs()
@@ -181,10 +183,10 @@ if "--lean-stamps" in flags:
         nwaves = ((p.tiles.tile_count + 7) // 8) * 8 * 4 * 4
         trace = torch.zeros((nwaves, 10), dtype=torch.int64, device="cuda")
         for _ in range(2):
-            launch(26, p, cur)
+            launch(stamp_variant, p, cur)
         torch.cuda.synchronize()
         L.vkv_debug_trace(ctx.handle, trace.data_ptr())
-        launch(26, p, cur)
+        launch(stamp_variant, p, cur)
         torch.cuda.synchronize()
         L.vkv_debug_trace(ctx.handle, None)
         t = trace.cpu().numpy().astype(np.uint64)

@@ -278,7 +278,6 @@ static void default_tuning(VkvTuning &t)
 	t.screen_cull          = 1;
 	t.feedback             = 1;
 	t.feedback_period      = 8;
-	t.ray_order            = 0;        // measured on C3: 0.1156 against 0.1120 ms per frame (the block executions it saves cost less than the locality it gives up)
 	t.arena_bytes          = 8u << 20;
 	auto env = [](const char *name) -> const char * { const char *e = std::getenv(name); return (e && e[0]) ? e : nullptr; };
 	if (const char *e = env("VKV_RAYMARCH_SCHEDULER"))
@@ -297,8 +296,6 @@ static void default_tuning(VkvTuning &t)
 		t.screen_cull = e[0] != '0';
 	if (const char *e = env("VKV_RAYMARCH_FEEDBACK"))
 		t.feedback = e[0] != '0';
-	if (const char *e = env("VKV_RAYMARCH_RAY_ORDER"))
-		t.ray_order = e[0] == '1';
 	if (const char *e = env("VKV_RAYMARCH_FEEDBACK_PERIOD"))
 		t.feedback_period = (uint32_t) std::max(1l, std::atol(e));
 	if (const char *e = env("VKV_RAYMARCH_TILE_MIX"))
@@ -374,8 +371,7 @@ void vkv_destroy(vkv_ctx *ctx)
 		{
 			(void) hipFree(f->d_cost);
 			(void) hipFree(f->d_order);
-			(void) hipFree(f->d_pixel);
-			delete f;
+					delete f;
 		}
 		for (void *p : ctx->overflow)
 			(void) hipFree(p);
@@ -435,17 +431,10 @@ int vkv_register_target(vkv_ctx *ctx, const void *d_target, uint32_t image_width
 	if (tiles->tile_count == 0)
 		return VKV_OK;
 	uint32_t *cost = nullptr, *order = nullptr;
-	uint8_t * pixel = nullptr;
 	const size_t bytes = (size_t) tiles->tile_count * sizeof(uint32_t);
-	// one byte per output pixel, indexed like the outputs (VkvTileSchedule.compact)
-	const size_t pixels = tiles->compact ? (size_t) tiles->tile_count * tiles->tile_width * tiles->tile_height : (size_t) image_width * image_height;
 	hipError_t   e      = hipMalloc((void **) &cost, bytes);
 	if (e == hipSuccess)
 		e = hipMalloc((void **) &order, bytes);
-	if (e == hipSuccess)
-		e = hipMalloc((void **) &pixel, pixels);
-	if (e == hipSuccess)
-		e = hipMemset(pixel, 0, pixels);
 	std::vector<uint32_t> identity(tiles->tile_count);
 	for (uint32_t i = 0; i < tiles->tile_count; ++i)
 		identity[i] = i;
@@ -455,13 +444,12 @@ int vkv_register_target(vkv_ctx *ctx, const void *d_target, uint32_t image_width
 	if (e == hipSuccess)
 		e = hipMemcpy(order, identity.data(), bytes, hipMemcpyHostToDevice);
 	auto *f = e == hipSuccess ? new (std::nothrow) vkv_ctx::TileFeedback{d_target, image_width, image_height, tiles->tile_width, tiles->tile_height, tiles->tile_first,
-	                                                                      tiles->tile_stride, tiles->tile_count, cost, order, pixel, tiles->compact, false, 0u, 0u, 8u, 0u}
+	                                                                      tiles->tile_stride, tiles->tile_count, cost, order, false, 0u, 0u, 8u, 0u}
 	                          : nullptr;
 	if (!f)
 	{
 		(void) hipFree(cost);
 		(void) hipFree(order);
-		(void) hipFree(pixel);
 		return set_error(ctx, e != hipSuccess ? (int) e : VKV_E_UNSUPPORTED, "register_target: %s", e != hipSuccess ? hipGetErrorString(e) : "out of memory");
 	}
 	std::lock_guard<std::mutex> lock(ctx->mutex);
@@ -491,7 +479,6 @@ int vkv_forget_target(vkv_ctx *ctx, const void *d_target)
 	(void) hipDeviceSynchronize();        // launches that still write costs or read the order (the entry is out of the list: no new ones)
 	(void) hipFree(f->d_cost);
 	(void) hipFree(f->d_order);
-	(void) hipFree(f->d_pixel);
 	delete f;
 	return VKV_OK;
 }

@@ -210,8 +210,6 @@ struct vkv_ctx
 		const void *target;
 		uint32_t    img_w, img_h, tile_w, tile_h, first, stride, count;
 		uint32_t *  d_cost, *d_order;
-		uint8_t *   d_pixel;         // ray-order feedback: one byte per output pixel (RayMarchArgs::pixel_cost)
-		uint32_t    compact;         // the schedule's compact flag (it decides how the pixels of d_pixel are indexed)
 		bool        has_cost;        // a frame has been rendered into this target with the cost buffer attached
 		uint32_t    frames;          // frames rendered into this target so far (costs are measured and sorted every few frames)
 		uint32_t    measured_at = 0; // value of `frames` at the last measured frame
