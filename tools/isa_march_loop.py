@@ -1,0 +1,46 @@
+"""The march loop of each ray-march kernel in a `hipcc -S --cuda-device-only` listing: the SMALLEST backward-branch region that holds the
+probe byte load and the four footprint loads.  Prints instruction counts by class; with --dump the loop's instructions.
+usage: isa_march_loop.py file.s [name-filter] [--dump]"""
+import re
+import sys
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+dump = "--dump" in sys.argv
+s = open(args[0]).read()
+flt = args[1] if len(args) > 1 else ""
+for f in re.split(r'\n(?=_Z\w+:)', s):
+    name = f.split(':')[0]
+    if not name.startswith('_Z') or flt not in name:
+        continue
+    body = f.split('.Lfunc_end')[0]
+    labels, ins = {}, []
+    for l in body.split('\n'):
+        t = l.strip()
+        if not t or t.startswith(';') or (t.startswith('.') and not t.startswith('.LBB')):
+            continue
+        if t.startswith('.LBB') and t.split()[0].endswith(':'):
+            labels[t.split(':')[0]] = len(ins)
+            continue
+        if t.endswith(':'):
+            continue
+        ins.append(t.split(';')[0].strip())
+    loops = []
+    for i, t in enumerate(ins):
+        mm = re.match(r's_cbranch_\w+\s+(\.LBB\w+)|s_branch\s+(\.LBB\w+)', t)
+        if mm:
+            lab = mm.group(1) or mm.group(2)
+            if lab in labels and labels[lab] <= i:
+                loops.append((labels[lab], i))
+    def loads(a, b):
+        return sum(1 for x in ins[a:b + 1] if x.startswith(('global_load', 'buffer_load', 'flat_load')))
+    cand = [(a, b) for a, b in loops if loads(a, b) >= 4]
+    # innermost qualifying loops
+    cand = [(a, b) for a, b in cand if not any((a <= a2 and b2 <= b) and (a2, b2) != (a, b) for a2, b2 in cand)]
+    for a, b in cand:
+        seg = ins[a:b + 1]
+        c = lambda p: sum(1 for x in seg if x.startswith(p))
+        print("%-72s march loop %4d instr: valu %3d salu %3d vmem-load %2d lds %2d waitcnt %2d branch %2d" % (
+            name[:72], len(seg), c('v_'), c('s_') - c('s_waitcnt') - c('s_cbranch') - c('s_branch'), c(('global_load', 'buffer_load', 'flat_load')), c('ds_'),
+            c('s_waitcnt'), c(('s_cbranch', 's_branch'))))
+        if dump:
+            print("\n".join("    " + x for x in seg))
