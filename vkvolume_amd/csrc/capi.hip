@@ -278,7 +278,6 @@ static void default_tuning(VkvTuning &t)
 	t.screen_cull          = 1;
 	t.feedback             = 1;
 	t.feedback_period      = 8;
-	t.probe_hops           = 1;
 	t.arena_bytes          = 8u << 20;
 	auto env = [](const char *name) -> const char * { const char *e = std::getenv(name); return (e && e[0]) ? e : nullptr; };
 	if (const char *e = env("VKV_RAYMARCH_SCHEDULER"))
@@ -297,8 +296,6 @@ static void default_tuning(VkvTuning &t)
 		t.screen_cull = e[0] != '0';
 	if (const char *e = env("VKV_RAYMARCH_FEEDBACK"))
 		t.feedback = e[0] != '0';
-	if (const char *e = env("VKV_RAYMARCH_PROBE_HOPS"))
-		t.probe_hops = e[0] == '2' ? 2 : 1;
 	if (const char *e = env("VKV_RAYMARCH_FEEDBACK_PERIOD"))
 		t.feedback_period = (uint32_t) std::max(1l, std::atol(e));
 	if (const char *e = env("VKV_RAYMARCH_TILE_MIX"))
@@ -399,7 +396,7 @@ int vkv_set_tuning(vkv_ctx *ctx, const VkvTuning *tuning)
 	if (!tuning || tuning->struct_size != sizeof(VkvTuning))
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "set_tuning: struct_size must be sizeof(VkvTuning) = %zu (start from vkv_get_tuning)", sizeof(VkvTuning));
 	if (tuning->scheduler < 0 || tuning->scheduler > 1 || tuning->batch_mode < 0 || tuning->batch_mode > 1 || tuning->address_tables < 0 ||
-	    tuning->address_tables > 2 || tuning->probe_hops < 0 || tuning->probe_hops > 2 || tuning->feedback_period == 0 || tuning->gradient_segment > 255u ||
+	    tuning->address_tables > 2 || tuning->feedback_period == 0 || tuning->gradient_segment > 255u ||
 	    (tuning->pack_tile != 0 && tuning->pack_tile != 2 && tuning->pack_tile != 4))
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "set_tuning: field out of range");
 	std::lock_guard<std::mutex> lock(ctx->mutex);

@@ -131,15 +131,15 @@ static int launch_single(vkv_ctx *ctx, int skip, bool ert, int sched, const VkvT
 	}
 }
 
-static bool launch_batch(int skip, bool ert, int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, LeanChoice c, bool no_counts, bool hop2, hipStream_t s)
+static bool launch_batch(int skip, bool ert, int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, LeanChoice c, bool no_counts, hipStream_t s)
 {
 	switch (skip)
 	{
-		case VKV_SKIP_NONE: ert ? RayMarchLaunchers<VKV_SKIP_NONE, true>::batch(grad, d_frames, n, grid, gpf, c, no_counts, hop2, s) : RayMarchLaunchers<VKV_SKIP_NONE, false>::batch(grad, d_frames, n, grid, gpf, c, no_counts, hop2, s); return true;
-		case VKV_SKIP_BLOCK: ert ? RayMarchLaunchers<VKV_SKIP_BLOCK, true>::batch(grad, d_frames, n, grid, gpf, c, no_counts, hop2, s) : RayMarchLaunchers<VKV_SKIP_BLOCK, false>::batch(grad, d_frames, n, grid, gpf, c, no_counts, hop2, s); return true;
-		case VKV_SKIP_DISTANCE: ert ? RayMarchLaunchers<VKV_SKIP_DISTANCE, true>::batch(grad, d_frames, n, grid, gpf, c, no_counts, hop2, s) : RayMarchLaunchers<VKV_SKIP_DISTANCE, false>::batch(grad, d_frames, n, grid, gpf, c, no_counts, hop2, s); return true;
+		case VKV_SKIP_NONE: ert ? RayMarchLaunchers<VKV_SKIP_NONE, true>::batch(grad, d_frames, n, grid, gpf, c, no_counts, s) : RayMarchLaunchers<VKV_SKIP_NONE, false>::batch(grad, d_frames, n, grid, gpf, c, no_counts, s); return true;
+		case VKV_SKIP_BLOCK: ert ? RayMarchLaunchers<VKV_SKIP_BLOCK, true>::batch(grad, d_frames, n, grid, gpf, c, no_counts, s) : RayMarchLaunchers<VKV_SKIP_BLOCK, false>::batch(grad, d_frames, n, grid, gpf, c, no_counts, s); return true;
+		case VKV_SKIP_DISTANCE: ert ? RayMarchLaunchers<VKV_SKIP_DISTANCE, true>::batch(grad, d_frames, n, grid, gpf, c, no_counts, s) : RayMarchLaunchers<VKV_SKIP_DISTANCE, false>::batch(grad, d_frames, n, grid, gpf, c, no_counts, s); return true;
 		case VKV_SKIP_ANISOTROPIC_DISTANCE:
-			ert ? RayMarchLaunchers<VKV_SKIP_ANISOTROPIC_DISTANCE, true>::batch(grad, d_frames, n, grid, gpf, c, no_counts, hop2, s) : RayMarchLaunchers<VKV_SKIP_ANISOTROPIC_DISTANCE, false>::batch(grad, d_frames, n, grid, gpf, c, no_counts, hop2, s);
+			ert ? RayMarchLaunchers<VKV_SKIP_ANISOTROPIC_DISTANCE, true>::batch(grad, d_frames, n, grid, gpf, c, no_counts, s) : RayMarchLaunchers<VKV_SKIP_ANISOTROPIC_DISTANCE, false>::batch(grad, d_frames, n, grid, gpf, c, no_counts, s);
 			return true;
 		default: return false;
 	}
@@ -458,7 +458,7 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 			hipLaunchKernelGGL(k_tile_orders_from_cost, dim3(n), dim3(256), 0, s, d_frames);
 		return check_launch(ctx, "render_batch");
 	}
-	if (!launch_batch(P[0].options.skipping_type, ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, no_counts, T.probe_hops == 2, s))
+	if (!launch_batch(P[0].options.skipping_type, ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, no_counts, s))
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: bad skipping_type %d", P[0].options.skipping_type);
 	// behind the render, on the same stream: the costs it measured become the start order of the next frames into these targets (the
 	// sort is not in front of anybody's render this way; in front it cost 70 us per 20-frame block of three launches)

@@ -975,11 +975,6 @@ constexpr uint32_t kLeanNoCounts = 4u;        // the three per-pixel counters (v
                                               // additions and the EXEC-masked else-branch of the empty sample leave the loop
 constexpr uint32_t kLeanStamp    = 8u;        // (diagnostic, instantiated by tools/lab only, with the trace buffer) s_memtime at the top of every iteration,
                                               // summed per wave by the iteration's kind: only probing lanes / only sampling lanes / both
-constexpr uint32_t kLeanHop2     = 16u;       // a lane whose probe found an empty cell and that probes again at the position it skipped to (the next link of a
-                                              // probe chain: 5.7 hops on average on C3) takes that SECOND probe in the same wave iteration: its map byte is
-                                              // requested at the end of the first probe block and is in flight while the sampling lanes of the wave run the
-                                              // sample block; its outcome block follows the sample block.  Every ray's event sequence is the frag's
-                                              // (frag:215-312), a wave needs fewer iterations for it (vmcnt retires in order: probe 1, footprints, probe 2)
 constexpr size_t   kMaxLutBytes  = 8 * 1024;  // LDS budget of the two-level address tables (1.2 KB at 1024 voxels per axis, 1.9 KB at 2048)
 
 __device__ __forceinline__ float cvt_ubyte0(uint32_t q) { float f; asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(q)); return f; }
@@ -1207,7 +1202,6 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	constexpr bool kStamp = (LF & kLeanStamp) != 0, kCounts = (LF & kLeanNoCounts) == 0;
 	constexpr bool kHoist = PACKED && GRAD != 2;
 	constexpr bool kLut = (LF & kLeanLut) != 0, kFull = (LF & kLeanFull) != 0 && SEP, kTf = SEP && kHoist;
-	constexpr bool kHop2 = (LF & kLeanHop2) != 0 && SKIP != VKV_SKIP_NONE;
 	uint32_t       stamp_prev = 0, stamp_kind = 3;
 	const int      W = A.W, H = A.H, D = A.D;
 	const float    kx = SKIP != VKV_SKIP_NONE ? (float) W / A.block_size[0] : 0.0f, ky = SKIP != VKV_SKIP_NONE ? (float) H / A.block_size[1] : 0.0f,
@@ -1221,53 +1215,6 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	FullLutConsts fullc = {};
 	if (kFull)
 		fullc = full_lut_consts(A);
-	// distance-map cell of a position (frag:192, 220-221): u = position in cells, ui = clamp(trunc(u), 0, map - 1), linear index
-	struct MapCell
-	{
-		float    ux, uy, uz;
-		int      uix, uiy, uiz;
-		uint32_t cell;
-	};
-	auto cell_of = [&](float px, float py, float pz) {
-		MapCell c;
-		c.ux = kx * px, c.uy = ky * py, c.uz = kz * pz;
-		if (kLut)
-		{
-			c.uix = clamp0_i32((int) c.ux, mw1), c.uiy = clamp0_i32((int) c.uy, mh1), c.uiz = clamp0_i32((int) c.uz, md1);
-			c.cell = mad_u24(mad_u24((uint32_t) c.uiz, (uint32_t) A.mh, (uint32_t) c.uiy), (uint32_t) A.mw, (uint32_t) c.uix);
-		}
-		else
-		{
-			c.uix = med3_i32((int) c.ux, 0, mw1), c.uiy = med3_i32((int) c.uy, 0, mh1), c.uiz = med3_i32((int) c.uz, 0, md1);
-			c.cell = __umul24(__umul24((uint32_t) c.uiz, (uint32_t) A.mh) + (uint32_t) c.uiy, (uint32_t) A.mw) + (uint32_t) c.uix;
-		}
-		return c;
-	};
-	// skip length of a probe that found the cell empty (frag:234-247): max(1, ceil(min over the axes)), as a float
-	auto skip_of = [&](const MapCell &c, uint32_t dist) {
-		const float rx = __builtin_amdgcn_fmed3f((float) c.uix - c.ux, -1.0f, 0.0f);
-		const float ry = __builtin_amdgcn_fmed3f((float) c.uiy - c.uy, -1.0f, 0.0f);
-		const float rz = __builtin_amdgcn_fmed3f((float) c.uiz - c.uz, -1.0f, 0.0f);
-		float       ax, ay, az;
-		if (SKIP == VKV_SKIP_BLOCK)
-		{
-			ax = (((R.six < 0.0f) ? 0.0f : 1.0f) + rx) * R.six;
-			ay = (((R.siy < 0.0f) ? 0.0f : 1.0f) + ry) * R.siy;
-			az = (((R.siz < 0.0f) ? 0.0f : 1.0f) + rz) * R.siz;
-		}
-		else
-		{        // step(0, -s) + sign(s) * dist = fd for s > 0, 1 - fd for s < 0: one fma with per-ray constants (exact: the product is exact)
-			const float fd = (float) dist;
-			ax = (__builtin_fmaf(sgx, fd, ofx) + rx) * R.six;
-			ay = (__builtin_fmaf(sgy, fd, ofy) + ry) * R.siy;
-			az = (__builtin_fmaf(sgz, fd, ofz) + rz) * R.siz;
-		}
-		// a NaN component (0 * inf on an axis-parallel ray) counts as +inf: minNum ignores it; all three cannot be NaN, and if
-		// they were the comparison caps the result exactly as the select chain of the oracle does
-		float m = __builtin_fminf(__builtin_fminf(ax, ay), az);
-		m       = (m < 1073741824.0f) ? m : 1073741824.0f;
-		return __builtin_fmaxf(1.0f, __builtin_ceilf(m));        // a NaN m gives 1 as max(1, (int) NaN = 0) does
-	};
 	// loop position, its bounds and the first hit as floats (exact: n_steps <= 2^24)
 	float       li = (float) R.i, li_min = (float) R.i_min, lfirst = (float) R.first_hit;
 	const float ln = (float) R.n_steps, lback = (float) A.back;
@@ -1275,10 +1222,23 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	{
 		const float i    = li;
 		const float posx = __builtin_fmaf(i, R.sx, R.ex), posy = __builtin_fmaf(i, R.sy, R.ey), posz = __builtin_fmaf(i, R.sz, R.ez);
-		MapCell     h = {};
+		int         uix = 0, uiy = 0, uiz = 0;
+		float       ux = 0, uy = 0, uz = 0;
+		uint32_t    cell = 0;
 		if (SKIP != VKV_SKIP_NONE)
-			h = cell_of(posx, posy, posz);
-		const uint32_t cell = h.cell;
+		{        // frag:192, 220-221
+			ux = kx * posx, uy = ky * posy, uz = kz * posz;
+			if (kLut)
+			{
+				uix = clamp0_i32((int) ux, mw1), uiy = clamp0_i32((int) uy, mh1), uiz = clamp0_i32((int) uz, md1);
+				cell = mad_u24(mad_u24((uint32_t) uiz, (uint32_t) A.mh, (uint32_t) uiy), (uint32_t) A.mw, (uint32_t) uix);
+			}
+			else
+			{
+				uix = med3_i32((int) ux, 0, mw1), uiy = med3_i32((int) uy, 0, mh1), uiz = med3_i32((int) uz, 0, md1);
+				cell = __umul24(__umul24((uint32_t) uiz, (uint32_t) A.mh) + (uint32_t) uiy, (uint32_t) A.mw) + (uint32_t) uix;
+			}
+		}
 		const bool probe = SKIP != VKV_SKIP_NONE && !occ && cell != ul;        // frag:224
 		if (kStamp)
 		{
@@ -1313,6 +1273,33 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			q01 = load_row(ba + 50);
 			q11 = load_row(ba + 60);
 		}
+
+		// ---- probe outcome (frag:234-247); needs the probe byte only ---------------------------------------------------
+		float skip = 0.0f;
+		auto  probe_outcome = [&]() {
+			const float rx = __builtin_amdgcn_fmed3f((float) uix - ux, -1.0f, 0.0f);
+			const float ry = __builtin_amdgcn_fmed3f((float) uiy - uy, -1.0f, 0.0f);
+			const float rz = __builtin_amdgcn_fmed3f((float) uiz - uz, -1.0f, 0.0f);
+			float       ax, ay, az;
+			if (SKIP == VKV_SKIP_BLOCK)
+			{
+				ax = (((R.six < 0.0f) ? 0.0f : 1.0f) + rx) * R.six;
+				ay = (((R.siy < 0.0f) ? 0.0f : 1.0f) + ry) * R.siy;
+				az = (((R.siz < 0.0f) ? 0.0f : 1.0f) + rz) * R.siz;
+			}
+			else
+			{        // step(0, -s) + sign(s) * dist = fd for s > 0, 1 - fd for s < 0: one fma with per-ray constants (exact: the product is exact)
+				const float fd = (float) dist;
+				ax = (__builtin_fmaf(sgx, fd, ofx) + rx) * R.six;
+				ay = (__builtin_fmaf(sgy, fd, ofy) + ry) * R.siy;
+				az = (__builtin_fmaf(sgz, fd, ofz) + rz) * R.siz;
+			}
+			// a NaN component (0 * inf on an axis-parallel ray) counts as +inf: minNum ignores it; all three cannot be NaN, and if
+			// they were the comparison caps the result exactly as the select chain of the oracle does
+			float m = __builtin_fminf(__builtin_fminf(ax, ay), az);
+			m       = (m < 1073741824.0f) ? m : 1073741824.0f;
+			skip    = __builtin_fmaxf(1.0f, __builtin_ceilf(m));        // a NaN m gives 1 as max(1, (int) NaN = 0) does
+		};
 
 		// ---- sample outcome (frag:272-284) ---------------------------------------------------------------------------
 		float    intensity = 0.0f, gradient = 1.0f;
@@ -1411,13 +1398,9 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		// ---- the frag's state update (frag:224-310) under EXEC: plain moves and adds instead of selects ------------------
 		__builtin_amdgcn_wave_barrier();        // emits nothing; keeps the load blocks above apart from the blocks below (left to itself the
 		                                        // compiler sinks each load into its block: the footprint would be requested after the probe outcome)
-		bool     probe2 = false;        // kLeanHop2: this lane takes a second probe in this iteration
-		uint32_t dist2  = 0;
-		if (kHop2)
-			dist2 = undefined_value<uint32_t>();
 		if (probe)
 		{
-			const float skip = skip_of(h, dist);        // an empty side is skipped by the branch the compiler puts around it (s_cbranch_execz)
+			probe_outcome();        // an empty side is skipped by the branch the compiler puts around it (s_cbranch_execz)
 			if (kCounts)
 				++R.n_dist;
 			// frag:244-247 (dist > 0: skip) and frag:253-261 (occupied cell: step back).  The step-back side is three instructions: as
@@ -1430,21 +1413,8 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			occ  = hit ? true : occ;
 			ul   = hit ? cell : ul;
 			done = li >= ln;
-			if (kHop2)
-			{        // the next event of a lane that skipped and is still inside its ray: a probe again unless it landed in the cell of
-				 // its last occupied sample (frag:224 with voxel_occupied == false, which a probing lane has and a skip keeps)
-				if (!hit && !done)
-				{
-					const MapCell h2 = cell_of(__builtin_fmaf(li, R.sx, R.ex), __builtin_fmaf(li, R.sy, R.ey), __builtin_fmaf(li, R.sz, R.ez));
-					probe2           = h2.cell != ul;
-					if (probe2)
-						dist2 = load_u8_global(R.dmap, h2.cell);
-				}
-			}
 		}
-		if (kHop2)
-			__builtin_amdgcn_wave_barrier();        // the second probe's request stays in front of the sample block
-		if (!probe)
+		else
 		{
 			sample_outcome();
 			if (kCounts)
@@ -1480,26 +1450,6 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 				li_min = li;
 			}
 			done = ended || li >= ln;
-		}
-		if (kHop2)
-		{
-			__builtin_amdgcn_wave_barrier();
-			if (probe2)
-			{        // the second probe of this iteration: position li (recomputed: cheaper than seven registers kept across the sample block)
-				const float   i2 = li;
-				const MapCell h2 = cell_of(__builtin_fmaf(i2, R.sx, R.ex), __builtin_fmaf(i2, R.sy, R.ey), __builtin_fmaf(i2, R.sz, R.ez));
-				const float   skip2 = skip_of(h2, dist2);
-				if (kCounts)
-					++R.n_dist;
-				const float back_to = max_f32_raw(i2 - lback, li_min);
-				const bool  hit     = dist2 == 0u;
-				li                  = back_to;
-				if (!hit)
-					li = i2 + skip2;
-				occ  = hit ? true : occ;
-				ul   = hit ? h2.cell : ul;
-				done = li >= ln;
-			}
 		}
 		// the frame time is the critical path of the wave with the longest ray: once a wave has run 48 iterations it is one of
 		// those, so let it win instruction arbitration against the younger waves on its SIMD

@@ -21,9 +21,6 @@ constexpr uint32_t kLfLut    = kLeanLut;                         // two-level ad
 constexpr uint32_t kLfFull   = kLeanLut | kLeanFull;             // + one entry per voxel index with the separable transfer function
 constexpr uint32_t kLfFullNc = kLfFull | kLeanNoCounts;          // the same without the per-pixel counters (what a renderer launches)
 constexpr uint32_t kLfLutNc  = kLfLut | kLeanNoCounts;
-// VkvTuning.probe_hops = 2: the four table kernels of the common configuration (empty-space skipping + ERT + gradient map) with a second
-// probe per iteration (kLeanHop2)
-constexpr uint32_t kLfHop(uint32_t lf) { return lf | kLeanHop2; }
 
 struct LeanChoice
 {
@@ -44,7 +41,7 @@ struct RayMarchLaunchers
 	// one frame (vkv_render); grad: 0 unused, 1 precomputed map, 2 on the fly
 	static int single(vkv_ctx *ctx, int sched, const VkvTuning &T, int grad, RayMarchArgs &a, hipStream_t s);
 	// n frames interleaved in one grid (vkv_render_batch); c = {0, 0}: the frames disagree about the tables
-	static void batch(int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, LeanChoice c, bool no_counts, bool hop2, hipStream_t s);
+	static void batch(int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, LeanChoice c, bool no_counts, hipStream_t s);
 	// the same with resident workgroups whose waves pull their units; returns the grid size
 	static uint32_t pull(vkv_ctx *ctx, int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t *d_heads, LeanChoice c, uint64_t units, hipStream_t s);
 };
@@ -82,25 +79,14 @@ static int launch_one(vkv_ctx *ctx, int sched, const VkvTuning &T, RayMarchArgs 
 		if constexpr (PACKED && GRAD != 2)
 		{
 			const LeanChoice c = choose_lean(a, T);
-			bool no_counts = false, hop2 = false;
+			bool no_counts = false;
 			if constexpr (SKIP != VKV_SKIP_NONE && ERT && GRAD == 1)
-			{        // the common configuration only: every further instantiation costs build time
-				no_counts = c.kind != 0 && !wants_counts(a);
-				hop2      = c.kind != 0 && T.probe_hops == 2;
-			}
-			if (no_counts || hop2)
+				no_counts = c.kind != 0 && !wants_counts(a);        // the common configuration only: every further instantiation costs build time
+			if (no_counts)
 			{
 				if constexpr (SKIP != VKV_SKIP_NONE && ERT && GRAD == 1)
 				{
-					if (c.kind == 2 && no_counts && hop2)
-						hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfHop(kLfFullNc)>), dim3(grid), dim3(256), c.lds, s, a);
-					else if (c.kind == 2 && hop2)
-						hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfHop(kLfFull)>), dim3(grid), dim3(256), c.lds, s, a);
-					else if (no_counts && hop2)
-						hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfHop(kLfLutNc)>), dim3(grid), dim3(256), c.lds, s, a);
-					else if (hop2)
-						hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfHop(kLfLut)>), dim3(grid), dim3(256), c.lds, s, a);
-					else if (c.kind == 2)
+					if (c.kind == 2)
 						hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfFullNc>), dim3(grid), dim3(256), c.lds, s, a);
 					else
 						hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfLutNc>), dim3(grid), dim3(256), c.lds, s, a);
@@ -128,23 +114,15 @@ int RayMarchLaunchers<SKIP, ERT>::single(vkv_ctx *ctx, int sched, const VkvTunin
 
 // ---- several frames in one launch --------------------------------------------------------------------------------
 template <int SKIP, bool ERT, int GRAD>
-static void launch_batch_kind(LeanChoice c, bool no_counts, bool hop2, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, hipStream_t s)
+static void launch_batch_kind(LeanChoice c, bool no_counts, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, hipStream_t s)
 {
 	if constexpr (GRAD != 2)
 	{
 		if constexpr (SKIP != VKV_SKIP_NONE && ERT && GRAD == 1)
 		{
-			if (c.kind != 0 && (no_counts || hop2))
+			if (c.kind != 0 && no_counts)
 			{
-				if (c.kind == 2 && no_counts && hop2)
-					hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfHop(kLfFullNc)>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
-				else if (c.kind == 2 && hop2)
-					hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfHop(kLfFull)>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
-				else if (no_counts && hop2)
-					hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfHop(kLfLutNc)>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
-				else if (hop2)
-					hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfHop(kLfLut)>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
-				else if (c.kind == 2)
+				if (c.kind == 2)
 					hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfFullNc>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
 				else
 					hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfLutNc>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
@@ -162,15 +140,15 @@ static void launch_batch_kind(LeanChoice c, bool no_counts, bool hop2, const Ray
 }
 
 template <int SKIP, bool ERT>
-void RayMarchLaunchers<SKIP, ERT>::batch(int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, LeanChoice c, bool no_counts, bool hop2, hipStream_t s)
+void RayMarchLaunchers<SKIP, ERT>::batch(int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, LeanChoice c, bool no_counts, hipStream_t s)
 {
 	// c.kind > 0: every frame of the batch has address tables of that size (same volume extent) and they fit the LDS budget
 	if (grad == 0)
-		launch_batch_kind<SKIP, ERT, 0>(c, no_counts, hop2, d_frames, n, grid, gpf, s);
+		launch_batch_kind<SKIP, ERT, 0>(c, no_counts, d_frames, n, grid, gpf, s);
 	else if (grad == 1)
-		launch_batch_kind<SKIP, ERT, 1>(c, no_counts, hop2, d_frames, n, grid, gpf, s);
+		launch_batch_kind<SKIP, ERT, 1>(c, no_counts, d_frames, n, grid, gpf, s);
 	else
-		launch_batch_kind<SKIP, ERT, 2>(c, no_counts, hop2, d_frames, n, grid, gpf, s);
+		launch_batch_kind<SKIP, ERT, 2>(c, no_counts, d_frames, n, grid, gpf, s);
 }
 
 // ---- the same, with resident workgroups whose waves pull their units ------------------------------------------------
