@@ -5,6 +5,7 @@ TEST INFRASTRUCTURE ONLY: imported by ``tests/``, ``__graft_entry__.smoke()`` an
 """
 import ctypes as C
 import os
+import time
 import subprocess
 
 import numpy as np
@@ -48,6 +49,8 @@ def lib():
     build()
     name = "libvkv_oracle_fma.so" if _has_fma() and os.path.exists(os.path.join(_HERE, "libvkv_oracle_fma.so")) \
         else "libvkv_oracle.so"
+    # tests/test_sanitizers_cpu.py: the ASan + UBSan build (`make -C oracle asan`), in a process that has the ASan runtime preloaded
+    name = os.environ.get("VKV_ORACLE_LIB", name)
     L = C.CDLL(os.path.join(_HERE, name))
     u8p, f32p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.c_void_p
     L.vkvo_transfer_function_uniform.argtypes = [C.POINTER(abi.VolumeOptions), C.POINTER(abi.TransferFunctionUniform)]
@@ -166,14 +169,16 @@ def synth_volume(shape_whd, kind, seed):
 
 
 class RenderResult:
-    def __init__(self, color, counts, depth, rgba8, rays):
+    def __init__(self, color, counts, depth, rgba8, rays, seconds=0.0):
         self.color, self.counts, self.depth, self.rgba8, self.rays = color, counts, depth, rgba8, rays
+        self.seconds = seconds  # wall time of the vkvo_render call alone (outputs allocated and touched before it)
 
 
 def render(params, vol, grad, tf_tex, maps, n_threads=None, pixel_stride=1, want_rgba8=False, in_depth=None, target_color=None,
-           target_rgba8=None):
+           target_rgba8=None, reuse=None):
     """Run the oracle ray-marcher. ``params`` is an ``abi.RenderParams`` whose pointer fields are overwritten with
-    host arrays; outputs are image-shaped (or compact, following ``params.tiles``).  ``in_depth`` feeds the DEPTH_ATTACHMENT
+    host arrays; outputs are image-shaped (or compact, following ``params.tiles``).  ``reuse``: a RenderResult of the same shape whose
+    arrays are cleared and written again (bench.py: no allocation, no first-touch page faults inside the timed call).  ``in_depth`` feeds the DEPTH_ATTACHMENT
     variant; ``target_color`` / ``target_rgba8`` are existing frames to blend onto (sets ``blend_over_target``)."""
     p = abi.RenderParams.from_buffer_copy(params)
     vol = np.ascontiguousarray(vol, np.uint8)
@@ -199,13 +204,19 @@ def render(params, vol, grad, tf_tex, maps, n_threads=None, pixel_stride=1, want
     else:
         shape = (p.image_height, p.image_width)
     blend = target_color is not None or target_rgba8 is not None
-    color = np.zeros(shape + (4,), np.float32) if target_color is None else np.ascontiguousarray(target_color, np.float32).copy()
-    counts = np.zeros(shape + (3,), np.uint32)
-    depth = np.zeros(shape, np.float32)
     want_rgba8 = want_rgba8 or target_rgba8 is not None
     rgba8 = None
-    if want_rgba8:
-        rgba8 = np.zeros(shape + (4,), np.uint8) if target_rgba8 is None else np.ascontiguousarray(target_rgba8, np.uint8).copy()
+    if reuse is not None and not blend and reuse.counts.shape == shape + (3,) and (reuse.rgba8 is not None) == want_rgba8:
+        color, counts, depth, rgba8 = reuse.color, reuse.counts, reuse.depth, reuse.rgba8
+        color.fill(0), counts.fill(0), depth.fill(0)
+        if rgba8 is not None:
+            rgba8.fill(0)
+    else:
+        color = np.zeros(shape + (4,), np.float32) if target_color is None else np.ascontiguousarray(target_color, np.float32).copy()
+        counts = np.zeros(shape + (3,), np.uint32)
+        depth = np.zeros(shape, np.float32)
+        if want_rgba8:
+            rgba8 = np.zeros(shape + (4,), np.uint8) if target_rgba8 is None else np.ascontiguousarray(target_rgba8, np.uint8).copy()
     p.blend_over_target = 1 if blend else 0
     p.d_in_depth = None
     if in_depth is not None:
@@ -216,9 +227,11 @@ def render(params, vol, grad, tf_tex, maps, n_threads=None, pixel_stride=1, want
     p.d_out_rgba8 = rgba8.ctypes.data if want_rgba8 else None
     if n_threads is None:
         n_threads = os.cpu_count() or 1
+    t0 = time.perf_counter()
     rays = lib().vkvo_render(C.byref(p), n_threads, pixel_stride)
+    seconds = time.perf_counter() - t0
     del keep
-    return RenderResult(color, counts, depth, rgba8, rays)
+    return RenderResult(color, counts, depth, rgba8, rays, seconds)
 
 
 class Header(C.Structure):
