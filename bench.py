@@ -106,7 +106,7 @@ if ROOT not in sys.path:
 
 from vkvolume_amd import abi, camera, lib, multigpu, volume as V  # noqa: E402
 
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_traffic.json")  # PMC-measured HBM bytes per launch (own rocprofv3 passes)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r4_traffic.json")  # PMC-measured HBM bytes per launch (own rocprofv3 passes)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 WORKLOADS = {
@@ -135,7 +135,7 @@ def kernel_source_digest():
     import hashlib
     import re
     h = hashlib.sha256()
-    for name in ("raymarch_core.hpp", "raymarch.hip", "vkv_device.hpp", "Makefile"):
+    for name in ("raymarch_core.hpp", "raymarch_inst.hpp", "raymarch.hip", "vkv_device.hpp", "Makefile"):
         with open(os.path.join(ROOT, "vkvolume_amd", "csrc", name), "r", errors="replace") as f:
             text = f.read()
         if not name.endswith("Makefile"):
@@ -612,9 +612,12 @@ def main():
                 # measured with 8 frames per launch: scaled to this run's average launch
                 out["roofline"]["traffic"] = int(tr["traffic_bytes_per_launch"] * out["roofline"]["frames_per_launch"] / tr.get("frames_per_launch", 8))
                 out["roofline"]["traffic_source"] = tr["source"]
-                if tr.get("valu_busy") is not None:
-                    # the binding limit: share of the SIMD cycles of that launch in which a VALU instruction was executing (PMC pass, same file)
-                    out["roofline"]["valu_busy"] = tr["valu_busy"]
+                # the binding limit (same PMC passes, DESIGN.md section 6 has the formulas): valu_issue_frac = the launch's VALU wave-instructions
+                # by SQ counter class x the issue cost measured for the opcodes of that class on gfx950 / the SIMD cycles of the launch;
+                # wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES (share of a resident wave's time parked in s_waitcnt); waves_per_simd = resident waves
+                for k in ("valu_issue_frac", "wait_frac", "waves_per_simd"):
+                    if tr.get(k) is not None:
+                        out["roofline"][k] = tr[k]
             else:
                 out["roofline"]["traffic_source"] = "withheld: %s was measured on other integrator sources than this tree's" % os.path.basename(TRAFFIC_FILE)
     except (OSError, ValueError, KeyError):
