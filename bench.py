@@ -42,14 +42,19 @@ import time
 
 
 
-def self_launch(argv):
+def self_launch(argv, child_cmd=None):
     """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the PARENT of the job.  It starts
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a
     child BEFORE anything here has touched the GPU (no exec from a process that has initialised HIP: it never initialises it), relays
-    the one JSON line rank 0 prints and exits with the children's status.  `--dry-launch` prints the child command line instead."""
+    the one JSON line rank 0 prints and exits with the children's status.  `--dry-launch` prints the child command line instead.
+    `--launch-timeout S` (default 900): if the ranks have not finished after S seconds (an RCCL bring-up that hangs, a rank that died
+    while the others wait in a collective) the parent kills the process group it started - fresh processes in a session of their own,
+    never a re-exec - and exits with status 124.  `child_cmd` replaces the command (tests)."""
+    import signal
     import socket
     import subprocess
-    n, dry = 1, False
+    import threading
+    n, dry, timeout = 1, False, 900.0
     for i, a in enumerate(argv):
         if a == "--gpus" and i + 1 < len(argv):
             n = int(argv[i + 1])
@@ -57,6 +62,10 @@ def self_launch(argv):
             n = int(a.split("=", 1)[1])
         elif a == "--dry-launch":
             dry = True
+        elif a == "--launch-timeout" and i + 1 < len(argv):
+            timeout = float(argv[i + 1])
+        elif a.startswith("--launch-timeout="):
+            timeout = float(a.split("=", 1)[1])
     if n <= 1 or "WORLD_SIZE" in os.environ:
         return  # a rank of an existing job (or N = 1): run in this process
     port = os.environ.get("MASTER_PORT")
@@ -65,14 +74,27 @@ def self_launch(argv):
             sk.bind(("127.0.0.1", 0))
             port = str(sk.getsockname()[1])
     child_args = [a for a in argv if a != "--dry-launch"]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", port,
-           os.path.abspath(__file__)] + child_args
+    cmd = child_cmd or ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", port,
+                         os.path.abspath(__file__)] + child_args)
     if dry:
-        print(json.dumps({"dry_launch": cmd, "n_ranks": n}))
+        print(json.dumps({"dry_launch": cmd, "n_ranks": n, "launch_timeout_s": timeout}))
         raise SystemExit(0)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)  # own process group: killable as a whole
+    timed_out = []
+
+    def kill_job():
+        timed_out.append(True)
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)  # exactly the group this parent started
+        except OSError:
+            pass
+
+    watchdog = threading.Timer(timeout, kill_job) if timeout > 0 else None
+    if watchdog:
+        watchdog.daemon = True
+        watchdog.start()
     line = None
     for out_line in proc.stdout:  # rank 0 prints exactly one JSON line; anything else a child writes to stdout goes to stderr
         t = out_line.strip()
@@ -81,6 +103,11 @@ def self_launch(argv):
         elif t:
             print(t, file=sys.stderr)
     rc = proc.wait()
+    if watchdog:
+        watchdog.cancel()
+    if timed_out:
+        print("bench.py: the ranks did not finish within --launch-timeout %.0f s: killed" % timeout, file=sys.stderr)
+        raise SystemExit(124)
     if rc != 0:
         raise SystemExit(rc if rc > 0 else 1)
     if line is None:
@@ -227,6 +254,10 @@ def main():
     ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 without WORLD_SIZE: print the torch.distributed.run command line the "
                     "parent would start, and exit")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--launch-timeout", type=float, default=900.0, help="--gpus N > 1 without WORLD_SIZE: seconds after which the parent kills the ranks it "
+                    "started and exits with status 124 (0 = never)")
+    ap.add_argument("--c5-block", default="auto", choices=["auto", "on", "off"], help="after the headline blocks, a short block of BASELINE.json configs[4] (c5: "
+                    "2048^3, anisotropic maps, the fixed 7680x4320 frame dealt over the ranks), reported as \"c5_strong\" in the same line; auto = at N > 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -255,6 +286,32 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     ctx = lib.Context(local_rank)  # raises if the HIP library is missing: there is no fallback path
+    env = {"world": world, "rank": rank, "local_rank": local_rank, "dist": dist, "ctx": ctx, "use_gather": use_gather, "submit": submit}
+    out = job(args, env)
+    # BASELINE.json configs[4] is the configuration north_star names for 8 GPUs: at N > 1 the same ranks then time a short block of it (strong
+    # scaling: the 7680x4320 frame is fixed, its tiles are dealt over the ranks); c3 stays the headline so that N = 1 agrees with BENCH
+    if args.c5_block == "on" or (args.c5_block == "auto" and world > 1 and args.workload != "c5"):
+        import copy
+        a2 = copy.copy(args)
+        a2.workload, a2.scaling, a2.skip, a2.tf, a2.no_ert = "c5", "strong", None, "app", False
+        a2.steps, a2.warmup, a2.min_seconds = min(args.steps, 16), min(args.warmup, 8), min(args.min_seconds, 1.0)
+        a2.verify, a2.no_cpu_baseline, a2.no_depth_block = False, True, True
+        torch.cuda.empty_cache()
+        o2 = job(a2, env)
+        if rank == 0:
+            out["c5_strong"] = {k: o2[k] for k in ("ms_per_step", "value", "unit", "steps", "warmup", "repeats", "scaling", "covered_Mray_per_s", "phases") if k in o2}
+            out["c5_strong"].update(frac=o2["roofline"]["frac"], achieved=o2["roofline"]["achieved"], workload=o2["config"]["workload"],
+                                    parallelism=o2["config"]["parallelism"])
+    if rank == 0:
+        print(json.dumps(out), file=json_out, flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def job(args, env):
+    """One measurement (scene set-up, pre-pass, warm-up, the timed blocks) of args.workload on the ranks of `env`; returns the result
+    line as a dict on rank 0, None elsewhere."""
+    world, rank, local_rank, dist, ctx, use_gather, submit = (env[k] for k in ("world", "rank", "local_rank", "dist", "ctx", "use_gather", "submit"))
     v, tf, frame, skip = build_scene(ctx, args.workload, args.tf)
     if args.skip is not None:
         skip = {"none": abi.SKIP_NONE, "block": abi.SKIP_BLOCK, "distance": abi.SKIP_DISTANCE, "anisotropic": abi.SKIP_ANISOTROPIC_DISTANCE}[args.skip]
@@ -331,6 +388,8 @@ def main():
     xchg = torch.cuda.Stream(priority=-1) if gather else None  # native exchange: RCCL's gather here, the de-interleave on `side`
     freed = [None] * (nsets if (use_gather and submit == "batch") else nbuf)
     launches = []  # (start event, stop event, algorithmic bytes) of the timed launches of the last block
+    phases = []  # gather path, launches this rank owns: (render start, render end, gathered or None, de-interleaved) events
+    phase_ms = {"render_ms": [], "gather_ms": [], "scatter_ms": [], "exchange_ms": []}
 
     # per-launch parameter blocks of the batch path: slot j of a launch renders into bufs[j]
     batch_params = None
@@ -395,6 +454,10 @@ def main():
                 # vkv_assemble_frames on the exchange stream, behind the launch: one ncclGather + one de-interleave kernel, nothing waits on the host
                 xchg.wait_event(rendered)
                 gather.assemble(slot, owner, n, xchg)
+                if timed and rank == owner:  # phases of a launch on its owner: render, then gather + de-interleave (one call here)
+                    x1 = torch.cuda.Event(enable_timing=True)
+                    x1.record(xchg)
+                    phases.append((e0, e1, None, x1))
                 freed[slot] = torch.cuda.Event()
                 freed[slot].record(xchg)
                 last_owner[0] = owner
@@ -402,10 +465,18 @@ def main():
                 with torch.cuda.stream(side):
                     got = gather.finish(slot)
                     if got is not None:
+                        g1 = None
+                        if timed:
+                            g1 = torch.cuda.Event(enable_timing=True)
+                            g1.record(side)  # the launch's block has arrived from every rank
                         flat, nf = got
                         for j in range(nf):
                             src, stride = gather.frame_source(flat, j)
                             ctx.scatter_tiles(src, images[slot * fpl + j].data_ptr(), (fw, fh), (TILE, TILE), world, stride, 4, side.cuda_stream)
+                        if timed:
+                            s1 = torch.cuda.Event(enable_timing=True)
+                            s1.record(side)
+                            phases.append((e0, e1, g1, s1))
                     freed[slot] = torch.cuda.Event()
                     freed[slot].record(side)
                 last_owner[0] = owner
@@ -464,6 +535,7 @@ def main():
     total = 0.0
     while True:
         del launches[:]
+        del phases[:]
         fence()
         t0 = time.perf_counter()
         run(args.steps, True)
@@ -477,6 +549,14 @@ def main():
         blocks.append(elapsed)
         enqueue_times.append(host_enqueue)
         kernel_ms += [e0.elapsed_time(e1) for e0, e1, _, _ in launches]
+        for p0, p1, pg, ps in phases:
+            phase_ms["render_ms"].append(p0.elapsed_time(p1))
+            if pg is not None:
+                phase_ms["gather_ms"].append(p1.elapsed_time(pg))
+                phase_ms["scatter_ms"].append(pg.elapsed_time(ps))
+            else:
+                phase_ms["exchange_ms"].append(p1.elapsed_time(ps))
+        del phases[:]
         kernel_bytes += [b for _, _, b, _ in launches]
         kernel_frames += [n for _, _, _, n in launches]
         total += elapsed
@@ -548,8 +628,7 @@ def main():
     if rank != 0:
         if native:
             gather.close()
-        dist.destroy_process_group()
-        return
+        return None
 
     value = rays_per_frame_all * args.steps / elapsed / 1e6
     aggregate_gbs = sum(frame_bytes[k % N_VIEWS] for k in range(args.steps)) / elapsed / 1e9
@@ -559,7 +638,8 @@ def main():
     out = {
         "metric": "Mray/s", "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic", "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+        "dtype": "f32", "data": "synthetic", "rccl_ranks": (gather.comm_count() if native else (dist.get_world_size() if dist is not None else 1)),
+        "rccl_ranks_source": ("ncclCommCount of the exchange's own communicator" if native else ("torch.distributed.get_world_size (backend nccl = RCCL)" if dist is not None else "no communicator")),
         "repeats": len(blocks), "host_enqueue_ms_per_step": round(float(np.median(enqueue_times)) / args.steps * 1e3, 4), "ms_per_step_min_max": [round(min(blocks) / args.steps * 1e3, 4), round(max(blocks) / args.steps * 1e3, 4)],
         "config": {"workload": "%s (%s): %dx%dx%d uint8 synthetic shells, %dx%d frame, %s, block 4, TF %s, "
                                "8 orbit views" % (args.workload, WORKLOAD_NOTE[args.workload], *extent, fw, fh,
@@ -593,6 +673,11 @@ def main():
                              "gaps between launches. single_frame is the same kernel with nothing else running. HIP events bracket every launch at "
                              "N = 1 and every 7th launch on the gather path (where launches of consecutive frames overlap)"},
     }
+    if any(phase_ms.values()):
+        # HIP-event times of the launches rank 0 owned, from the render's end: gather_ms includes waiting for the slowest rank's render (torch
+        # exchange: until the block has arrived; then scatter_ms = the de-interleave kernels), exchange_ms = both (native: one call)
+        out["phases"] = {k: round(float(np.mean(x)), 4) for k, x in phase_ms.items() if x}
+        out["phases"].update(launches_sampled=len(phase_ms["render_ms"]), rank=0, frames_per_launch=out["roofline"]["frames_per_launch"])
     if single is not None:
         out["single_frame"] = single
     if depth_ms is not None:
@@ -625,11 +710,9 @@ def main():
 
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ctx, sp, v, params, (fw, fh), args.cpu_seconds, not args.no_verify_cpu, out)
-    print(json.dumps(out), file=json_out, flush=True)
     if native:
         gather.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    return out
 
 
 def verify(ctx, sp, v, views, params, steps, nbuf, fpl, frame, bufs, images, gather, rank, owner):

@@ -797,6 +797,7 @@ typedef struct
 	const float *          lut;
 	uint32_t               stride;
 	uint64_t               n_items;        /* tile_count * ceil(tile_height / CHUNK_ROWS) */
+	uint64_t               grab;           /* items per claim */
 	/* the two words the workers write, on a cache line of their own (the fields above are read per pixel by every worker) */
 	__attribute__((aligned(64))) uint64_t next;        /* next unclaimed item (atomic) */
 	uint64_t                              rays;        /* rays marched (atomic, added once per worker) */
@@ -813,11 +814,19 @@ static void render_items(RenderJob *job)
 	const float *          lut     = job->lut;
 	const uint64_t         n_items = job->n_items;
 	uint64_t               rays    = 0;
+	/* items are claimed `grab` at a time: ~32 claims per worker and frame (one contended atomic per item cost 256 threads more than the
+	 * marching itself: 260 000 atomics on one cache line per 1920x1080 frame) */
+	const uint64_t grab = job->grab;
+	uint64_t       item = 0, item_end = 0;
 	for (;;)
 	{
-		const uint64_t item = __atomic_fetch_add(&job->next, 1, __ATOMIC_RELAXED);
-		if (item >= n_items)
-			break;
+		if (item == item_end)
+		{
+			item = __atomic_fetch_add(&job->next, grab, __ATOMIC_RELAXED);
+			if (item >= n_items)
+				break;
+			item_end = item + grab < n_items ? item + grab : n_items;
+		}
 		const uint32_t k  = (uint32_t) (item / chunks), row0 = (uint32_t) (item % chunks) * CHUNK_ROWS;
 		const uint32_t t  = P->tiles.tile_first + k * P->tiles.tile_stride;
 		const uint32_t x0 = (t % tiles_x) * tw, y0 = (t / tiles_x) * th;
@@ -881,6 +890,7 @@ static void render_items(RenderJob *job)
 					P->d_out_depth[o] = po.depth;
 			}
 		}
+		++item;
 	}
 	__atomic_fetch_add(&job->rays, rays, __ATOMIC_RELAXED);
 }
@@ -932,6 +942,9 @@ uint64_t vkvo_render(const VkvRenderParams *P, int n_threads, uint32_t pixel_str
 	RenderJob job;
 	job.P = P, job.lut = lut, job.stride = pixel_stride, job.next = 0, job.rays = 0;
 	job.n_items = (uint64_t) P->tiles.tile_count * ((P->tiles.tile_height + CHUNK_ROWS - 1) / CHUNK_ROWS);
+	job.grab = job.n_items / ((uint64_t) n_threads * 32u);
+	if (job.grab < 1)
+		job.grab = 1;
 	if (n_threads == 1 || job.n_items < 2)
 	{
 		render_items(&job);

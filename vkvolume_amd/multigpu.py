@@ -175,6 +175,16 @@ class NativeExchange:
                                self.tiles_per_rank, self.bpp, scatter_stream.cuda_stream)
         return scatter_stream
 
+    def comm_count(self):
+        """ranks of the exchange's communicator as RCCL itself reports them (ncclCommCount)"""
+        import ctypes as C
+        n = C.c_int(0)
+        self._rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        rc = self._rccl.ncclCommCount(self._comm, C.byref(n))
+        if rc != 0:
+            raise RuntimeError("ncclCommCount failed: %d" % rc)
+        return int(n.value)
+
     def close(self):
         if self._comm:
             self._rccl.ncclCommDestroy.argtypes = [__import__("ctypes").c_void_p]
