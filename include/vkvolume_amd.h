@@ -15,9 +15,16 @@
  *     (vkv_create, vkv_prepare_render, vkv_register_target; marked "set-up call") have seen the
  *     shapes, streams and targets they are used with: the small device tables a launch needs
  *     (tile start order, address tables, per-stream scratch) come out of an arena allocated by
- *     vkv_create and are uploaded asynchronously on the launch's stream; nothing is ever freed
- *     or re-used while a launch could still read it (only vkv_forget_target, vkv_release_stream
- *     and vkv_destroy give device memory back, and they say what they wait for);
+ *     vkv_create and are uploaded asynchronously on the launch's stream from a pinned host copy;
+ *     nothing is ever freed or re-used while a launch could still read it (only vkv_trim,
+ *     vkv_forget_target, vkv_release_stream and vkv_destroy give device memory back, and they
+ *     say what they wait for).  GROWTH: every distinct (frame size, tile schedule) and every
+ *     distinct volume extent a context has rendered keeps one cached table (32 KiB for a
+ *     1920x1080 frame of 16x16 tiles); the arena's table region (default 6 MiB of 8) holds
+ *     ~190 such sizes.  When it is full, launches run without the table (plain tile order,
+ *     address arithmetic in registers: the same bits, a few per cent slower) until vkv_trim
+ *     empties it; the scratch blocks of streams have a region of their own (16 streams) and
+ *     are never starved by tables;
  *   - pointers named `d_*` are device pointers owned by the caller; POD structs are
  *     passed by const pointer and copied at call time;
  *   - volumes are dense uint8, x fastest: index = (z*height + y)*width + x
@@ -325,8 +332,8 @@ int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_transfer_function,
  * does not allow. */
 int vkv_prepare_render(vkv_ctx *ctx, const VkvRenderParams *params, uint32_t count, void *stream);
 
-/* Start-order and ray-order feedback need device state per render target (one uint32 cost and one uint32 order entry per tile of the
- * schedule, one byte per pixel): a renderer draws into the same swap-chain images again and again with a camera that moves little, so the tiles that took longest in the
+/* Start-order feedback needs device state per render target (one uint32 cost and one uint32 order entry per tile of the
+ * schedule): a renderer draws into the same swap-chain images again and again with a camera that moves little, so the tiles that took longest in the
  * last measured frame are started first in the next ones (any order renders the same bits).
  * vkv_register_target - set-up call: allocates and initialises that state for frames of image_width x image_height pixels rendered with
  *   tile schedule `tiles` into `d_target` (the d_out_rgba8 or, without one, d_out_color pointer of the parameter block).  Targets that
@@ -336,6 +343,12 @@ int vkv_prepare_render(vkv_ctx *ctx, const VkvRenderParams *params, uint32_t cou
  *   itself, it must not run concurrently with a render into that target from another thread. */
 int vkv_register_target(vkv_ctx *ctx, const void *d_target, uint32_t image_width, uint32_t image_height, const VkvTileSchedule *tiles);
 int vkv_forget_target(vkv_ctx *ctx, const void *d_target);
+
+/* Set-up call: waits for the device, then drops every cached table (tile start orders, address tables) and empties the arena's table
+ * region; the next launches create what they need again (asynchronously, as on first use).  For a renderer whose window or volume sizes
+ * keep changing: call it at a quiet point (a resize, a scene change) - like vkv_forget_target it must not run concurrently with a launch
+ * from another thread.  Stream scratch blocks and registered targets are not touched. */
+int vkv_trim(vkv_ctx *ctx);
 
 /* Gives the 128 KiB scratch block vkv_render_batch / vkv_compute_distance_map / ... keep per HIP stream back to the context's pool.
  * Call it before destroying a stream that was handed to this context, when all work enqueued on it has completed (it does not wait). */

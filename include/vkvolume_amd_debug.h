@@ -25,7 +25,8 @@ int vkv_debug_tile_orders(vkv_ctx *ctx, const uint32_t *d_orders, uint32_t frame
  *   what = 0  the gradient kernel's short correctly rounded sqrt against __builtin_sqrtf
  *   what = 1  its one-instruction clamped R8_UNORM store
  *   what = 2  the ray set-up's reciprocal (v_rcp_f32 + refinement) against the IEEE division 1.0f / x
- *   what = 3  the ray set-up's quotient a / b through that reciprocal against the IEEE division, b = the pattern, a = a hash of it */
+ *   what = 3  the ray set-up's quotient a / b through that reciprocal against the IEEE division, b = the pattern, a = a hash of it
+ *   what = 4  the dispatch of that quotient for the numerators +0 and -0: they take the IEEE division (the refinement loses the sign of -0 / b) */
 int vkv_debug_check(vkv_ctx *ctx, int32_t what, uint32_t first_bits, uint64_t count, uint64_t *d_mismatches, void *stream);
 
 #ifdef __cplusplus

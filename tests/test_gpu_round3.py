@@ -258,9 +258,9 @@ def test_prepare_render_then_launches_take_nothing_new(ctx):
 def test_arena_exhaustion_degrades_to_table_free_launches(monkeypatch):
     """A context whose arena has no room for a table still renders the same bits: the launch runs without its start order instead of
     allocating, and a batch launch on a stream that cannot get a scratch block says so (VKV_ARENA_BYTES is read by vkv_create; the
-    minimum is 1 MiB = eight 128 KiB scratch blocks)."""
+    minimum is 1 MiB: four 128 KiB scratch blocks + 512 KiB of tables - round 4 gave the two their own regions)."""
     scene = T.OracleScene(O.synth_volume((72, 64, 56), 1, 99), abi.VolumeOptions(**T.APP_TF), 4)
-    size = (4096, 4096)        # 65 536 tiles: a start order of 256 KiB
+    size = (6144, 6144)        # 147 456 tiles: a start order of 576 KiB, more than the small arena's table region
     ro = abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0)
     frames = []
     for arena in (None, "1048576"):
@@ -273,7 +273,7 @@ def test_arena_exhaustion_degrades_to_table_free_launches(monkeypatch):
             v, tf = make_gpu_volume(c, scene)
             V.ComputeDistanceMap(c).compute(v, tf, abi.SKIP_DISTANCE)        # the default stream's scratch block
             count = torch.zeros(1, dtype=torch.int64, device="cuda")
-            for s_ in [torch.cuda.Stream() for _ in range(6)]:        # six more: 7 x 128 KiB of the small arena are gone
+            for s_ in [torch.cuda.Stream() for _ in range(3)]:        # three more: the four scratch blocks of the small arena are gone
                 c.occupied_voxel_count(v.volume.data_ptr(), v.gradient.data_ptr(), tf, v.extent, count.data_ptr(), s_.cuda_stream)
             torch.cuda.synchronize()
             sp = V.VolumeRenderSubpass(c, v, ro, size)
@@ -281,7 +281,7 @@ def test_arena_exhaustion_degrades_to_table_free_launches(monkeypatch):
             p = sp.make_params(*T.orbit(40.0, image_size=size))
             p.d_out_rgba8, p.d_out_color, p.d_out_counts, p.d_out_depth = t.data_ptr(), None, None, None
             st = torch.cuda.Stream()
-            c.render(p, st.cuda_stream)        # small arena: no room for the 256 KiB start order - plain tile order, same frame
+            c.render(p, st.cuda_stream)        # small arena: no room for the 576 KiB start order - plain tile order, same frame
             torch.cuda.synchronize()
             frames.append(t)
             if arena:

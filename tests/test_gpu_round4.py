@@ -5,7 +5,7 @@ import torch
 
 from oracle import vkv_oracle as O
 from tests import helpers as T
-from tests.test_gpu_parity import make_gpu_volume
+from tests.test_gpu_parity import gpu_render, make_gpu_volume
 from vkvolume_amd import abi, volume as V
 
 pytestmark = pytest.mark.gpu
@@ -57,3 +57,90 @@ def test_sample_count_test_mode_without_a_counter_buffer(ctx, skipping_type):
                     assert np.array_equal(got["rgba8"].cpu().numpy(), ref.rgba8), "%s, tables %d, view %d: RGBA8 differs from the oracle" % (name, tables, i)
     finally:
         ctx.set_tuning(address_tables=2)
+
+
+def test_zero_numerators_take_the_ieee_division(ctx):
+    """the fast division of the ray set-up (v_rcp_f32 + refinement) loses the sign of -0 / d, so a zero numerator must not be
+    'ordinary' (div_ordinary_num) - vkv_debug_check what = 4 runs the dispatch for +0 and -0 over EVERY float as the denominator: the fast
+    path is never taken and the quotient is the IEEE one bit for bit."""
+    import ctypes as C
+    L = ctx._lib
+    L.vkv_debug_check.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+    bad = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for first in (0, 0x80000000):
+        ctx.check(L.vkv_debug_check(ctx.handle, 4, first, 1 << 31, bad.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert bad.tolist() == [0]
+
+
+def test_table_region_fills_up_falls_back_and_trims(ctx):
+    """tables are never evicted, so a renderer that keeps meeting new window sizes fills the arena's table region.
+    300 distinct frame sizes: every frame is still the oracle-checked frame (once the region is full launches run without the start-order
+    table: same bits), a NEW stream still gets its scratch block (its region is separate: vkv_render_batch works), vkv_trim empties the
+    region and tables are created again; nothing of this allocates device memory (hipMemGetInfo)."""
+    opt = abi.VolumeOptions(**T.APP_TF)
+    scene = T.OracleScene(O.synth_volume((48, 40, 36), 1, 0x5EED0006), opt, 4)
+    v, tf = make_gpu_volume(ctx, scene)
+    V.ComputeDistanceMap(ctx).compute(v, tf, abi.SKIP_DISTANCE)
+    ro = abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0)
+    st = torch.cuda.current_stream().cuda_stream
+    big = (1920, 1088)  # 8 160 tiles = 32 KiB per table: the 6 MiB region holds ~190 of them
+    rgba8 = torch.zeros((big[1] + 300, big[0], 4), dtype=torch.uint8, device="cuda")
+    view, proj = T.orbit(40.0, image_size=(256, 160))
+    small = (256, 160)
+    ref = scene.render(scene.params(view, proj, small, ro), want_rgba8=True)
+
+    def draw(size, stream=st):
+        sp = V.VolumeRenderSubpass(ctx, v, ro, size)
+        p = sp.bind(scene.params(view, proj, size, ro))
+        q = abi.RenderParams.from_buffer_copy(p)
+        q.d_out_rgba8, q.d_out_color, q.d_out_counts, q.d_out_depth = rgba8.data_ptr(), None, None, None
+        ctx.render(q, stream)
+        return q
+
+    draw(small)
+    torch.cuda.synchronize()
+    assert np.array_equal(rgba8.view(-1)[:small[0] * small[1] * 4].view(small[1], small[0], 4).cpu().numpy(), ref.rgba8)
+    free0 = torch.cuda.mem_get_info()[0]
+    for i in range(300):  # 300 x 32 KiB > the region: the later ones run without a start-order table
+        draw((big[0], big[1] + i))
+    torch.cuda.synchronize()
+    # a stream the context has never seen still gets a scratch block and renders a batch
+    s2 = torch.cuda.Stream()
+    q = draw(small, s2.cuda_stream)
+    ctx.render_batch([q, q], s2.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(rgba8.view(-1)[:small[0] * small[1] * 4].view(small[1], small[0], 4).cpu().numpy(), ref.rgba8)
+    ctx.trim()
+    draw(small)
+    draw((big[0], big[1] + 7))
+    draw(small)
+    torch.cuda.synchronize()
+    assert np.array_equal(rgba8.view(-1)[:small[0] * small[1] * 4].view(small[1], small[0], 4).cpu().numpy(), ref.rgba8)
+    assert torch.cuda.mem_get_info()[0] >= free0, "launches, the new stream or vkv_trim took device memory"
+    ctx.release_stream(s2.cuda_stream)
+
+
+def test_set_tuning_rejects_values_that_would_break_every_launch(ctx):
+    """a tile_mix that is not a number would never match a cached schedule (a new table per launch); a
+    full_table_lds_limit above what a kernel may request as dynamic LDS would fail every launch instead of choosing smaller tables."""
+    with pytest.raises(Exception):
+        ctx.set_tuning(tile_mix_heavy=float("nan"))
+    with pytest.raises(Exception):
+        ctx.set_tuning(tile_mix_spread=1.5)
+    try:
+        ctx.set_tuning(full_table_lds_limit=1 << 30)
+        assert ctx.get_tuning().full_table_lds_limit <= 64 * 1024
+        opt = abi.VolumeOptions(**T.APP_TF)
+        scene = T.OracleScene(O.synth_volume((40, 40, 40), 1, 0x5EED0007), opt, 4)
+        v, tf = make_gpu_volume(ctx, scene)
+        V.ComputeDistanceMap(ctx).compute(v, tf, abi.SKIP_DISTANCE)
+        size = (96, 64)
+        ro = abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0)
+        view, proj = T.orbit(10.0, image_size=size)
+        params = scene.params(view, proj, size, ro)
+        color, counts, _, _ = gpu_render(ctx, v, params)
+        ref = scene.render(params)
+        assert np.array_equal(counts, ref.counts) and np.abs(color - ref.color).max() <= 1e-5
+    finally:
+        ctx.set_tuning(full_table_lds_limit=17920)

@@ -58,13 +58,18 @@ VkvTuning tuning_of(vkv_ctx *ctx)
 
 // `bytes` of device memory that stay valid until vkv_destroy (caller holds ctx->mutex).  Launch paths only take from the arena; set-up
 // calls may fall back to hipMalloc.
-static void *arena_take(vkv_ctx *ctx, size_t bytes, bool setup)
+// The arena has two regions: the first kScratchReserve scratch blocks (stream_scratch) and, behind them, the tables.  A renderer that
+// keeps meeting new window sizes fills the TABLE region (a 1920x1080 schedule of 16x16 tiles costs 32 KiB per distinct size) - it can
+// never take the room a new stream's scratch block needs, and vkv_trim gives the table region back.
+static void *arena_take_table(vkv_ctx *ctx, size_t bytes, bool setup, bool *from_arena)
 {
 	const size_t need = (bytes + 255u) & ~(size_t) 255u;
-	if (ctx->arena && ctx->arena_used + need <= ctx->arena_bytes)
+	*from_arena       = false;
+	if (ctx->arena && ctx->table_used + need <= ctx->arena_bytes - ctx->table_base)
 	{
-		void *p = ctx->arena + ctx->arena_used;
-		ctx->arena_used += need;
+		void *p = ctx->arena + ctx->table_base + ctx->table_used;
+		ctx->table_used += need;
+		*from_arena = true;
 		return p;
 	}
 	if (!setup)
@@ -88,12 +93,24 @@ uint8_t *stream_scratch(vkv_ctx *ctx, hipStream_t stream, bool setup)
 		p = ctx->free_scratch.back();
 		ctx->free_scratch.pop_back();
 	}
-	else
-		p = static_cast<uint8_t *>(arena_take(ctx, kScratchBytes, setup));
+	else if (ctx->arena && ctx->scratch_used + kScratchBytes <= ctx->table_base)
+	{
+		p = ctx->arena + ctx->scratch_used;
+		ctx->scratch_used += kScratchBytes;
+	}
+	else if (setup)
+	{        // more streams than the arena reserves blocks for: a set-up call may allocate (freed by vkv_destroy)
+		void *q = nullptr;
+		if (hipMalloc(&q, kScratchBytes) == hipSuccess)
+		{
+			ctx->overflow_scratch.push_back(q);
+			p = static_cast<uint8_t *>(q);
+		}
+	}
 	if (!p)
 	{
-		set_error(ctx, VKV_E_UNSUPPORTED, "no room for the scratch block of a new stream: the context's arena is full (call vkv_prepare_render at set-up "
-		                                  "time, give finished streams back with vkv_release_stream, or raise VKV_ARENA_BYTES)");
+		set_error(ctx, VKV_E_UNSUPPORTED, "no scratch block left for a new stream: the arena reserves %zu (call vkv_prepare_render for the stream at set-up "
+		                                  "time, give finished streams back with vkv_release_stream, or raise VKV_ARENA_BYTES)", ctx->table_base / kScratchBytes);
 		return nullptr;
 	}
 	ctx->scratch.emplace(stream, p);
@@ -105,20 +122,35 @@ uint8_t *stream_scratch(vkv_ctx *ctx, hipStream_t stream, bool setup)
 static bool table_upload(vkv_ctx *ctx, vkv_ctx::Table &t, hipStream_t s, bool setup)
 {
 	const size_t bytes = t.host.size() * sizeof(uint32_t);
-	t.d                = static_cast<uint32_t *>(arena_take(ctx, bytes, setup));
+	bool         from_arena = false;
+	t.d                = static_cast<uint32_t *>(arena_take_table(ctx, bytes, setup, &from_arena));
 	if (!t.d)
 		return false;
 	if (hipEventCreateWithFlags(&t.uploaded, hipEventDisableTiming) != hipSuccess)
-		return false;        // (the arena bytes stay taken: harmless)
-	if (hipMemcpyAsync(t.d, t.host.data(), bytes, hipMemcpyHostToDevice, s) != hipSuccess || hipEventRecord(t.uploaded, s) != hipSuccess)
+		return false;        // (the arena bytes stay taken until the next vkv_trim: harmless)
+	// The source of the asynchronous copy is the table's twin in the PINNED mirror of the table region (same offset): a copy from pageable
+	// memory may block the enqueueing thread behind earlier work of the stream, which a launch must not do; the mirror lives as long as
+	// the arena, so the source outlives the copy whatever happens to the entry.  A table a set-up call put outside the arena (hipMalloc
+	// fallback) is copied from the entry's own vector and waited for right here.
+	const void *src = t.host.data();
+	if (from_arena && ctx->table_mirror)
 	{
+		uint8_t *m = ctx->table_mirror + (reinterpret_cast<uint8_t *>(t.d) - (ctx->arena + ctx->table_base));
+		std::memcpy(m, t.host.data(), bytes);
+		src = m;
+	}
+	const bool queued = hipMemcpyAsync(t.d, src, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+	if (!queued || hipEventRecord(t.uploaded, s) != hipSuccess)
+	{
+		if (queued)
+			(void) hipStreamSynchronize(s);        // the copy may still be reading its source: not while the caller deletes the entry
 		(void) hipEventDestroy(t.uploaded);
 		t.uploaded = nullptr;
 		return false;
 	}
 	t.upload_stream = s;
-	if (setup)
-	{        // a set-up call hands out finished tables
+	if (setup || src == t.host.data())
+	{        // a set-up call hands out finished tables (and a pageable source must not be left to an asynchronous copy)
 		(void) hipEventSynchronize(t.uploaded);
 		t.ready = true;
 	}
@@ -312,6 +344,42 @@ static void default_tuning(VkvTuning &t)
 		t.arena_bytes = (uint32_t) std::min(std::max(std::atol(e), 1l << 20), 1l << 30);
 }
 
+// every cached table gone, the table region of the arena empty again (caller: the device is idle, ctx->mutex held or nobody else around)
+static void drop_tables(vkv_ctx *ctx)
+{
+	for (auto *t : ctx->tile_orders)
+	{
+		if (t->table.uploaded)
+			(void) hipEventDestroy(t->table.uploaded);
+		delete t;
+	}
+	for (auto *t : ctx->addr_luts)
+	{
+		if (t->table.uploaded)
+			(void) hipEventDestroy(t->table.uploaded);
+		delete t;
+	}
+	ctx->tile_orders.clear();
+	ctx->addr_luts.clear();
+	for (void *p : ctx->overflow)
+		(void) hipFree(p);
+	ctx->overflow.clear();
+	ctx->table_used = 0;
+}
+
+int vkv_trim(vkv_ctx *ctx)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	DeviceGuard      guard(ctx->device);
+	const hipError_t e = hipDeviceSynchronize();        // launches that still read a table
+	if (e != hipSuccess)
+		return set_error(ctx, (int) e, "trim: %s", hipGetErrorString(e));
+	std::lock_guard<std::mutex> lock(ctx->mutex);
+	drop_tables(ctx);
+	return VKV_OK;
+}
+
 int vkv_create(int device_ordinal, vkv_ctx **out_ctx)
 {
 	if (!out_ctx)
@@ -342,7 +410,13 @@ int vkv_create(int device_ordinal, vkv_ctx **out_ctx)
 			delete ctx;
 			return VKV_E_NO_DEVICE;
 		}
-		ctx->arena = static_cast<uint8_t *>(p), ctx->arena_bytes = ctx->tuning.arena_bytes, ctx->arena_used = 0;
+		ctx->arena = static_cast<uint8_t *>(p), ctx->arena_bytes = ctx->tuning.arena_bytes;
+		// scratch region: kScratchReserve blocks, at most half of a small arena; the tables get the rest and a pinned host mirror of it
+		const size_t blocks = std::min<size_t>(kScratchReserve, ctx->arena_bytes / 2 / kScratchBytes);
+		ctx->table_base = blocks * kScratchBytes, ctx->scratch_used = 0, ctx->table_used = 0;
+		void *m = nullptr;
+		if (hipHostMalloc(&m, ctx->arena_bytes - ctx->table_base, hipHostMallocDefault) == hipSuccess)
+			ctx->table_mirror = static_cast<uint8_t *>(m);        // (without it uploads fall back to the entry's own vector + a wait)
 	}
 	*out_ctx      = ctx;        // the caller's current device is left as it is: every entry point switches to ctx->device itself
 	return VKV_OK;
@@ -355,26 +429,17 @@ void vkv_destroy(vkv_ctx *ctx)
 	{
 		DeviceGuard guard(ctx->device);
 		(void) hipDeviceSynchronize();        // launches that still read the context's tables, scratch or feedback buffers
-		for (auto *t : ctx->tile_orders)
-		{
-			if (t->table.uploaded)
-				(void) hipEventDestroy(t->table.uploaded);
-			delete t;
-		}
-		for (auto *t : ctx->addr_luts)
-		{
-			if (t->table.uploaded)
-				(void) hipEventDestroy(t->table.uploaded);
-			delete t;
-		}
+		drop_tables(ctx);
 		for (auto *f : ctx->feedback)
 		{
 			(void) hipFree(f->d_cost);
 			(void) hipFree(f->d_order);
 					delete f;
 		}
-		for (void *p : ctx->overflow)
+		for (void *p : ctx->overflow_scratch)
 			(void) hipFree(p);
+		if (ctx->table_mirror)
+			(void) hipHostFree(ctx->table_mirror);
 		(void) hipFree(ctx->arena);
 	}
 	delete ctx;
@@ -399,10 +464,17 @@ int vkv_set_tuning(vkv_ctx *ctx, const VkvTuning *tuning)
 	    tuning->address_tables > 2 || tuning->feedback_period == 0 || tuning->gradient_segment > 255u ||
 	    (tuning->pack_tile != 0 && tuning->pack_tile != 2 && tuning->pack_tile != 4))
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "set_tuning: field out of range");
+	// a transfer-function mix that is not a number never compares equal to a cached schedule's: every launch would build a new table
+	if (!std::isfinite(tuning->tile_mix_heavy) || !std::isfinite(tuning->tile_mix_spread) || tuning->tile_mix_heavy < 0.0f || tuning->tile_mix_heavy > 1.0f ||
+	    tuning->tile_mix_spread < 0.0f || tuning->tile_mix_spread > 1.0f)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "set_tuning: tile_mix_heavy / tile_mix_spread must be numbers in [0, 1]");
 	std::lock_guard<std::mutex> lock(ctx->mutex);
 	const uint32_t              arena = ctx->tuning.arena_bytes;
 	ctx->tuning                       = *tuning;
 	ctx->tuning.arena_bytes           = arena;        // read-only
+	// the kernels request their whole LDS layout as dynamic LDS without raising the 64 KiB default limit: a larger figure would make every
+	// launch fail instead of choosing the smaller tables
+	ctx->tuning.full_table_lds_limit = std::min<uint32_t>(ctx->tuning.full_table_lds_limit, kMaxDynamicLds);
 	return VKV_OK;
 }
 

@@ -58,6 +58,7 @@ __device__ __forceinline__ uint32_t store_unorm8_clamped(float g) { return __bui
 // what = 0: sqrt_rn_normal vs __builtin_sqrtf; what = 1: store_unorm8_clamped vs store_unorm8(g_clamp(., 0, 1));
 // what = 2: recip_exact(x) vs 1.0f / x for every ordinary x (vkv_device.hpp; the others take the IEEE path in ray_setup by construction);
 // what = 3: div_by(a, x, recip_refined(x)) vs a / x with eight hashed ordinary numerators per denominator x
+// what = 4: numerators +0 and -0 must NOT take the reciprocal path (div_ordinary_num), and the quotient the dispatch delivers is the IEEE one
 __global__ void __launch_bounds__(256) k_check_numerics(int what, uint32_t first_bits, uint64_t count, unsigned long long *mismatches)
 {
 	const uint64_t i = (uint64_t) blockIdx.x * 256u + threadIdx.x;
@@ -72,6 +73,18 @@ __global__ void __launch_bounds__(256) k_check_numerics(int what, uint32_t first
 		bad = (uint8_t) store_unorm8_clamped(x) != store_unorm8(g_clamp(x, 0.0f, 1.0f));
 	else if (what == 2)
 		bad = div_ordinary(x) && __float_as_uint(recip_exact(x)) != __float_as_uint(1.0f / x);
+	else if (what == 4)
+	{        // the dispatch of ray_setup for a zero numerator: not "ordinary", so the quotient comes from the IEEE division - and it has to,
+		 // the refined reciprocal path returns +0 for -0 / x (checked here too, so that nobody relaxes div_ordinary_num on the comment's word)
+		const float zeros[2] = {0.0f, -0.0f};
+		for (int k = 0; k < 2; ++k)
+		{
+			const float a = zeros[k];
+			const bool  fast = div_ordinary(x) && div_ordinary_num(a);
+			const float q    = fast ? div_by(a, x, recip_refined(x)) : a / x;
+			bad = bad || fast || __float_as_uint(q) != __float_as_uint(a / x);
+		}
+	}
 	else if (div_ordinary(x))
 	{
 		const float r = recip_refined(x);
@@ -1548,7 +1561,7 @@ int launch_check_numerics(vkv_ctx *ctx, int what, uint32_t first_bits, uint64_t 
 {
 	if (count == 0)
 		return VKV_OK;
-	if ((count + 255) / 256 > 0x7fffffffull || what < 0 || what > 3)
+	if ((count + 255) / 256 > 0x7fffffffull || what < 0 || what > 4)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "check_numerics: bad arguments");
 	hipLaunchKernelGGL(k_check_numerics, dim3((uint32_t) ((count + 255) / 256)), dim3(256), 0, s, what, first_bits, count, d_mismatches);
 	return check_launch(ctx, "check_numerics");

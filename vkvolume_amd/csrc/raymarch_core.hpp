@@ -182,13 +182,15 @@ __device__ __forceinline__ uint8_t quantise_rgba8(float c) { return (uint8_t) __
 // ---------------------------------------------------------------------------------------------------------------
 // Correctly rounded fp32 division out of v_rcp_f32 - the sequence the compiler itself emits for `a / b` under
 // -fhip-fp32-correctly-rounded-divide-sqrt, without its range scaling (v_div_scale / v_div_fmas) and special-case fix-up
-// (v_div_fixup), which do nothing for "ordinary" operands (both magnitudes in [2^-40, 2^40], or a zero numerator):
+// (v_div_fixup), which do nothing for "ordinary" operands (both magnitudes in [2^-40, 2^40]; a ZERO numerator is not ordinary - the
+// refinement would lose the sign of -0 / d - and takes the IEEE path like everything else outside the range: div_ordinary_num):
 //     r0 = rcp(d); e = fma(-d, r0, 1); r = fma(e, r0, r0)                          <- depends on the denominator only
 //     q0 = a * r; q1 = fma(fma(-d, q0, a), r, q0); q = fma(fma(-d, q1, a), r, q1)
 // The ray set-up divides three numerators by the same length (twice), by the same step count, takes three reciprocals of a
 // direction ...: 22 divisions per covered ray, 13 % of a C3 frame.  Sharing r between the quotients of one denominator and dropping
 // the scale / fix-up instructions leaves 149 of their 242 instructions, with the same bits: checked on the device against the IEEE
-// division for every float as denominator (vkv_debug_check what = 2: reciprocals; what = 3: quotients with hashed numerators).
+// division for every float as denominator (vkv_debug_check what = 2: reciprocals; what = 3: quotients with hashed numerators; what = 4:
+// the dispatch itself with numerators +0 and -0).
 // Operands outside the ordinary range (axis-parallel rays: 1 / 0; NaNs of a degenerate camera) send the whole wave through the
 // plain IEEE set-up (ray_setup below), so the fast path never has to be right about them.
 // ---------------------------------------------------------------------------------------------------------------

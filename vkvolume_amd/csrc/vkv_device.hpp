@@ -157,11 +157,13 @@ __host__ __device__ __forceinline__ size_t packed_brick_offset(int bx, int by, i
 // Device scratch is handed out PER STREAM (stream_scratch): calls on one stream are ordered, so they may share a buffer; calls on
 // different streams never touch the same bytes, which makes every entry point re-entrant across streams of one context.
 //
-// Device memory policy (include/vkvolume_amd.h, "Conventions"): vkv_create allocates one ARENA; the small immutable tables a launch needs
-// (tile start orders, address tables) and the per-stream scratch blocks are carved out of it and are never freed or re-used before
-// vkv_destroy, so no launch can ever read a freed table, whatever the streams and threads do.  A table is uploaded asynchronously on the
-// stream of the launch that first needs it; launches on other streams are ordered behind that upload with an event until it has completed.
-// Only the set-up calls (vkv_prepare_render, vkv_register_target) fall back to hipMalloc when the arena is full.
+// Device memory policy (include/vkvolume_amd.h, "Conventions"): vkv_create allocates one ARENA with two regions - the scratch blocks of
+// up to kScratchReserve streams, and the small immutable tables a launch needs (tile start orders, address tables) - plus a pinned host
+// mirror of the table region.  A table is written into the mirror and uploaded from there asynchronously on the stream of the launch that
+// first needs it; launches on other streams are ordered behind that upload with an event until it has completed.  Nothing is freed or
+// re-used while a launch could read it: tables stay until vkv_trim (a set-up call that waits for the device, then empties the region) or
+// vkv_destroy; when the region is full a launch runs without the table.  Only set-up calls (vkv_prepare_render, vkv_register_target) fall
+// back to hipMalloc when a region is full.
 struct vkv_ctx
 {
 	int   device;
@@ -174,8 +176,12 @@ struct vkv_ctx
 	VkvTuning       tuning;        // vkv_create: defaults + environment; vkv_set_tuning replaces it (read under the mutex, copied per call)
 	// ---- device arena ----
 	uint8_t *           arena = nullptr;
-	size_t              arena_bytes = 0, arena_used = 0;
-	std::vector<void *> overflow;        // hipMalloc blocks set-up calls took when the arena was full; freed by vkv_destroy
+	size_t              arena_bytes = 0;
+	size_t              table_base = 0;          // the arena's first table_base bytes are scratch blocks, the rest holds tables
+	size_t              scratch_used = 0, table_used = 0;
+	uint8_t *           table_mirror = nullptr;  // pinned host twin of the table region: the source of every asynchronous table upload
+	std::vector<void *> overflow;                // hipMalloc blocks set-up calls took for tables when the region was full; freed by vkv_trim / vkv_destroy
+	std::vector<void *> overflow_scratch;        // ... for scratch blocks beyond the reserve; freed by vkv_destroy
 	std::unordered_map<hipStream_t, uint8_t *> scratch;        // stream -> kScratchBytes of device memory
 	std::vector<uint8_t *>                     free_scratch;   // blocks given back by vkv_release_stream
 	// an immutable device table with its host copy (the source of the asynchronous upload: it must outlive the call)
@@ -240,6 +246,8 @@ const uint32_t *tile_start_order(vkv_ctx *ctx, uint32_t img_w, uint32_t img_h, u
                                  hipStream_t stream, bool setup = false);
 VkvTuning tuning_of(vkv_ctx *ctx);        // a copy of the context's tuning block (taken under its mutex)
 constexpr size_t kScratchBytes     = 128 * 1024;
+constexpr size_t kScratchReserve   = 16;          // scratch blocks the arena keeps for streams (2 MiB of the default 8 MiB)
+constexpr uint32_t kMaxDynamicLds  = 64 * 1024 - 1024;        // what a lean kernel may ask for as dynamic LDS (its tables; no hipFuncSetAttribute is called)
 constexpr size_t kTfBitsOffset     = 0;           // 256*256 bits = 8 KiB: TF bit table of the map update / the voxel count
 constexpr size_t kQueueHeadsOffset = 8192;        // 8 x u32 tile-queue heads of the persistent ray-march scheduler
 constexpr size_t kPullHeadsBytes   = 2048;        // 8 ticket counters of k_raymarch_lean_pull, 256 bytes apart (one memory channel each), directly in
