@@ -1481,7 +1481,11 @@ static int launch_dm_rmq(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *ds
 		                   os, chunks_x, chunks_p, ch, vec);                                                                                            \
 	} while (0)
 	// (measured and dropped: resident workgroups marching over several tiles with the next tile's cells prefetched into registers - 38 -> 44 us
-	// per pass on C3; the CU already overlaps one workgroup's loads with the others' table building)
+	// per pass on C3; the CU already overlaps one workgroup's loads with the others' table building.  Round 4: WAVE-OWNED dword columns - a
+	// wave builds the nine levels of 4 lines and answers their queries alone, two workgroup barriers instead of eleven - with workgroups of
+	// 2 waves x 8 lines or 4 waves x 16 lines: bit-identical, C3 iso 0.102-0.117 ms against 0.087-0.092, aniso 0.41 against 0.30; the same
+	// LDS then holds half as many waves per CU (14 against 32), and the walk's dependent LDS round trips need the waves more than the
+	// barriers cost: profiles/r4_dm_variants.txt)
 	if (len <= 128 && me.width > 16)
 		VKV_DM_RMQ(16, 128);
 	else if (len <= 256)        // 8 lines per workgroup: 20 KB of LDS instead of 40 (8 workgroups per CU, not 4) and runs of 8 cells per thread:
