@@ -31,6 +31,10 @@ constexpr uint32_t kLabFmt     = 32768u;    // x-pair rows through buffer FORMAT
 constexpr uint32_t kLabFmtVec  = 65536u;    // kLabFmt with the uniform loop operands left in vector registers
 constexpr uint32_t kLabStamp   = 131072u;   // s_memtime at the top of every iteration, summed per wave by the iteration's kind
 constexpr uint32_t kLabNoCounts = 262144u;  // the three per-pixel counters are not kept
+constexpr uint32_t kLabBrickMap = 524288u;   // (round 4) the distance map the probes read is BRICKED: 4x4x4 cells = one 64-byte block (bricks x fastest), as
+                                             // vkv_lab_brick_map lays it out; the cell id compared with u_last_alpha is the bricked index (any injective id works)
+constexpr uint32_t kLabProbeOnly = 1048576u; // (round 4, timing / cache-counter runs only: the frame is WRONG) the footprint gathers are not issued (the filter sees zeros),
+                                             // so that the probes are the only vector memory traffic of the loop
 constexpr uint32_t kLabDefault = kLabUniform | kLabBranch | kLabCvt;
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -644,7 +648,10 @@ __device__ __forceinline__ void lab_lean_march(const RayMarchArgs &A, Ray &R, co
 	               kCvt = (LF & kLabCvt) != 0, kNest = (LF & kLabNest) != 0 && kBranch, kKeep = (LF & kLabKeep) != 0, kScalar = (LF & kLabScalar) != 0, kFull = (LF & kLabFull) != 0 && SEP, kTf = (LF & kLabTf) != 0 && SEP && kHoist && kCvt,
 	               kGradSkip = (LF & kLabGradSkip) != 0 && kTf && GRAD == 1, kFloatI = (LF & kLabFloatI) != 0 && kBranch, kWb = (LF & kLabWb) != 0,
 	               kFloatCell = (LF & kLabFloatCell) != 0 && SKIP != VKV_SKIP_NONE, kPrefetch = (LF & kLabPrefetch) != 0 && kHoist && kNest,
-	               kFmt = (LF & kLabFmt) != 0 && kFull && kTf && !kPrefetch, kFmtScalar = kFmt && (LF & kLabFmtVec) == 0;
+	               kFmt = (LF & kLabFmt) != 0 && kFull && kTf && !kPrefetch, kFmtScalar = kFmt && (LF & kLabFmtVec) == 0,
+	               kBrick = (LF & kLabBrickMap) != 0 && kScalar && !kFloatCell, kProbeOnly = (LF & kLabProbeOnly) != 0;
+	// bricked map: index = x + 4 y + 16 z + 60 (x >> 2) + (64 bw - 16) (y >> 2) + (64 bw bh - 64) (z >> 2), bw / bh = bricks per row / column
+	const uint32_t brick_cy = 64u * (((uint32_t) A.mw + 3u) >> 2) - 16u, brick_cz = 64u * (((uint32_t) A.mw + 3u) >> 2) * (((uint32_t) A.mh + 3u) >> 2) - 64u;
 	using idx_t = std::conditional_t<kFloatI, float, int>;
 	const int   W = A.W, H = A.H, D = A.D;
 	float kx = SKIP != VKV_SKIP_NONE ? (float) W / A.block_size[0] : 0.0f, ky = SKIP != VKV_SKIP_NONE ? (float) H / A.block_size[1] : 0.0f,
@@ -692,7 +699,13 @@ __device__ __forceinline__ void lab_lean_march(const RayMarchArgs &A, Ray &R, co
 			else if (kScalar)
 			{
 				uix = clamp0_i32((int) ux, mw1), uiy = clamp0_i32((int) uy, mh1), uiz = clamp0_i32((int) uz, md1);
-				cell = mad_u24(mad_u24((uint32_t) uiz, (uint32_t) A.mh, (uint32_t) uiy), (uint32_t) A.mw, (uint32_t) uix);
+				if (kBrick)
+				{
+					const uint32_t low = (((uint32_t) uiz << 4) + ((uint32_t) uiy << 2)) + (uint32_t) uix;
+					cell = mad_u24((uint32_t) uiz >> 2, brick_cz, mad_u24((uint32_t) uiy >> 2, brick_cy, mad_u24((uint32_t) uix >> 2, 60u, low)));
+				}
+				else
+					cell = mad_u24(mad_u24((uint32_t) uiz, (uint32_t) A.mh, (uint32_t) uiy), (uint32_t) A.mw, (uint32_t) uix);
 			}
 			else
 			{
@@ -747,6 +760,11 @@ __device__ __forceinline__ void lab_lean_march(const RayMarchArgs &A, Ray &R, co
 			}
 			else if (kPrefetch && pf_i == i)
 				q00 = pq00, q10 = pq10, q01 = pq01, q11 = pq11, wx = pwx, wy = pwy, wz = pwz;        // requested an iteration ago
+			else if (kProbeOnly)
+			{
+				(void) footprint_of(posx, posy, posz, wx, wy, wz);
+				q00 = q10 = q01 = q11 = 0u;
+			}
 			else
 			{
 				const uint8_t *ba = footprint_of(posx, posy, posz, wx, wy, wz);

@@ -106,6 +106,11 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 		case 24: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabFmt>(a, s);
 		case 25: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabFmt | kLabFmtVec>(a, s);
 		case 26: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabStamp>(a, s);
+		// round 4: bricked distance map (the caller passes maps laid out by vkv_lab_brick_map), and the probes-only timing variants
+		case 40: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabBrickMap>(a, s);
+		case 41: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabProbeOnly>(a, s);
+		case 42: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabProbeOnly | kLabBrickMap>(a, s);
+		case 43: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabStamp | kLabBrickMap>(a, s);
 		case 23: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabPrefetch>(a, s);
 		case 17: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabFull>(a, s);
 		// the product's lean_march (raymarch_core.hpp), instantiated here: 30 = kLeanLut | kLeanFull as shipped, 31 = + per-iteration stamps
@@ -143,6 +148,28 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 	}
 }
 }        // namespace
+
+// dense [md][mh][mw] distance map -> 4x4x4-cell bricks of 64 bytes, bricks x fastest; cells beyond the map's edge are 0 (never read: the
+// integrator clamps its cell coordinates).  dst holds 64 * ceil(mw / 4) * ceil(mh / 4) * ceil(md / 4) bytes.
+__global__ void __launch_bounds__(256) k_lab_brick_map(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint32_t mw, uint32_t mh, uint32_t md, uint64_t total)
+{
+	const uint64_t i = (uint64_t) blockIdx.x * 256u + threadIdx.x;
+	if (i >= total)
+		return;
+	const uint32_t bw = (mw + 3u) >> 2, bh = (mh + 3u) >> 2;
+	const uint32_t in = (uint32_t) (i & 63u);
+	const uint64_t b  = i >> 6;
+	const uint32_t bx = (uint32_t) (b % bw), by = (uint32_t) ((b / bw) % bh), bz = (uint32_t) (b / ((uint64_t) bw * bh));
+	const uint32_t x = bx * 4u + (in & 3u), y = by * 4u + ((in >> 2) & 3u), z = bz * 4u + (in >> 4);
+	dst[i] = (x < mw && y < mh && z < md) ? src[((size_t) z * mh + y) * mw + x] : (uint8_t) 0;
+}
+
+extern "C" int vkv_lab_brick_map(const uint8_t *d_src, uint8_t *d_dst, uint32_t mw, uint32_t mh, uint32_t md, void *stream)
+{
+	const uint64_t total = 64ull * ((mw + 3u) >> 2) * ((mh + 3u) >> 2) * ((md + 3u) >> 2);
+	hipLaunchKernelGGL(k_lab_brick_map, dim3((uint32_t) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream, d_src, d_dst, mw, mh, md, total);
+	return (int) hipGetLastError();
+}
 
 // LAB_ALL variants = 200 + the ids of the first half of profiles/r2_lab_variants.txt: 210 + W evaluate+replay with W lanes per ray;
 // 220 + W: every lane loads both kinds; 230 + W: stamped diagnostic build; 24x masked loads; 26x / 27x brick cache.
