@@ -67,7 +67,10 @@ def march_loop(listing, name_filter):
         cand = [(a, b) for a, b in loops if loads(a, b) >= 4]
         cand = [(a, b) for a, b in cand if not any((a <= a2 and b2 <= b) and (a2, b2) != (a, b) for a2, b2 in cand)]
         if cand:
-            a, b = max(cand, key=lambda ab: ab[1] - ab[0])  # the separable-TF loop (the larger of the two copies)
+            # a kernel holds one copy of the march loop per transfer-function path; the bench's TF is the reference's separable product, whose
+            # copy reads no RGBA texel (the generic copy's dependent texel fetch is the loop's only flat_load)
+            sep = [(a, b) for a, b in cand if not any(x.startswith("flat_load") for x in ins[a:b + 1])]
+            a, b = max(sep or cand, key=lambda ab: ab[1] - ab[0])
             return name, ins[a:b + 1]
     raise SystemExit("no march loop found for %r" % name_filter)
 
