@@ -935,7 +935,8 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 		if (pa < pb)
 		{
 			if (MODE == 0)
-			{
+			{        // (measured and dropped: the run as two half runs with a bisection each, two chains side by side - C3 iso 0.099-0.109 ms against
+				 // 0.087-0.092: the second bisection's 16 reads cost more than the shorter chain returns)
 				uint32_t c               = bisect(pa, 0);
 				s_t[kOut + at(pa, line)] = (uint8_t) c;
 				for (int p = pa + 1; p < pb; ++p)
@@ -948,7 +949,37 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 					s_t[kOut + at(p, line)] = (uint8_t) c;
 				}
 			}
-			if (MODE == 1 || MODE == 2)
+			if (MODE == 2)
+			{        // both one-sided results of the run as ONE loop: the walk down (candidates at higher index, from pb - 1) and the walk up
+				 // (candidates at lower index, from pa) are independent chains of dependent LDS round trips - side by side each hides the
+				 // other's latency (as two loops the LDS stores between them keep the compiler from overlapping them)
+				constexpr int o2 = kOut + kLevel;
+				uint32_t lo1 = 0, hi1 = s_t[at(pb - 1, line)], lo2 = 0, hi2 = s_t[at(pa, line)];
+#pragma unroll
+				for (int it = 0; it < 8; ++it)
+				{
+					const uint32_t m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
+					const uint32_t w1 = rmq(pb - 1, min(pb - 1 + (int) m1, n - 1)), w2 = rmq(max(pa - (int) m2, 0), pa);
+					const bool     ok1 = w1 <= m1, ok2 = w2 <= m2;
+					hi1 = ok1 ? m1 : hi1, lo1 = ok1 ? lo1 : m1 + 1;
+					hi2 = ok2 ? m2 : hi2, lo2 = ok2 ? lo2 : m2 + 1;
+				}
+				uint32_t c1 = hi1, c2 = hi2;
+				s_t[kOut + at(pb - 1, line)] = (uint8_t) c1;
+				s_t[o2 + at(pa, line)]       = (uint8_t) c2;
+				for (int j = 1; j < pb - pa; ++j)
+				{
+					const int      pd = pb - 1 - j, pu = pa + j;
+					const uint32_t wd = c1 >= 1u ? rmq(pd + 1, min(pd + (int) c1, n - 1)) : 255u;
+					const uint32_t wu = c2 >= 1u ? rmq(max(pu - (int) c2, 0), pu - 1) : 255u;
+					const uint32_t gd = s_t[at(pd, line)], gu = s_t[at(pu, line)];
+					const uint32_t Td = (c1 >= 1u && wd <= c1) ? c1 : c1 + 1u, Tu = (c2 >= 1u && wu <= c2) ? c2 : c2 + 1u;
+					c1 = min(gd, Td), c2 = min(gu, Tu);
+					s_t[kOut + at(pd, line)] = (uint8_t) c1;
+					s_t[o2 + at(pu, line)]   = (uint8_t) c2;
+				}
+			}
+			if (MODE == 1)
 			{        // candidates at higher index: walk down; the candidates above p give c or c + 1, the cell itself g(p)
 				uint32_t c                   = bisect(pb - 1, 1);
 				s_t[kOut + at(pb - 1, line)] = (uint8_t) c;
@@ -960,9 +991,9 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 					s_t[kOut + at(p, line)] = (uint8_t) c;
 				}
 			}
-			if (MODE == -1 || MODE == 2)
+			if (MODE == -1)
 			{
-				constexpr int o2             = MODE == 2 ? kOut + kLevel : kOut;
+				constexpr int o2             = kOut;
 				uint32_t      c              = bisect(pa, -1);
 				s_t[o2 + at(pa, line)]       = (uint8_t) c;
 				for (int p = pa + 1; p < pb; ++p)
