@@ -785,86 +785,67 @@ __device__ __forceinline__ uint32_t min_u8x4(uint32_t a, uint32_t b)
 	return (b & m) | (a & ~m);
 }
 
-template <int MODE, int XT, int SEG, bool XAXIS>
-__global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst, uint8_t *dst2, uint32_t n_lines, int len,
-                                                size_t line_stride, size_t axis_stride, size_t other_stride, uint32_t chunks_x, uint32_t chunks_p, int ch, int vec)
+// up to four independent passes of one launch (blockIdx.y picks one): the anisotropic schedule runs both y passes, then all four z passes,
+// as one grid each
+struct DmPasses
 {
-	// A line is one run of the axis; the workgroup owns lines cx * XT .. + XT of group `other`:
-	//   y / z pass: lines = consecutive x (line_stride 1), LDS index p * XT + line (a dword = 4 lines of one cell row)
-	//   x pass (XAXIS): lines = consecutive rows (line_stride = width), LDS index line * (SEG + 4) + p (a dword = 4 cells of one line)
-	// Levels 0..8 of the sparse table, then one (MODE 2: two) level-sized result area for a coalesced write-out.
-	constexpr int kPitch = XAXIS ? SEG + 4 : XT;        // x pass: one dword of padding per line spreads the lines over the LDS banks
-	constexpr int kLevel = XAXIS ? XT * kPitch : SEG * XT, kOut = 9 * kLevel;
+	const uint8_t *src[4];
+	uint8_t *      dst[4], *dst2[4];
+};
+
+template <int MODE, int XT, int SEG>
+__global__ void __launch_bounds__(256) k_dm_rmq(const DmPasses passes, uint32_t n_lines, int len, size_t axis_stride, size_t other_stride, uint32_t chunks_x,
+                                                uint32_t chunks_p, int ch, int vec)
+{
+	// A line is one run of the axis; the workgroup owns lines cx * XT .. + XT (consecutive x) of group `other`; LDS index p * XT + line
+	// (a dword = 4 lines of one cell row).  Levels 0..8 of the sparse table, then one (MODE 2: two) level-sized result area for a coalesced
+	// write-out.  src may be dst (in place) when a workgroup stages whole lines (chunks_p == 1): it reads only the cells it writes.
+	constexpr int kLevel = SEG * XT, kOut = 9 * kLevel;
 	__shared__ __align__(16) uint8_t s_t[(MODE == 2 ? 11 : 10) * kLevel];
+	const uint8_t *src = passes.src[blockIdx.y];
+	uint8_t *      dst = passes.dst[blockIdx.y], *dst2 = passes.dst2[blockIdx.y];
 	// neighbouring line groups read and write parts of the same 128-byte lines: give each XCD (own L2) a contiguous range of them
 	const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
 	const uint32_t cx = bid % chunks_x, cp = (bid / chunks_x) % chunks_p, other = bid / (chunks_x * chunks_p);
 	const int      out0 = (int) cp * ch, out1 = min(len, out0 + ch);
 	const int      seg0 = max(0, out0 - 255), n = min(len, out1 + 255) - seg0;        // staged cells [seg0, seg0 + n), n <= SEG
 	const int      t      = (int) threadIdx.x;
-	const size_t   base   = (size_t) other * other_stride + (size_t) cx * XT * line_stride + (size_t) seg0 * axis_stride;
-	auto           at     = [](int p, int line) { return XAXIS ? line * kPitch + p : p * XT + line; };
-	const int      n4     = (n + 3) & ~3;        // x pass: the tail of the last dword of a line is padded with 255
-	// staging / write-out: iteration q of a thread is cell (line, p); x pass: threads run along the row, rows one after the other;
-	// y / z pass: 256 / XT cell rows of XT lines at a time
-	constexpr int kPerLine = SEG / 256 > 0 ? SEG / 256 : 1;        // x pass: 256-cell pieces per line (compile-time: no division in the loops)
-	const int     n_iter   = XAXIS ? XT * kPerLine : (n + 256 / XT - 1) / (256 / XT);
-	auto          cell     = [&](int q, int &line, int &p) {
-		if (XAXIS)
-			line = q / kPerLine, p = t + 256 * (q % kPerLine);        // pieces past the end of the line fail the p < n tests below
-		else
-			line = t % XT, p = t / XT + q * (256 / XT);
-	};
-	// `vec`: every group of XT lines (y / z pass, XT = 16: one 16-byte row segment) or every 4 cells of a line (x pass) is an aligned
-	// vector in memory and in the LDS layout - one load / store instruction moves what 16 / 4 byte-wide ones would
-	if (vec && !XAXIS)
+	const size_t   base   = (size_t) other * other_stride + (size_t) cx * XT + (size_t) seg0 * axis_stride;
+	auto           at     = [](int p, int line) { return p * XT + line; };
+	// staging / write-out: iteration q of a thread is cell (line, p): 256 / XT cell rows of XT lines at a time
+	const int n_iter = (n + 256 / XT - 1) / (256 / XT);
+	auto      cell   = [&](int q, int &line, int &p) { line = t % XT, p = t / XT + q * (256 / XT); };
+	using vec_t = typename std::conditional<XT == 16, uint4, typename std::conditional<XT == 8, uint2, uint32_t>::type>::type;        // the XT lines of one cell row
+	// `vec`: every group of XT lines (one XT-byte row segment) is an aligned vector in memory and in the LDS layout - one load / store
+	// instruction moves what XT byte-wide ones would
+	if (vec)
 	{
-		using vec_t = typename std::conditional<XT == 16, uint4, typename std::conditional<XT == 8, uint2, uint32_t>::type>::type;        // the XT lines of one cell row
 		for (int p = t; p < n; p += 256)
 			*reinterpret_cast<vec_t *>(s_t + p * XT) = *reinterpret_cast<const vec_t *>(src + base + (size_t) p * axis_stride);
 	}
-	else if (vec)
-	{
-		constexpr int kDw = SEG / 4, kIter = XT * kDw / 256;
-		uint32_t      v[kIter];
-#pragma unroll
-		for (int j = 0; j < kIter; ++j)
-		{
-			const int  idx = t + 256 * j, line = idx / kDw, e = idx % kDw;
-			const bool ok  = 4 * e < n && cx * XT + (uint32_t) line < n_lines;
-			v[j]           = ok ? *reinterpret_cast<const uint32_t *>(src + base + (size_t) line * line_stride + (size_t) (4 * e)) : 0xffffffffu;
-		}
-#pragma unroll
-		for (int j = 0; j < kIter; ++j)
-		{
-			const int idx = t + 256 * j, line = idx / kDw, e = idx % kDw;
-			if (4 * e < n4)
-				*reinterpret_cast<uint32_t *>(s_t + line * kPitch + 4 * e) = v[j];
-		}
-	}
 	else
 	{
-	constexpr int kBatch = 8;        // loads in flight per thread
-	for (int q0 = 0; q0 < n_iter; q0 += kBatch)
-	{
-		uint8_t v[kBatch];
-#pragma unroll
-		for (int j = 0; j < kBatch; ++j)
+		constexpr int kBatch = 8;        // loads in flight per thread
+		for (int q0 = 0; q0 < n_iter; q0 += kBatch)
 		{
-			int line, p;
-			cell(q0 + j, line, p);
-			const bool ok = q0 + j < n_iter && p < n && cx * XT + (uint32_t) line < n_lines;
-			v[j]          = ok ? src[base + (size_t) line * line_stride + (size_t) p * axis_stride] : (uint8_t) 255;
-		}
+			uint8_t v[kBatch];
 #pragma unroll
-		for (int j = 0; j < kBatch; ++j)
-		{
-			int line, p;
-			cell(q0 + j, line, p);
-			if (q0 + j < n_iter && p < (XAXIS ? n4 : n))
-				s_t[at(p, line)] = v[j];
+			for (int j = 0; j < kBatch; ++j)
+			{
+				int line, p;
+				cell(q0 + j, line, p);
+				const bool ok = q0 + j < n_iter && p < n && cx * XT + (uint32_t) line < n_lines;
+				v[j]          = ok ? src[base + (size_t) line + (size_t) p * axis_stride] : (uint8_t) 255;
+			}
+#pragma unroll
+			for (int j = 0; j < kBatch; ++j)
+			{
+				int line, p;
+				cell(q0 + j, line, p);
+				if (q0 + j < n_iter && p < n)
+					s_t[at(p, line)] = v[j];
+			}
 		}
-	}
 	}
 	__syncthreads();
 	// ---- sparse table, four cells per operation ------------------------------------------------------------------
@@ -873,36 +854,13 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 		const int       h = 1 << (k - 1);
 		const uint32_t *a = reinterpret_cast<const uint32_t *>(s_t + (k - 1) * kLevel);
 		uint32_t *      b = reinterpret_cast<uint32_t *>(s_t + k * kLevel);
-		if (XAXIS)
-		{        // dword e of a line = cells 4e .. 4e+3; the partner cells 4e+h .. are a byte-shifted pair of dwords for h < 4
-			constexpr int kDw = SEG / 4, kRowDw = kPitch / 4;
-			const int     nd  = n4 / 4;
-			for (int idx = t; idx < XT * kDw; idx += 256)
-			{
-				const int line = idx / kDw, e = idx % kDw;
-				if (e >= nd)
-					continue;
-				const uint32_t *row = a + line * kRowDw;
-				uint32_t        o;
-				if (h >= 4)
-					o = (e + h / 4 < nd) ? row[e + h / 4] : 0xffffffffu;
-				else
-				{
-					const uint32_t nx = (e + 1 < nd) ? row[e + 1] : 0xffffffffu;
-					o                 = h == 1 ? __builtin_amdgcn_alignbyte(nx, row[e], 1) : __builtin_amdgcn_alignbyte(nx, row[e], 2);
-				}
-				b[line * kRowDw + e] = min_u8x4(row[e], o);
-			}
-		}
-		else
-		{        // dword = 4 lines of cell row p; the partner is the same dword h rows on
-			constexpr int kDw = XT / 4;
-			for (int e = t; e < n * kDw; e += 256)
-			{
-				const int      p = e / kDw;
-				const uint32_t o = (p + h < n) ? a[e + h * kDw] : 0xffffffffu;
-				b[e]             = min_u8x4(a[e], o);
-			}
+		// dword = 4 lines of cell row p; the partner is the same dword h rows on
+		constexpr int kDw = XT / 4;
+		for (int e = t; e < n * kDw; e += 256)
+		{
+			const int      p = e / kDw;
+			const uint32_t o = (p + h < n) ? a[e + h * kDw] : 0xffffffffu;
+			b[e]             = min_u8x4(a[e], o);
 		}
 		__syncthreads();
 	}
@@ -910,7 +868,7 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 	// (the result of a neighbouring cell differs by at most one, so one or two window tests settle each further cell)
 	{
 		constexpr int kRuns = 256 / XT;
-		const int     line  = XAXIS ? t / kRuns : t % XT, run = XAXIS ? t % kRuns : t / XT;
+		const int     line  = t % XT, run = t / XT;
 		const int     nout  = out1 - out0, rl = (nout + kRuns - 1) / kRuns;
 		const int     pa = out0 - seg0 + run * rl, pb = min(pa + rl, out1 - seg0);        // [pa, pb)
 		auto rmq = [&](int l, int r) -> uint32_t {
@@ -1007,9 +965,8 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 		}
 	}
 	__syncthreads();
-	if (vec && !XAXIS)
+	if (vec)
 	{
-		using vec_t = typename std::conditional<XT == 16, uint4, typename std::conditional<XT == 8, uint2, uint32_t>::type>::type;
 		for (int p = out0 - seg0 + t; p < out1 - seg0; p += 256)
 		{
 			const size_t o = base + (size_t) p * axis_stride;
@@ -1019,29 +976,13 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const uint8_t *src, uint8_t *dst
 		}
 		return;
 	}
-	if (vec)
-	{        // x pass, whole lines (out0 = seg0 = 0, n = len, 4 | n)
-		constexpr int kDw = SEG / 4, kIter = XT * kDw / 256;
-#pragma unroll
-		for (int j = 0; j < kIter; ++j)
-		{
-			const int idx = t + 256 * j, line = idx / kDw, e = idx % kDw;
-			if (4 * e >= n || cx * XT + (uint32_t) line >= n_lines)
-				continue;
-			const size_t o = base + (size_t) line * line_stride + (size_t) (4 * e);
-			*reinterpret_cast<uint32_t *>(dst + o) = *reinterpret_cast<const uint32_t *>(s_t + kOut + line * kPitch + 4 * e);
-			if (MODE == 2)
-				*reinterpret_cast<uint32_t *>(dst2 + o) = *reinterpret_cast<const uint32_t *>(s_t + kOut + kLevel + line * kPitch + 4 * e);
-		}
-		return;
-	}
 	for (int q = 0; q < n_iter; ++q)
 	{
 		int line, p;
 		cell(q, line, p);
 		if (p < out0 - seg0 || p >= out1 - seg0 || cx * XT + (uint32_t) line >= n_lines)
 			continue;
-		const size_t o = base + (size_t) line * line_stride + (size_t) p * axis_stride;
+		const size_t o = base + (size_t) line + (size_t) p * axis_stride;
 		dst[o]         = s_t[kOut + at(p, line)];
 		if (MODE == 2)
 			dst2[o] = s_t[kOut + kLevel + at(p, line)];
@@ -1449,6 +1390,9 @@ static int row_stride_for(int mw)
 
 template <int MODE>
 static int launch_dm_rmq(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *dst, uint8_t *dst2, VkvExtent3D me, hipStream_t s);
+template <int MODE>
+static int launch_dm_rmq_passes(vkv_ctx *ctx, int axis, const DmPasses &passes, uint32_t n_passes, VkvExtent3D me, hipStream_t s);
+static bool dm_whole_lines(int axis, VkvExtent3D me) { return (axis == 1 ? me.height : me.depth) <= 512u; }        // a workgroup stages the whole line: in place is safe
 
 template <int MODE>
 static int launch_dm_x(vkv_ctx *ctx, const uint8_t *src, uint8_t *dst, VkvExtent3D me, hipStream_t s)
@@ -1470,13 +1414,9 @@ static int launch_dm_x(vkv_ctx *ctx, const uint8_t *src, uint8_t *dst, VkvExtent
 template <int MODE>
 static int launch_dm_rmq(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *dst, uint8_t *dst2, VkvExtent3D me, hipStream_t s)
 {
-	const size_t   sy = me.width, sz = (size_t) me.width * me.height;
-	const int      len     = axis == 0 ? (int) me.width : axis == 1 ? (int) me.height : (int) me.depth;
-	const uint32_t other   = axis == 0 ? 1u : axis == 1 ? me.depth : me.height;
-	const uint32_t n_lines = axis == 0 ? me.height * me.depth : me.width;
-	const size_t   as = axis == 0 ? 1 : axis == 1 ? sy : sz, os = axis == 1 ? sz : sy;
 	if (axis == 0)
 	{        // rows of up to 1024 cells: one wave per row, in registers (k_dm_x_wave); longer rows never get here (launch_dm_x)
+		const int      len    = (int) me.width;
 		const uint32_t n_rows = me.height * me.depth;
 		const bool     vec    = (me.width & 3u) == 0 && ((((uintptr_t) src) | ((uintptr_t) dst) | ((uintptr_t) dst2)) & 3u) == 0;
 #define VKV_DM_XW(C)                                                                                                                            \
@@ -1498,7 +1438,23 @@ static int launch_dm_rmq(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *ds
 #undef VKV_DM_XW
 		return check_launch(ctx, "distance_map x pass");
 	}
-	const size_t ls = 1;
+	DmPasses one = {};
+	one.src[0] = src, one.dst[0] = dst, one.dst2[0] = dst2;
+	return launch_dm_rmq_passes<MODE>(ctx, axis, one, 1, me, s);
+}
+
+// y (axis 1) or z (axis 2) pass over n_passes independent (src, dst, dst2) triples in one grid
+template <int MODE>
+static int launch_dm_rmq_passes(vkv_ctx *ctx, int axis, const DmPasses &passes, uint32_t n_passes, VkvExtent3D me, hipStream_t s)
+{
+	const size_t   sy = me.width, sz = (size_t) me.width * me.height;
+	const int      len     = axis == 1 ? (int) me.height : (int) me.depth;
+	const uint32_t other   = axis == 1 ? me.depth : me.height;
+	const uint32_t n_lines = me.width;
+	const size_t   as = axis == 1 ? sy : sz, os = axis == 1 ? sz : sy;
+	uintptr_t      al = 0;
+	for (uint32_t i = 0; i < n_passes; ++i)
+		al |= (uintptr_t) passes.src[i] | (uintptr_t) passes.dst[i] | (uintptr_t) passes.dst2[i];
 #define VKV_DM_RMQ(XT, SEG)                                                                                                                            \
 	do                                                                                                                                                  \
 	{                                                                                                                                                   \
@@ -1506,10 +1462,9 @@ static int launch_dm_rmq(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *ds
 		const uint32_t chunks_p = (uint32_t) ((len + ch - 1) / ch), chunks_x = (n_lines + (XT) -1) / (XT);                                              \
 		if ((uint64_t) chunks_x * chunks_p * other > 0x7fffffffull)                                                                                     \
 			return set_error(ctx, VKV_E_UNSUPPORTED, "distance_map: map too large for one launch");                                                     \
-		const uintptr_t al = (uintptr_t) src | (uintptr_t) dst | (uintptr_t) dst2;                                                                      \
 		const int vec = (me.width & ((XT) -1)) == 0 && (al & ((XT) -1)) == 0;                                                                           \
-		hipLaunchKernelGGL((k_dm_rmq<MODE, XT, SEG, false>), dim3(chunks_x * chunks_p * other), dim3(256), 0, s, src, dst, dst2, n_lines, len, ls, as,  \
-		                   os, chunks_x, chunks_p, ch, vec);                                                                                            \
+		hipLaunchKernelGGL((k_dm_rmq<MODE, XT, SEG>), dim3(chunks_x * chunks_p * other, n_passes), dim3(256), 0, s, passes, n_lines, len, as, os, chunks_x, \
+		                   chunks_p, ch, vec);                                                                                                          \
 	} while (0)
 	// (measured and dropped: resident workgroups marching over several tiles with the next tile's cells prefetched into registers - 38 -> 44 us
 	// per pass on C3; the CU already overlaps one workgroup's loads with the others' table building.  Round 4: WAVE-OWNED dword columns - a
@@ -1567,6 +1522,23 @@ int launch_distance_map_anisotropic(vkv_ctx *ctx, uint8_t *const m[8], uint8_t *
 		// pass leaves x+ in m[3] and x- in m[7] (in place on the occupancy); y of x+ puts y+ into swap and y- into m[1], whose z
 		// passes fill (m[2], m[3]) and then (m[0], m[1]); the x- half repeats this with m[4..7].
 		if ((rc = launch_dm_rmq<2>(ctx, 0, occ, m[3], m[7], me, s))) return rc;
+		if (dm_whole_lines(1, me) && dm_whole_lines(2, me))
+		{        // Three launches: x; both y passes as one grid; all four z passes as one grid (every launch boundary costs a drain and a ramp-up
+			 // of a grid that is only three rounds of workgroups deep).  No swap buffer: y of x+ (m[3]) goes to m[0] / m[2], y of x- (m[7]) to
+			 // m[4] / m[6] (all four still free), and every z pass writes its + result IN PLACE over its source (a workgroup stages the whole
+			 // lines it owns before it writes them) and its - result into the odd neighbour: m[1], m[3], m[5], m[7] (whose x results have
+			 // been consumed by the y launch).
+			DmPasses y = {}, z = {};
+			for (int h = 0; h < 2; ++h)
+			{
+				uint8_t *const *q = m + 4 * h;
+				y.src[h] = q[3], y.dst[h] = q[0], y.dst2[h] = q[2];
+				for (int k = 0; k < 2; ++k)
+					z.src[2 * h + k] = q[2 * k], z.dst[2 * h + k] = q[2 * k], z.dst2[2 * h + k] = q[2 * k + 1];
+			}
+			if ((rc = launch_dm_rmq_passes<2>(ctx, 1, y, 2, me, s))) return rc;
+			return launch_dm_rmq_passes<2>(ctx, 2, z, 4, me, s);
+		}
 		for (int h = 0; h < 2; ++h)
 		{
 			uint8_t *const *q = m + 4 * h;
