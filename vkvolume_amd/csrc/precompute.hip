@@ -1474,10 +1474,10 @@ static int launch_dm_rmq_passes(vkv_ctx *ctx, int axis, const DmPasses &passes, 
 	// barriers cost: profiles/r4_dm_variants.txt)
 	if (len <= 128 && me.width > 16)
 		VKV_DM_RMQ(16, 128);
-	else if (len <= 256)        // 8 lines per workgroup: 20 KB of LDS instead of 40 (8 workgroups per CU, not 4) and runs of 8 cells per thread:
+	else if (len <= 256)        // (4 lines per workgroup here: C3 iso 0.112-0.115 ms against 0.087 - the wave slots, not the LDS, cap the CU at this size) 8 lines per workgroup: 20 KB of LDS instead of 40 (8 workgroups per CU, not 4) and runs of 8 cells per thread:
 		VKV_DM_RMQ(8, 256);        // C3 42.6 -> 36.8 us per isotropic pass, 63 -> 47 us per anisotropic pass
-	else if (len <= 512)
-		VKV_DM_RMQ(8, 512);        // whole line, no halo
+	else if (len <= 512)        // whole line, no halo; 4 lines per workgroup: 22 KB of LDS instead of 45 (7 workgroups per CU, not 3): C4 iso 0.70 -> 0.64 ms,
+		VKV_DM_RMQ(4, 512);        // aniso 3.11 -> 2.60 ms
 	else
 		VKV_DM_RMQ(8, 768);
 #undef VKV_DM_RMQ
