@@ -798,10 +798,14 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const DmPasses passes, uint32_t 
                                                 uint32_t chunks_p, int ch, int vec)
 {
 	// A line is one run of the axis; the workgroup owns lines cx * XT .. + XT (consecutive x) of group `other`; LDS index p * XT + line
-	// (a dword = 4 lines of one cell row).  Levels 0..8 of the sparse table, then one (MODE 2: two) level-sized result area for a coalesced
+	// (a dword = 4 lines of one cell row).  The levels of the sparse table, then one (MODE 2: two) level-sized result area for a coalesced
 	// write-out.  src may be dst (in place) when a workgroup stages whole lines (chunks_p == 1): it reads only the cells it writes.
-	constexpr int kLevel = SEG * XT, kOut = 9 * kLevel;
-	__shared__ __align__(16) uint8_t s_t[(MODE == 2 ? 11 : 10) * kLevel];
+	// Levels 0 .. kTop: a query never spans more than the staged cells, and a window of up to 2^(kTop + 1) cells is covered by two blocks of
+	// level kTop (its first and its last 2^kTop cells overlap or touch) - so 256 staged cells need levels 0..7, not 0..8: one level less to
+	// build, and 20 KB instead of 22 for the anisotropic passes (8 workgroups per CU instead of 7)
+	constexpr int kTop   = SEG <= 128 ? 6 : (SEG <= 256 ? 7 : 8);
+	constexpr int kLevel = SEG * XT, kOut = (kTop + 1) * kLevel;
+	__shared__ __align__(16) uint8_t s_t[(kTop + 1 + (MODE == 2 ? 2 : 1)) * kLevel];
 	const uint8_t *src = passes.src[blockIdx.y];
 	uint8_t *      dst = passes.dst[blockIdx.y], *dst2 = passes.dst2[blockIdx.y];
 	// neighbouring line groups read and write parts of the same 128-byte lines: give each XCD (own L2) a contiguous range of them
@@ -849,7 +853,7 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const DmPasses passes, uint32_t 
 	}
 	__syncthreads();
 	// ---- sparse table, four cells per operation ------------------------------------------------------------------
-	for (int k = 1; k <= 8 && (1 << (k - 1)) < n; ++k)
+	for (int k = 1; k <= kTop && (1 << (k - 1)) < n; ++k)
 	{
 		const int       h = 1 << (k - 1);
 		const uint32_t *a = reinterpret_cast<const uint32_t *>(s_t + (k - 1) * kLevel);
@@ -872,7 +876,7 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const DmPasses passes, uint32_t 
 		const int     nout  = out1 - out0, rl = (nout + kRuns - 1) / kRuns;
 		const int     pa = out0 - seg0 + run * rl, pb = min(pa + rl, out1 - seg0);        // [pa, pb)
 		auto rmq = [&](int l, int r) -> uint32_t {
-			const int      k  = 31 - __builtin_clz((uint32_t) (r - l + 1));
+			const int      k  = min(31 - __builtin_clz((uint32_t) (r - l + 1)), kTop);
 			const uint8_t *tk = s_t + k * kLevel;
 			return min((uint32_t) tk[at(l, line)], (uint32_t) tk[at(r - (1 << k) + 1, line)]);
 		};
