@@ -37,3 +37,14 @@ for n in [1, 2, 4, 8, 16, 32, 64, 96, 128, 192, 256]:
         best = max(best, r.rays / r.seconds / 1e6)
     base = base or best
     print("threads %3d: %8.3f Mray/s  = %6.1f x one thread" % (n, best, best / base), flush=True)
+
+# the bench's own call pattern: all 8 views, every pixel, outputs reused between passes
+params = [sp.make_params(*vw, abi.full_frame_tiles(frame[0], frame[1], 16, 16)) for vw in views]
+last = [O.render(q, vol, grad, tex, maps, n_threads=cores, pixel_stride=4, want_rgba8=True) for q in params]
+for ps in range(3):
+    secs = []
+    for i, q in enumerate(params):
+        last[i] = O.render(q, vol, grad, tex, maps, n_threads=cores, pixel_stride=1, want_rgba8=True, reuse=last[i])
+        secs.append(last[i].seconds)
+    print("pass %d, every pixel of 8 views on %d threads: %s s per view = %.1f Mray/s" % (ps, cores, " ".join("%.3f" % x for x in secs),
+                                                                                        sum(r.rays for r in last) / sum(secs) / 1e6), flush=True)
