@@ -254,6 +254,10 @@ def main():
     ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 without WORLD_SIZE: print the torch.distributed.run command line the "
                     "parent would start, and exit")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the ranks: nccl (= RCCL on ROCm, default) or gloo "
+                    "(functional test of the N > 1 orchestration without RCCL: the tile blocks travel through host memory)")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses device 0 (functional test of the N > 1 path on a one-GPU box; needs "
+                    "--backend gloo and --exchange torch: RCCL refuses two ranks on one device)")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="--gpus N > 1 without WORLD_SIZE: seconds after which the parent kills the ranks it "
                     "started and exits with status 124 (0 = never)")
     ap.add_argument("--c5-block", default="auto", choices=["auto", "on", "off"], help="after the headline blocks, a short block of BASELINE.json configs[4] (c5: "
@@ -267,7 +271,10 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if world not in GRID:
         raise SystemExit("--gpus must be 1, 2, 4 or 8")
-    torch.cuda.set_device(local_rank)
+    if args.one_device and (args.backend != "gloo" or args.exchange != "torch"):
+        raise SystemExit("--one-device needs --backend gloo --exchange torch")
+    device = 0 if args.one_device else local_rank
+    torch.cuda.set_device(device)
     dist = None
     use_gather = world > 1 or args.force_gather
     # N > 1 (and the one-rank --force-gather proxy): batch launches with ONE gather per launch - through torch.distributed.gather or, with
@@ -283,10 +290,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         # no device_id: an eagerly created communicator measured 20 % slower on this pipeline than the lazily created one
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    ctx = lib.Context(local_rank)  # raises if the HIP library is missing: there is no fallback path
-    env = {"world": world, "rank": rank, "local_rank": local_rank, "dist": dist, "ctx": ctx, "use_gather": use_gather, "submit": submit}
+    ctx = lib.Context(device)  # raises if the HIP library is missing: there is no fallback path
+    env = {"world": world, "rank": rank, "local_rank": device, "dist": dist, "ctx": ctx, "use_gather": use_gather, "submit": submit}
     out = job(args, env)
     # BASELINE.json configs[4] is the configuration north_star names for 8 GPUs: at N > 1 the same ranks then time a short block of it (strong
     # scaling: the 7680x4320 frame is fixed, its tiles are dealt over the ranks); c3 stays the headline so that N = 1 agrees with BENCH
@@ -295,7 +302,7 @@ def main():
         a2 = copy.copy(args)
         a2.workload, a2.scaling, a2.skip, a2.tf, a2.no_ert = "c5", "strong", None, "app", False
         a2.steps, a2.warmup, a2.min_seconds = min(args.steps, 16), min(args.warmup, 8), min(args.min_seconds, 1.0)
-        a2.verify, a2.no_cpu_baseline, a2.no_depth_block = False, True, True
+        a2.verify, a2.no_cpu_baseline, a2.no_depth_block = args.verify, True, True
         torch.cuda.empty_cache()
         o2 = job(a2, env)
         if rank == 0:
@@ -353,7 +360,8 @@ def job(args, env):
             gather = multigpu.NativeBatchExchange(ctx, dist, rank, world, (fw, fh), TILE, 4, frames=fpl, n_sets=nsets, any_root=rotate)
             images = gather.images or []
         else:
-            gather = multigpu.BatchTileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda", frames=fpl, n_sets=nsets, any_root=rotate)
+            gather = multigpu.BatchTileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda", frames=fpl, n_sets=nsets, any_root=rotate,
+                                              host_staging=args.backend == "gloo")
             if rank == 0 or rotate:
                 images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nsets * fpl)]
         nbuf = nsets * fpl
@@ -365,6 +373,8 @@ def job(args, env):
             gather = multigpu.NativeExchange(ctx, dist, rank, world, (fw, fh), TILE, 4, n_buffers=nbuf, any_root=rotate)
             images = gather.images or []
         else:
+            if args.backend == "gloo":
+                raise SystemExit("--backend gloo supports the batch submission only")
             gather = multigpu.TileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda", n_buffers=nbuf, any_root=rotate)
             if rank == 0 or rotate:
                 images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
@@ -525,7 +535,11 @@ def job(args, env):
 
     def fence():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                torch.cuda.synchronize()
+                dist.barrier()
         torch.cuda.synchronize()
 
     run(args.warmup, False)
@@ -639,7 +653,7 @@ def job(args, env):
         "metric": "Mray/s", "value": round(value, 3), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "rccl_ranks": (gather.comm_count() if native else (dist.get_world_size() if dist is not None else 1)),
-        "rccl_ranks_source": ("ncclCommCount of the exchange's own communicator" if native else ("torch.distributed.get_world_size (backend nccl = RCCL)" if dist is not None else "no communicator")),
+        "rccl_ranks_source": ("ncclCommCount of the exchange's own communicator" if native else ("torch.distributed.get_world_size (backend %s)" % ("nccl = RCCL" if args.backend == "nccl" else args.backend) if dist is not None else "no communicator")),
         "repeats": len(blocks), "host_enqueue_ms_per_step": round(float(np.median(enqueue_times)) / args.steps * 1e3, 4), "ms_per_step_min_max": [round(min(blocks) / args.steps * 1e3, 4), round(max(blocks) / args.steps * 1e3, 4)],
         "config": {"workload": "%s (%s): %dx%dx%d uint8 synthetic shells, %dx%d frame, %s, block 4, TF %s, "
                                "8 orbit views" % (args.workload, WORKLOAD_NOTE[args.workload], *extent, fw, fh,
@@ -648,7 +662,7 @@ def job(args, env):
                                                   "imin 0.1 imax 1 gmin 0 gmax 0.2" if args.tf == "app" else "imin 0.1 imax 1 gmin 0 gmax 0 (intensity only)"),
                    "parallelism": "screen tiles 16x16 round-robin over %d GPU(s), RCCL gather to %s" % (
                        world, ("rank l mod N for launch l (one gather per launch)" if submit == "batch" else "rank k mod N for frame k") if rotate else "rank 0")
-                   + ((" (vkv_assemble_frames: one ncclGather + one de-interleave per launch)" if submit == "batch" else " (vkv_assemble_frame: ncclGather + de-interleave)") if native else " (torch.distributed.gather)")
+                   + ((" (vkv_assemble_frames: one ncclGather + one de-interleave per launch)" if submit == "batch" else " (vkv_assemble_frame: ncclGather + de-interleave)") if native else (" (torch.distributed.gather)" if args.backend == "nccl" else " (torch.distributed.gather over GLOO through host memory: a functional run, not a measurement)"))
                    if world > 1 else "1 GPU",
                    "output": "RGBA8",
                    "submission": ("vkv_render_batch, up to %d frames per launch, consecutive launches on %d HIP stream(s); tile start order from the "

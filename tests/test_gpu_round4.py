@@ -144,3 +144,29 @@ def test_set_tuning_rejects_values_that_would_break_every_launch(ctx):
         assert np.array_equal(counts, ref.counts) and np.abs(color - ref.color).max() <= 1e-5
     finally:
         ctx.set_tuning(full_table_lds_limit=17920)
+
+
+def test_bench_two_ranks_share_one_device_over_gloo():
+    """The N > 1 orchestration of bench.py with TWO REAL RANKS (the self-launching parent, torch.distributed.run, rank != owner paths, the
+    rotating owner, buffer-set reuse behind the exchange's events, the max-over-ranks timing, --verify on the launch's owner) on a box with
+    one GPU: both ranks use device 0 and the tile blocks travel over gloo through host memory (RCCL refuses two ranks on one device; what
+    stays untested without a second GPU is RCCL moving the bytes).  The assembled frame of the last step must equal a direct render."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    for steps, fpl in ((12, 8), (7, 3)):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device", "--workload", "small", "--steps", str(steps),
+               "--warmup", "3", "--frames-per-launch", str(fpl), "--min-seconds", "0.2", "--verify", "--c5-block", "off", "--no-cpu-baseline", "--launch-timeout", "600"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == steps and d["scaling"] == "weak"
+        assert "gloo" in d["rccl_ranks_source"].lower() and "GLOO" in d["config"]["parallelism"]
+        assert d["phases"]["launches_sampled"] > 0 and d["phases"]["render_ms"] > 0 and "gather_ms" in d["phases"] and "scatter_ms" in d["phases"]
+        assert d["value"] > 0 and d["roofline"]["frac"] > 0
+        assert "verify ok" in r.stderr, r.stderr[-2000:]

@@ -70,9 +70,12 @@ class BatchTileGather(TileGather):
     de-interleaves frame f with vkv_scatter_tiles on the block's f-th slice (rank stride = frames x tiles_per_rank tiles).  One
     gather and one host call per launch instead of one per frame."""
 
-    def __init__(self, dist, rank, world, frame_size, tile=16, bytes_per_pixel=4, device="cuda", frames=8, n_sets=2, any_root=False):
+    def __init__(self, dist, rank, world, frame_size, tile=16, bytes_per_pixel=4, device="cuda", frames=8, n_sets=2, any_root=False, host_staging=False):
         import torch
         super().__init__(dist, rank, world, frame_size, tile, bytes_per_pixel, device, n_buffers=0, any_root=any_root)
+        # host_staging: the backend cannot gather device tensors (gloo): the block goes through host memory - a functional path for tests
+        # of the N > 1 orchestration (bench.py --backend gloo), not a data path anybody should measure
+        self.host_staging, self._host = host_staging, [None] * n_sets
         n = self.tiles_per_rank * tile * tile
         self.frames = frames
         self.sets = [torch.zeros((frames, n, bytes_per_pixel), dtype=torch.uint8, device=device) for _ in range(n_sets)]
@@ -87,8 +90,15 @@ class BatchTileGather(TileGather):
         if root != 0 and not self.any_root:
             raise ValueError("BatchTileGather was created for rank 0 as the only frame owner")
         n = self.frames if n_frames is None else n_frames
-        gl = [self.flat[b][r, :n] for r in range(self.world)] if self.rank == root else None
         self.roots[b], self.counts[b] = root, n
+        if self.host_staging:
+            import torch
+            mine = self.sets[b][:n].cpu()  # (waits for the render on the current stream)
+            gl = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == root else None
+            self._host[b] = gl
+            self.works[b] = self.dist.gather(mine, gl, dst=root, async_op=True)
+            return
+        gl = [self.flat[b][r, :n] for r in range(self.world)] if self.rank == root else None
         self.works[b] = self.dist.gather(self.sets[b][:n], gl, dst=root, async_op=True)
 
     def finish(self, b):
@@ -97,6 +107,10 @@ class BatchTileGather(TileGather):
             return None
         self.works[b].wait()
         self.works[b] = None
+        if self.host_staging and self.rank == self.roots[b]:
+            for r in range(self.world):
+                self.flat[b][r, :self.counts[b]].copy_(self._host[b][r])
+            self._host[b] = None
         return (self.flat[b], self.counts[b]) if self.rank == self.roots[b] else None
 
     def frame_source(self, flat, f):
