@@ -329,7 +329,10 @@ int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_transfer_function,
  * arena with an asynchronous upload on its own stream (no device-wide wait; if the arena is exhausted the launch runs without the table:
  * plain tile order / address arithmetic in registers, same bits) - vkv_prepare_render only moves that work to set-up time.  Call it
  * before capturing `stream` into a hipGraph: a launch that still has to create a table records and queries an event, which a capture
- * does not allow. */
+ * does not allow.  Captured launches replay with the parameter blocks they were captured with (camera included: capture one graph per
+ * view, or re-capture); a captured vkv_render_batch keeps its argument blocks in one of 32 pinned slots of the context until vkv_destroy,
+ * because the graph's copy node reads its source at every replay (the 33rd captured batch launch of a context is refused).  The graph
+ * must be destroyed before the context. */
 int vkv_prepare_render(vkv_ctx *ctx, const VkvRenderParams *params, uint32_t count, void *stream);
 
 /* Start-order feedback needs device state per render target (one uint32 cost and one uint32 order entry per tile of the

@@ -170,3 +170,59 @@ def test_bench_two_ranks_share_one_device_over_gloo():
         assert d["phases"]["launches_sampled"] > 0 and d["phases"]["render_ms"] > 0 and "gather_ms" in d["phases"] and "scatter_ms" in d["phases"]
         assert d["value"] > 0 and d["roofline"]["frac"] > 0
         assert "verify ok" in r.stderr, r.stderr[-2000:]
+
+
+def test_render_launches_captured_into_a_hip_graph_replay_the_same_frames(ctx):
+    """hipGraph capture of the render entry points (include/vkvolume_amd.h: vkv_prepare_render first): eight vkv_render launches, and one
+    vkv_render_batch launch of eight frames, captured on a stream and replayed several times - with host allocations churned between the
+    capture and the replays - must produce the frames of direct launches.  (The argument blocks of the captured batch launch live in a
+    pinned copy the context keeps: the graph's copy node reads its source at every replay; round 4 found the temporary it used to point
+    to.)"""
+    opt = abi.VolumeOptions(**T.APP_TF)
+    scene = T.OracleScene(O.synth_volume((96, 80, 72), 1, 0x5EED0008), opt, 4)
+    v, tf = make_gpu_volume(ctx, scene)
+    V.ComputeDistanceMap(ctx).compute(v, tf, abi.SKIP_DISTANCE)
+    size = (320, 192)
+    ro = abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0)
+    sp = V.VolumeRenderSubpass(ctx, v, ro, size)
+    plist, direct, bufs = [], [], []
+    for k in range(8):
+        view, proj = T.orbit(45.0 * k, image_size=size)
+        p = sp.bind(scene.params(view, proj, size, ro))
+        buf = torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda")
+        p.d_out_rgba8, p.d_out_color, p.d_out_counts, p.d_out_depth = buf.data_ptr(), None, None, None
+        ctx.render(p, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        direct.append(buf.clone())
+        plist.append(p)
+        bufs.append(buf)
+    assert int(direct[0].to(torch.int64).sum().item()) > 0
+    ref = scene.render(plist[3], want_rgba8=True)
+    assert np.array_equal(direct[3].cpu().numpy(), ref.rgba8)
+    s = torch.cuda.Stream()
+    ctx.prepare_render(plist, s.cuda_stream)  # tables + the stream's scratch block in place: a capture allows no event query
+    torch.cuda.synchronize()
+    graphs = []
+    for batch in (False, True):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            st = torch.cuda.current_stream().cuda_stream
+            if batch:
+                ctx.render_batch(plist, st)
+            else:
+                for p in plist:
+                    ctx.render(p, st)
+        graphs.append(g)
+    torch.cuda.synchronize()
+    churn = [np.random.default_rng(i).integers(0, 255, size=200_000, dtype=np.uint8) for i in range(64)]  # reuse what the capture call freed
+    for rep in range(3):
+        for g, name in zip(graphs, ("8 x vkv_render", "vkv_render_batch")):
+            for b in bufs:
+                b.fill_(9)
+            g.replay()
+            torch.cuda.synchronize()
+            for k in range(8):
+                assert torch.equal(bufs[k], direct[k]), "replay %d of the captured %s: view %d differs from the direct launch" % (rep, name, k)
+        churn = [c[::-1].copy() for c in churn]
+    del graphs
+    ctx.release_stream(s.cuda_stream)

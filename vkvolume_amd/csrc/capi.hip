@@ -417,6 +417,9 @@ int vkv_create(int device_ordinal, vkv_ctx **out_ctx)
 		void *m = nullptr;
 		if (hipHostMalloc(&m, ctx->arena_bytes - ctx->table_base, hipHostMallocDefault) == hipSuccess)
 			ctx->table_mirror = static_cast<uint8_t *>(m);        // (without it uploads fall back to the entry's own vector + a wait)
+		void *cp = nullptr;
+		if (hipHostMalloc(&cp, (size_t) kCaptureSlots * kCaptureSlotBytes, hipHostMallocDefault) == hipSuccess)
+			ctx->capture_pool = static_cast<uint8_t *>(cp);        // (without it vkv_render_batch cannot be captured into a hipGraph)
 	}
 	*out_ctx      = ctx;        // the caller's current device is left as it is: every entry point switches to ctx->device itself
 	return VKV_OK;
@@ -438,6 +441,8 @@ void vkv_destroy(vkv_ctx *ctx)
 		}
 		for (void *p : ctx->overflow_scratch)
 			(void) hipFree(p);
+		if (ctx->capture_pool)
+			(void) hipHostFree(ctx->capture_pool);
 		if (ctx->table_mirror)
 			(void) hipHostFree(ctx->table_mirror);
 		(void) hipFree(ctx->arena);

@@ -386,6 +386,7 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	// the argument blocks go through this stream's scratch buffer: an earlier batch on the same stream has finished with it by the
 	// time the copy (same stream) runs
 	static_assert(kMaxBatch * sizeof(RayMarchArgs) <= kScratchBytes - kBatchArgsOffset, "batch argument blocks must fit the stream scratch");
+	static_assert(kPullHeadsBytes + kMaxBatch * sizeof(RayMarchArgs) <= kCaptureSlotBytes, "a captured launch's upload must fit its pinned slot");
 	const VkvTuning           T = tuning_of(ctx);
 	std::vector<RayMarchArgs> host(n);
 	for (uint32_t i = 0; i < n; ++i)
@@ -415,7 +416,22 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	// one upload: the (zeroed) ticket counters of the pull kernel, then the argument blocks
 	std::vector<uint8_t> upload(kPullHeadsBytes + n * sizeof(RayMarchArgs), 0);
 	std::memcpy(upload.data() + kPullHeadsBytes, host.data(), n * sizeof(RayMarchArgs));
-	const hipError_t e = hipMemcpyAsync(d_heads, upload.data(), upload.size(), hipMemcpyHostToDevice, s);
+	const void *upload_src = upload.data();
+	{        // A stream that is being captured into a hipGraph records the copy's SOURCE POINTER and reads it at every replay: the block then has to
+		 // outlive the call - a pinned slot the context keeps until vkv_destroy
+		hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+		if (hipStreamIsCapturing(s, &capture) == hipSuccess && capture == hipStreamCaptureStatusActive)
+		{
+			// (no allocation inside a capture: it would invalidate it.  vkv_create set kCaptureSlots pinned slots aside; a slot is never re-used)
+			std::lock_guard<std::mutex> lock(ctx->mutex);
+			if (!ctx->capture_pool || ctx->capture_slots_used >= kCaptureSlots)
+				return set_error(ctx, VKV_E_UNSUPPORTED, "render_batch: more than %u vkv_render_batch launches captured into hipGraphs by this context", kCaptureSlots);
+			void *pinned = ctx->capture_pool + (size_t) ctx->capture_slots_used++ * kCaptureSlotBytes;
+			std::memcpy(pinned, upload.data(), upload.size());
+			upload_src = pinned;
+		}
+	}
+	const hipError_t e = hipMemcpyAsync(d_heads, upload_src, upload.size(), hipMemcpyHostToDevice, s);
 	if (e != hipSuccess)
 		return set_error(ctx, (int) e, "render_batch: argument upload: %s", hipGetErrorString(e));
 	const uint64_t grid = (uint64_t) ((host[0].tile_count + 7u) / 8u) * 8u * host[0].blocks_per_tile * n;

@@ -182,6 +182,8 @@ struct vkv_ctx
 	uint8_t *           table_mirror = nullptr;  // pinned host twin of the table region: the source of every asynchronous table upload
 	std::vector<void *> overflow;                // hipMalloc blocks set-up calls took for tables when the region was full; freed by vkv_trim / vkv_destroy
 	std::vector<void *> overflow_scratch;        // ... for scratch blocks beyond the reserve; freed by vkv_destroy
+	uint8_t *           capture_pool = nullptr;  // pinned slots for the argument blocks of vkv_render_batch launches captured into hipGraphs (the graph's
+	uint32_t            capture_slots_used = 0;  // copy node reads its source at every replay); a slot is never re-used; freed by vkv_destroy
 	std::unordered_map<hipStream_t, uint8_t *> scratch;        // stream -> kScratchBytes of device memory
 	std::vector<uint8_t *>                     free_scratch;   // blocks given back by vkv_release_stream
 	// an immutable device table with its host copy (the source of the asynchronous upload: it must outlive the call)
@@ -247,6 +249,8 @@ const uint32_t *tile_start_order(vkv_ctx *ctx, uint32_t img_w, uint32_t img_h, u
 VkvTuning tuning_of(vkv_ctx *ctx);        // a copy of the context's tuning block (taken under its mutex)
 constexpr size_t kScratchBytes     = 128 * 1024;
 constexpr size_t kScratchReserve   = 16;          // scratch blocks the arena keeps for streams (2 MiB of the default 8 MiB)
+constexpr uint32_t kCaptureSlots   = 32;          // vkv_render_batch launches one context may have captured into hipGraphs
+constexpr size_t   kCaptureSlotBytes = 96 * 1024;  // >= the pull heads + VKV_MAX_BATCH argument blocks (= the scratch block's argument area)
 constexpr uint32_t kMaxDynamicLds  = 64 * 1024 - 1024;        // what a lean kernel may ask for as dynamic LDS (its tables; no hipFuncSetAttribute is called)
 constexpr size_t kTfBitsOffset     = 0;           // 256*256 bits = 8 KiB: TF bit table of the map update / the voxel count
 constexpr size_t kQueueHeadsOffset = 8192;        // 8 x u32 tile-queue heads of the persistent ray-march scheduler
