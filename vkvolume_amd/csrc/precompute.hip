@@ -793,8 +793,8 @@ struct DmPasses
 	uint8_t *      dst[4], *dst2[4];
 };
 
-template <int MODE, int XT, int SEG>
-__global__ void __launch_bounds__(256) k_dm_rmq(const DmPasses passes, uint32_t n_lines, int len, size_t axis_stride, size_t other_stride, uint32_t chunks_x,
+template <int MODE, int XT, int SEG, int THREADS = 256>
+__global__ void __launch_bounds__(THREADS) k_dm_rmq(const DmPasses passes, uint32_t n_lines, int len, size_t axis_stride, size_t other_stride, uint32_t chunks_x,
                                                 uint32_t chunks_p, int ch, int vec)
 {
 	// A line is one run of the axis; the workgroup owns lines cx * XT .. + XT (consecutive x) of group `other`; LDS index p * XT + line
@@ -817,14 +817,14 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const DmPasses passes, uint32_t 
 	const size_t   base   = (size_t) other * other_stride + (size_t) cx * XT + (size_t) seg0 * axis_stride;
 	auto           at     = [](int p, int line) { return p * XT + line; };
 	// staging / write-out: iteration q of a thread is cell (line, p): 256 / XT cell rows of XT lines at a time
-	const int n_iter = (n + 256 / XT - 1) / (256 / XT);
-	auto      cell   = [&](int q, int &line, int &p) { line = t % XT, p = t / XT + q * (256 / XT); };
+	const int n_iter = (n + THREADS / XT - 1) / (THREADS / XT);
+	auto      cell   = [&](int q, int &line, int &p) { line = t % XT, p = t / XT + q * (THREADS / XT); };
 	using vec_t = typename std::conditional<XT == 16, uint4, typename std::conditional<XT == 8, uint2, uint32_t>::type>::type;        // the XT lines of one cell row
 	// `vec`: every group of XT lines (one XT-byte row segment) is an aligned vector in memory and in the LDS layout - one load / store
 	// instruction moves what XT byte-wide ones would
 	if (vec)
 	{
-		for (int p = t; p < n; p += 256)
+		for (int p = t; p < n; p += THREADS)
 			*reinterpret_cast<vec_t *>(s_t + p * XT) = *reinterpret_cast<const vec_t *>(src + base + (size_t) p * axis_stride);
 	}
 	else
@@ -860,7 +860,7 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const DmPasses passes, uint32_t 
 		uint32_t *      b = reinterpret_cast<uint32_t *>(s_t + k * kLevel);
 		// dword = 4 lines of cell row p; the partner is the same dword h rows on
 		constexpr int kDw = XT / 4;
-		for (int e = t; e < n * kDw; e += 256)
+		for (int e = t; e < n * kDw; e += THREADS)
 		{
 			const int      p = e / kDw;
 			const uint32_t o = (p + h < n) ? a[e + h * kDw] : 0xffffffffu;
@@ -871,7 +871,7 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const DmPasses passes, uint32_t 
 	// ---- results: each thread owns a run of consecutive cells of one line; the first by bisection, the rest by walking
 	// (the result of a neighbouring cell differs by at most one, so one or two window tests settle each further cell)
 	{
-		constexpr int kRuns = 256 / XT;
+		constexpr int kRuns = THREADS / XT;
 		const int     line  = t % XT, run = t / XT;
 		const int     nout  = out1 - out0, rl = (nout + kRuns - 1) / kRuns;
 		const int     pa = out0 - seg0 + run * rl, pb = min(pa + rl, out1 - seg0);        // [pa, pb)
@@ -971,7 +971,7 @@ __global__ void __launch_bounds__(256) k_dm_rmq(const DmPasses passes, uint32_t 
 	__syncthreads();
 	if (vec)
 	{
-		for (int p = out0 - seg0 + t; p < out1 - seg0; p += 256)
+		for (int p = out0 - seg0 + t; p < out1 - seg0; p += THREADS)
 		{
 			const size_t o = base + (size_t) p * axis_stride;
 			*reinterpret_cast<vec_t *>(dst + o) = *reinterpret_cast<const vec_t *>(s_t + kOut + p * XT);
@@ -1478,7 +1478,8 @@ static int launch_dm_rmq_passes(vkv_ctx *ctx, int axis, const DmPasses &passes, 
 	// barriers cost: profiles/r4_dm_variants.txt)
 	if (len <= 128 && me.width > 16)
 		VKV_DM_RMQ(16, 128);
-	else if (len <= 256)        // (4 lines per workgroup here: C3 iso 0.112-0.115 ms against 0.087 - the wave slots, not the LDS, cap the CU at this size) 8 lines per workgroup: 20 KB of LDS instead of 40 (8 workgroups per CU, not 4) and runs of 8 cells per thread:
+	else if (len <= 256)        // (4 lines per workgroup here: C3 iso 0.112-0.115 ms against 0.087 - the wave slots, not the LDS, cap the CU at this size;
+		                        // 16 lines x 512 threads, i.e. 16-byte row segments at the same waves per CU: the same 0.086-0.096 / 0.26 ms) 8 lines per workgroup: 20 KB of LDS instead of 40 (8 workgroups per CU, not 4) and runs of 8 cells per thread:
 		VKV_DM_RMQ(8, 256);        // C3 42.6 -> 36.8 us per isotropic pass, 63 -> 47 us per anisotropic pass
 	else if (len <= 512)        // whole line, no halo; 4 lines per workgroup: 22 KB of LDS instead of 45 (7 workgroups per CU, not 3): C4 iso 0.70 -> 0.64 ms,
 		VKV_DM_RMQ(4, 512);        // aniso 3.11 -> 2.60 ms
