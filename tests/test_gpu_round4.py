@@ -226,58 +226,3 @@ def test_render_launches_captured_into_a_hip_graph_replay_the_same_frames(ctx):
         churn = [c[::-1].copy() for c in churn]
     del graphs
     ctx.release_stream(s.cuda_stream)
-
-
-@pytest.mark.parametrize("skipping_type", [abi.SKIP_NONE, abi.SKIP_BLOCK, abi.SKIP_DISTANCE, abi.SKIP_ANISOTROPIC_DISTANCE])
-def test_format_rows_render_the_same_bits(ctx, skipping_type):
-    """VkvTuning.format_rows: the footprint rows through buffer FORMAT loads (f16 operands, v_fma_mix_f32) against dword gathers + byte
-    conversions - the same real numbers rounded once, so counters, float colour, depth and RGBA8 are equal bit for bit, with and without
-    early ray termination, with and without the per-pixel counters, through vkv_render and vkv_render_batch; and equal to the oracle."""
-    opt = abi.VolumeOptions(**T.APP_TF)
-    scene = T.OracleScene(O.synth_volume((90, 70, 60), 1, 0x5EED0009), opt, 4)
-    v, tf = make_gpu_volume(ctx, scene)
-    V.ComputeDistanceMap(ctx).compute(v, tf, skipping_type)
-    size = (176, 112)
-    st = torch.cuda.current_stream().cuda_stream
-    try:
-        for ert in (True, False):
-            ro = abi.RenderOptions(skipping_type=skipping_type, clip_distance=1.0, early_ray_termination=ert)
-            plist = []
-            for az in (15.0, 130.0, 260.0):
-                view, proj = T.orbit(az, image_size=size)
-                plist.append(V.VolumeRenderSubpass(ctx, v, ro, size).bind(scene.params(view, proj, size, ro)))
-            ref = scene.render(plist[1], want_rgba8=True)
-            got = {}
-            for fmt in (1, 0):
-                ctx.set_tuning(format_rows=fmt)
-                outs = []
-                for with_counts in (True, False):
-                    for batch in (False, True):
-                        o = [dict(color=torch.full((size[1], size[0], 4), -1.0, dtype=torch.float32, device="cuda"),
-                                  depth=torch.full((size[1], size[0]), -1.0, dtype=torch.float32, device="cuda"),
-                                  rgba8=torch.full((size[1], size[0], 4), 7, dtype=torch.uint8, device="cuda"),
-                                  counts=torch.full((size[1], size[0], 3), 9, dtype=torch.int32, device="cuda") if with_counts else None) for _ in plist]
-                        qs = []
-                        for p, x in zip(plist, o):
-                            q = abi.RenderParams.from_buffer_copy(p)
-                            q.d_out_color, q.d_out_depth, q.d_out_rgba8 = x["color"].data_ptr(), x["depth"].data_ptr(), x["rgba8"].data_ptr()
-                            q.d_out_counts = x["counts"].data_ptr() if with_counts else None
-                            qs.append(q)
-                        if batch:
-                            ctx.render_batch(qs, st)
-                        else:
-                            for q in qs:
-                                ctx.render(q, st)
-                        torch.cuda.synchronize()
-                        outs.append(o)
-                got[fmt] = outs
-            for a, b in zip(got[1], got[0]):
-                for i in range(len(plist)):
-                    for k in ("color", "depth", "rgba8", "counts"):
-                        if a[i][k] is not None:
-                            assert torch.equal(a[i][k], b[i][k]), "ERT %s, view %d: %s differs between format rows and dword gathers" % (ert, i, k)
-            assert np.array_equal(got[1][0][1]["counts"].cpu().numpy().astype(np.uint32), ref.counts)
-            assert np.array_equal(got[1][0][1]["rgba8"].cpu().numpy(), ref.rgba8)
-            assert np.array_equal(got[1][3][1]["rgba8"].cpu().numpy(), ref.rgba8)  # the counter-free batch launch
-    finally:
-        ctx.set_tuning(format_rows=1)
