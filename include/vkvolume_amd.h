@@ -210,8 +210,7 @@ typedef struct VkvTuning
 	int32_t  screen_cull;              /* 1 = pixels outside the screen bound of the volume's box skip the ray set-up (default)   VKV_RAYMARCH_CULL=0 */
 	int32_t  feedback;                 /* 1 = registered targets start their tiles in the order their last measured frame suggests (default)   VKV_RAYMARCH_FEEDBACK=0 */
 	uint32_t feedback_period;          /* frames between two cost measurements of a target (8)                            VKV_RAYMARCH_FEEDBACK_PERIOD */
-	int32_t  format_rows;              /* packed image below 4 GiB + per-voxel address tables: 1 = the footprint rows come through buffer FORMAT loads
-	                                      (f16 operands of v_fma_mix_f32, no byte conversions; default), 0 = dword gathers             VKV_RAYMARCH_FORMAT_ROWS=0 */
+	int32_t  reserved0;                /* ignored (round 3's ray-order experiment lived here; it lost 3 % and left the product)                        */
 	float    tile_mix_heavy;           /* experiment: central share of the tiles spread over the first tile_mix_spread of the order (0 = off)   VKV_RAYMARCH_TILE_MIX=h,s */
 	float    tile_mix_spread;
 	uint32_t gradient_segment;         /* vkv_gradient_map: tiles a workgroup marches in z; 0 = automatic                 VKV_GRADIENT_SEGMENT */

@@ -571,9 +571,41 @@ __device__ __forceinline__ void packed_filter_g(uint32_t q00, uint32_t q10, uint
 	out_g = __builtin_fmaf(wz, c1 - c0, c0) * kScale;
 }
 
-// (kLabFmt: the f16 row types, the buffer resource and fma_mix_lo / fma_mix_hi are the product's, raymarch_core.hpp)
+// ---- kLabFmt: rows as f16 quadruples (v0, g0, v1, g1) from a buffer FORMAT load ---------------------------------------------------
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef int      int4v __attribute__((ext_vector_type(4)));
+__device__ half4v vkv_buffer_load_format_h4(int4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f16");
+
+// buffer resource of the packed image: raw (stride 0), 4 GiB window, dst_sel RGBA, USCALED 8_8_8_8 (gfx9 V# word 3)
+__device__ __forceinline__ int4v packed_rows_rsrc(const uint8_t *base)
+{
+	const uint64_t a = reinterpret_cast<uint64_t>(base);
+	int4v          r;
+	r.x = __builtin_amdgcn_readfirstlane((int) (uint32_t) a);
+	r.y = __builtin_amdgcn_readfirstlane((int) (uint32_t) ((a >> 32) & 0xffffu));
+	r.z = -1;
+	r.w = (int) (0xFACu | (2u << 12) | (10u << 15));
+	return r;
+}
+
+// One channel pair of the x stage: d = (v1 - v0, g1 - g0) in f16 (integers below 256: exact), then c = fma(wx, d, b) with the f16
+// operands widened inside the instruction - the same real numbers the fp32 path multiplies and adds, rounded once: bit-identical.
+__device__ __forceinline__ float fma_mix_lo(float w, half2v d, half2v b)
+{        // fma(w, float(d.x), float(b.x)); the compiler forms it from the plain expression for the low halves only
+	float r;
+	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(d), "v"(b));
+	return r;
+}
+__device__ __forceinline__ float fma_mix_hi(float w, half2v d, half2v b)
+{        // fma(w, float(d.y), float(b.y))
+	float r;
+	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(d), "v"(b));
+	return r;
+}
+
 template <bool WANT_V, bool WANT_G, bool TABLE>
-__device__ __forceinline__ void lab_packed_filter_fmt(half4v h00, half4v h10, half4v h01, half4v h11, float wx, float wy, float wz, float &out_v, float &out_g)
+__device__ __forceinline__ void packed_filter_fmt(half4v h00, half4v h10, half4v h01, half4v h11, float wx, float wy, float wz, float &out_v, float &out_g)
 {
 	constexpr float kScale = TABLE ? kInv255 * 1024.0f : kInv255;
 	const half2v    b00 = {h00.x, h00.y}, b10 = {h10.x, h10.y}, b01 = {h01.x, h01.y}, b11 = {h11.x, h11.y};
@@ -591,6 +623,21 @@ __device__ __forceinline__ void lab_packed_filter_fmt(half4v h00, half4v h10, ha
 		out_g = __builtin_fmaf(wz, c1 - c0, c0) * kScale;
 	}
 }
+// the same footprint as a 32-bit byte offset into the packed image (kLabFmt: images below 4 GiB)
+__device__ __forceinline__ uint32_t packed_footprint_full_offset(const FullLutConsts &C, const RmLds &L, float px, float py, float pz, float &wx, float &wy, float &wz)
+{
+	const float cx = __builtin_fmaf(px, C.w, -0.5f), cy = __builtin_fmaf(py, C.h, -0.5f), cz = __builtin_fmaf(pz, C.d, -0.5f);
+	const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy), fz = __builtin_floorf(cz);
+	wx = cx - fx, wy = cy - fy, wz = cz - fz;
+	const int      tx = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fx, -1.0f, C.w), 4.0f, 4.0f);
+	const int      ty = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fy, -1.0f, C.h), 4.0f, C.oy);
+	const int      tz = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fz, -1.0f, C.d), 4.0f, C.oz);
+	const char *   lut = reinterpret_cast<const char *>(full_lut_base(L));
+	const uint32_t xo = *reinterpret_cast<const uint32_t *>(lut + tx), yo = *reinterpret_cast<const uint32_t *>(lut + ty);
+	const uint32_t zo = *reinterpret_cast<const uint32_t *>(lut + tz);
+	return ((xo + yo) + zo) << 1;
+}
+
 template <int SKIP, bool ERT, int GRAD, bool PACKED, bool SEP, uint32_t LF>
 __device__ __forceinline__ void lab_lean_march(const RayMarchArgs &A, Ray &R, const RmLds &L, uint32_t &iter, LeanStamp &stamp)
 {
@@ -793,9 +840,9 @@ __device__ __forceinline__ void lab_lean_march(const RayMarchArgs &A, Ray &R, co
 			if (kFmt)
 			{
 				if (GRAD == 1 && !kGradSkip)
-					lab_packed_filter_fmt<true, true, true>(h00, h10, h01, h11, wx, wy, wz, intensity, gradient);
+					packed_filter_fmt<true, true, true>(h00, h10, h01, h11, wx, wy, wz, intensity, gradient);
 				else
-					lab_packed_filter_fmt<true, false, true>(h00, h10, h01, h11, wx, wy, wz, intensity, g_unused);
+					packed_filter_fmt<true, false, true>(h00, h10, h01, h11, wx, wy, wz, intensity, g_unused);
 			}
 			else if (GRAD == 1 && !kGradSkip)
 				packed_filter_cvt<true, true>(q00, q10, q01, q11, wx, wy, wz, intensity, gradient);
@@ -808,7 +855,7 @@ __device__ __forceinline__ void lab_lean_march(const RayMarchArgs &A, Ray &R, co
 			if (GRAD == 1 && (!kGradSkip || __builtin_amdgcn_ballot_w64(ai > 0.0f) != 0ull))
 			{
 				if (kGradSkip && kFmt)
-					lab_packed_filter_fmt<false, true, true>(h00, h10, h01, h11, wx, wy, wz, g_unused, gradient);
+					packed_filter_fmt<false, true, true>(h00, h10, h01, h11, wx, wy, wz, g_unused, gradient);
 				else if (kGradSkip)
 					packed_filter_g<true>(q00, q10, q01, q11, wx, wy, wz, gradient);
 				ag = *reinterpret_cast<const float *>(ag_tab + ((uint32_t) (int) gradient & ~3u));

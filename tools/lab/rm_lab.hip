@@ -116,7 +116,6 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 		// the product's lean_march (raymarch_core.hpp), instantiated here: 30 = kLeanLut | kLeanFull as shipped, 31 = + per-iteration stamps
 		case 30: return launch_product_lean<SKIP, ERT, GRAD, kLeanLut | kLeanFull>(a, s);
 		case 31: return launch_product_lean<SKIP, ERT, GRAD, kLeanLut | kLeanFull | kLeanStamp>(a, s);
-		case 34: return launch_product_lean<SKIP, ERT, GRAD, kLeanLut | kLeanFull | kLeanFmt>(a, s);        // footprint rows through buffer FORMAT loads
 		case 6: return launch_lean<SKIP, ERT, GRAD, true, kLabUniform | kLabLut | kLabBranch | kLabCvt>(a, s);
 #ifdef LAB_ALL
 		case 1: return launch_lean<SKIP, ERT, GRAD, true, 0>(a, s);

@@ -310,7 +310,6 @@ static void default_tuning(VkvTuning &t)
 	t.screen_cull          = 1;
 	t.feedback             = 1;
 	t.feedback_period      = 8;
-	t.format_rows          = 1;
 	t.arena_bytes          = 8u << 20;
 	auto env = [](const char *name) -> const char * { const char *e = std::getenv(name); return (e && e[0]) ? e : nullptr; };
 	if (const char *e = env("VKV_RAYMARCH_SCHEDULER"))
@@ -329,8 +328,6 @@ static void default_tuning(VkvTuning &t)
 		t.screen_cull = e[0] != '0';
 	if (const char *e = env("VKV_RAYMARCH_FEEDBACK"))
 		t.feedback = e[0] != '0';
-	if (const char *e = env("VKV_RAYMARCH_FORMAT_ROWS"))
-		t.format_rows = e[0] != '0';
 	if (const char *e = env("VKV_RAYMARCH_FEEDBACK_PERIOD"))
 		t.feedback_period = (uint32_t) std::max(1l, std::atol(e));
 	if (const char *e = env("VKV_RAYMARCH_TILE_MIX"))

@@ -977,11 +977,6 @@ constexpr uint32_t kLeanNoCounts = 4u;        // the three per-pixel counters (v
                                               // additions and the EXEC-masked else-branch of the empty sample leave the loop
 constexpr uint32_t kLeanStamp    = 8u;        // (diagnostic, instantiated by tools/lab only, with the trace buffer) s_memtime at the top of every iteration,
                                               // summed per wave by the iteration's kind: only probing lanes / only sampling lanes / both
-constexpr uint32_t kLeanFmt      = 16u;       // with kLeanFull and the separable transfer function, packed image below 4 GiB: the x-pair rows of the footprint come
-                                              // through buffer FORMAT loads (buffer_load_format_d16_xyzw, 8_8_8_8 USCALED: the texture path hands the four bytes back
-                                              // as exact f16 at any byte alignment, at 0.6 x the address-path cost of a dword gather - tools/micro/typed_gather.hip)
-                                              // and the x stage of the two trilinear filters is 4 v_pk_add_f16 + 8 v_fma_mix_f32 where the byte conversions took 24
-                                              // instructions; the same real numbers rounded once: bit-identical
 constexpr size_t   kMaxLutBytes  = 8 * 1024;  // LDS budget of the two-level address tables (1.2 KB at 1024 voxels per axis, 1.9 KB at 2048)
 
 __device__ __forceinline__ float cvt_ubyte0(uint32_t q) { float f; asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(q)); return f; }
@@ -1016,59 +1011,6 @@ __device__ __forceinline__ void packed_filter_cvt(uint32_t q00, uint32_t q10, ui
 		out_g = __builtin_fmaf(wz, c1 - c0, c0) * kScale;
 	}
 }
-// ---- kLeanFmt: rows as f16 quadruples (v0, g0, v1, g1) from a buffer FORMAT load ---------------------------------------------------
-typedef _Float16 half4v __attribute__((ext_vector_type(4)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef int      int4v __attribute__((ext_vector_type(4)));
-__device__ half4v vkv_buffer_load_format_h4(int4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f16");
-
-// buffer resource of the packed image: raw (stride 0), 4 GiB window, dst_sel RGBA, USCALED 8_8_8_8 (gfx9 V# word 3)
-__device__ __forceinline__ int4v packed_rows_rsrc(const uint8_t *base)
-{
-	const uint64_t a = reinterpret_cast<uint64_t>(base);
-	int4v          r;
-	r.x = __builtin_amdgcn_readfirstlane((int) (uint32_t) a);
-	r.y = __builtin_amdgcn_readfirstlane((int) (uint32_t) ((a >> 32) & 0xffffu));
-	r.z = -1;
-	r.w = (int) (0xFACu | (2u << 12) | (10u << 15));
-	return r;
-}
-
-// One channel pair of the x stage: d = (v1 - v0, g1 - g0) in f16 (integers below 256: exact), then c = fma(wx, d, b) with the f16
-// operands widened inside the instruction - the same real numbers the fp32 path multiplies and adds, rounded once: bit-identical.
-__device__ __forceinline__ float fma_mix_lo(float w, half2v d, half2v b)
-{        // fma(w, float(d.x), float(b.x))
-	float r;
-	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(d), "v"(b));
-	return r;
-}
-__device__ __forceinline__ float fma_mix_hi(float w, half2v d, half2v b)
-{        // fma(w, float(d.y), float(b.y))
-	float r;
-	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(d), "v"(b));
-	return r;
-}
-
-// packed_filter_cvt<WANT_G, true> on f16 rows: results * 1024 (byte offsets into the 257-entry float tables)
-template <bool WANT_G>
-__device__ __forceinline__ void packed_filter_fmt(half4v h00, half4v h10, half4v h01, half4v h11, float wx, float wy, float wz, float &out_v, float &out_g)
-{
-	constexpr float kScale = kInv255 * 1024.0f;
-	const half2v    b00 = {h00.x, h00.y}, b10 = {h10.x, h10.y}, b01 = {h01.x, h01.y}, b11 = {h11.x, h11.y};
-	const half2v    d00 = half2v{h00.z, h00.w} - b00, d10 = half2v{h10.z, h10.w} - b10, d01 = half2v{h01.z, h01.w} - b01, d11 = half2v{h11.z, h11.w} - b11;
-	{
-		const float c00 = fma_mix_lo(wx, d00, b00), c10 = fma_mix_lo(wx, d10, b10), c01 = fma_mix_lo(wx, d01, b01), c11 = fma_mix_lo(wx, d11, b11);
-		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
-		out_v = __builtin_fmaf(wz, c1 - c0, c0) * kScale;
-	}
-	if (WANT_G)
-	{
-		const float c00 = fma_mix_hi(wx, d00, b00), c10 = fma_mix_hi(wx, d10, b10), c01 = fma_mix_hi(wx, d01, b01), c11 = fma_mix_hi(wx, d11, b11);
-		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
-		out_g = __builtin_fmaf(wz, c1 - c0, c0) * kScale;
-	}
-}
-
 // The LDS of the lean kernels is ONE dynamic segment whose layout the launcher sizes (lean_lds_bytes): RmLds at its start, behind it
 // either the two-level address tables (kLeanLut) or, starting inside RmLds behind the separable transfer-function tables, the
 // per-voxel-index tables (kLeanFull).  The kernels have NO static LDS object, so the segment starts at LDS address 0 - RmLds sits at
@@ -1226,21 +1168,6 @@ __device__ __forceinline__ const uint8_t *packed_footprint_full(const FullLutCon
 	const uint32_t zo = *reinterpret_cast<const uint32_t *>(lut + tz);
 	return C.base + ((uint64_t) ((xo + yo) + zo) << 1);        // the terms are in units of two bytes
 }
-// the same footprint as a 32-bit byte offset into the packed image (kLeanFmt: images below 4 GiB)
-__device__ __forceinline__ uint32_t packed_footprint_full_offset(const FullLutConsts &C, const RmLds &L, float px, float py, float pz, float &wx, float &wy, float &wz)
-{
-	const float cx = __builtin_fmaf(px, C.w, -0.5f), cy = __builtin_fmaf(py, C.h, -0.5f), cz = __builtin_fmaf(pz, C.d, -0.5f);
-	const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy), fz = __builtin_floorf(cz);
-	wx = cx - fx, wy = cy - fy, wz = cz - fz;
-	const int      tx = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fx, -1.0f, C.w), 4.0f, 4.0f);
-	const int      ty = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fy, -1.0f, C.h), 4.0f, C.oy);
-	const int      tz = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fz, -1.0f, C.d), 4.0f, C.oz);
-	const char *   lut = reinterpret_cast<const char *>(full_lut_base(L));
-	const uint32_t xo = *reinterpret_cast<const uint32_t *>(lut + tx), yo = *reinterpret_cast<const uint32_t *>(lut + ty);
-	const uint32_t zo = *reinterpret_cast<const uint32_t *>(lut + tz);
-	return ((xo + yo) + zo) << 1;
-}
-
 // A footprint address that comes out of the LDS address tables is an integer: tell the compiler it points to global memory, or it emits
 // flat_load (which also counts on lgkmcnt, so every wait for an LDS read would wait for the footprint as well).
 typedef const __attribute__((address_space(1))) u32_align2 *global_row_ptr;
@@ -1277,7 +1204,6 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	constexpr bool kStamp = (LF & kLeanStamp) != 0, kCounts = (LF & kLeanNoCounts) == 0;
 	constexpr bool kHoist = PACKED && GRAD != 2;
 	constexpr bool kLut = (LF & kLeanLut) != 0, kFull = (LF & kLeanFull) != 0 && SEP, kTf = SEP && kHoist;
-	constexpr bool kFmt = (LF & kLeanFmt) != 0 && kFull && kTf;
 	uint32_t       stamp_prev = 0, stamp_kind = 3;
 	const int      W = A.W, H = A.H, D = A.D;
 	const float    kx = SKIP != VKV_SKIP_NONE ? (float) W / A.block_size[0] : 0.0f, ky = SKIP != VKV_SKIP_NONE ? (float) H / A.block_size[1] : 0.0f,
@@ -1287,12 +1213,10 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	uint32_t    ul   = 0;
 	bool        occ  = true, done = false;
 	const float sgx = R.six > 0.0f ? 1.0f : -1.0f, sgy = R.siy > 0.0f ? 1.0f : -1.0f, sgz = R.siz > 0.0f ? 1.0f : -1.0f;
+	const float ofx = R.six > 0.0f ? 0.0f : 1.0f, ofy = R.siy > 0.0f ? 0.0f : 1.0f, ofz = R.siz > 0.0f ? 0.0f : 1.0f;
 	FullLutConsts fullc = {};
 	if (kFull)
 		fullc = full_lut_consts(A);
-	int4v rows = {};
-	if (kFmt)
-		rows = packed_rows_rsrc(A.packed);
 	// loop position, its bounds and the first hit as floats (exact: n_steps <= 2^24)
 	float       li = (float) R.i, li_min = (float) R.i_min, lfirst = (float) R.first_hit;
 	const float ln = (float) R.n_steps, lback = (float) A.back;
@@ -1341,18 +1265,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		float    wx = undefined_value<float>(), wy = undefined_value<float>(), wz = undefined_value<float>();
 		if (SKIP != VKV_SKIP_NONE && probe)
 			dist = load_u8_global(R.dmap, cell);
-		half4v h00 = {}, h10 = {}, h01 = {}, h11 = {};
-		if (kFmt)
-			h00 = undefined_value<half4v>(), h10 = undefined_value<half4v>(), h01 = undefined_value<half4v>(), h11 = undefined_value<half4v>();
-		if (kFmt && !probe)
-		{
-			const int bo = (int) packed_footprint_full_offset(fullc, L, posx, posy, posz, wx, wy, wz);
-			h00 = vkv_buffer_load_format_h4(rows, bo, 0, 0);
-			h10 = vkv_buffer_load_format_h4(rows, bo + 10, 0, 0);
-			h01 = vkv_buffer_load_format_h4(rows, bo + 50, 0, 0);
-			h11 = vkv_buffer_load_format_h4(rows, bo + 60, 0, 0);
-		}
-		if (kHoist && !kFmt && !probe)
+		if (kHoist && !probe)
 		{
 			const uint8_t *ba = kFull  ? packed_footprint_full(fullc, L, posx, posy, posz, wx, wy, wz)
 			                    : kLut ? packed_footprint_lut(A, posx, posy, posz, wx, wy, wz)
@@ -1377,12 +1290,11 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 				az = (((R.siz < 0.0f) ? 0.0f : 1.0f) + rz) * R.siz;
 			}
 			else
-			{        // step(0, -s) + sign(s) * dist = fd for s > 0, 1 - fd for s < 0, as sign(s) * (fd - 0.5) + 0.5: one subtraction for the three axes
-				 // and one fma with a per-ray constant each (exact: fd is an integer below 256, every intermediate is a multiple of 0.5)
-				const float fh = (float) dist - 0.5f;
-				ax = (__builtin_fmaf(sgx, fh, 0.5f) + rx) * R.six;
-				ay = (__builtin_fmaf(sgy, fh, 0.5f) + ry) * R.siy;
-				az = (__builtin_fmaf(sgz, fh, 0.5f) + rz) * R.siz;
+			{        // step(0, -s) + sign(s) * dist = fd for s > 0, 1 - fd for s < 0: one fma with per-ray constants (exact: the product is exact)
+				const float fd = (float) dist;
+				ax = (__builtin_fmaf(sgx, fd, ofx) + rx) * R.six;
+				ay = (__builtin_fmaf(sgy, fd, ofy) + ry) * R.siy;
+				az = (__builtin_fmaf(sgz, fd, ofz) + rz) * R.siz;
 			}
 			// a NaN component (0 * inf on an axis-parallel ray) counts as +inf: minNum ignores it; all three cannot be NaN, and if
 			// they were the comparison caps the result exactly as the select chain of the oracle does
@@ -1401,14 +1313,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 				 // filter of bytes / 255; the tables have a 257th entry), alpha byte without a clamp (ai, ag <= 1 by construction of the tables)
 				const char *ai_tab = reinterpret_cast<const char *>(L.s.ai), *ag_tab = reinterpret_cast<const char *>(L.s.ag);
 				float       g_unused;
-				if (kFmt)
-				{
-					if (GRAD == 1)
-						packed_filter_fmt<true>(h00, h10, h01, h11, wx, wy, wz, intensity, gradient);
-					else
-						packed_filter_fmt<false>(h00, h10, h01, h11, wx, wy, wz, intensity, g_unused);
-				}
-				else if (GRAD == 1)
+				if (GRAD == 1)
 					packed_filter_cvt<true, true>(q00, q10, q01, q11, wx, wy, wz, intensity, gradient);
 				else
 					packed_filter_cvt<false, true>(q00, q10, q01, q11, wx, wy, wz, intensity, g_unused);

@@ -21,12 +21,10 @@ constexpr uint32_t kLfLut    = kLeanLut;                         // two-level ad
 constexpr uint32_t kLfFull   = kLeanLut | kLeanFull;             // + one entry per voxel index with the separable transfer function
 constexpr uint32_t kLfFullNc = kLfFull | kLeanNoCounts;          // the same without the per-pixel counters (what a renderer launches)
 constexpr uint32_t kLfLutNc  = kLfLut | kLeanNoCounts;
-constexpr uint32_t kLfFmt    = kLfFull | kLeanFmt;               // full tables + footprint rows through buffer FORMAT loads (packed image below 4 GiB)
-constexpr uint32_t kLfFmtNc  = kLfFmt | kLeanNoCounts;
 
 struct LeanChoice
 {
-	int    kind;        // 0 plain, 1 two-level tables, 2 full tables, 3 full tables + format rows
+	int    kind;        // 0 plain, 1 two-level tables, 2 full tables
 	size_t lds;         // dynamic LDS bytes (lean_lds_bytes: the kernels' whole LDS layout lives in the dynamic segment)
 };
 
@@ -88,16 +86,12 @@ static int launch_one(vkv_ctx *ctx, int sched, const VkvTuning &T, RayMarchArgs 
 			{
 				if constexpr (SKIP != VKV_SKIP_NONE && ERT && GRAD == 1)
 				{
-					if (c.kind == 3)
-						hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfFmtNc>), dim3(grid), dim3(256), c.lds, s, a);
-					else if (c.kind == 2)
+					if (c.kind == 2)
 						hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfFullNc>), dim3(grid), dim3(256), c.lds, s, a);
 					else
 						hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfLutNc>), dim3(grid), dim3(256), c.lds, s, a);
 				}
 			}
-			else if (c.kind == 3)
-				hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfFmt>), dim3(grid), dim3(256), c.lds, s, a);
 			else if (c.kind == 2)
 				hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfFull>), dim3(grid), dim3(256), c.lds, s, a);
 			else if (c.kind == 1)
@@ -128,18 +122,14 @@ static void launch_batch_kind(LeanChoice c, bool no_counts, const RayMarchArgs *
 		{
 			if (c.kind != 0 && no_counts)
 			{
-				if (c.kind == 3)
-					hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfFmtNc>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
-				else if (c.kind == 2)
+				if (c.kind == 2)
 					hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfFullNc>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
 				else
 					hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfLutNc>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
 				return;
 			}
 		}
-		if (c.kind == 3)
-			hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfFmt>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
-		else if (c.kind == 2)
+		if (c.kind == 2)
 			hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfFull>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
 		else if (c.kind == 1)
 			hipLaunchKernelGGL((k_raymarch_lean_batch<SKIP, ERT, GRAD, kLfLut>), dim3(grid), dim3(256), c.lds, s, d_frames, n, gpf);
@@ -180,7 +170,7 @@ static uint32_t launch_pull_kind(vkv_ctx *ctx, LeanChoice c, const RayMarchArgs 
 {
 	if constexpr (GRAD != 2)
 	{
-		if (c.kind >= 2)        // (the pull kernel has no format-row instantiation: the full tables with dword gathers)
+		if (c.kind == 2)
 			return launch_pull_one<SKIP, ERT, GRAD, kLfFull>(ctx, d_frames, n, d_heads, c.lds, units, s);
 		if (c.kind == 1)
 			return launch_pull_one<SKIP, ERT, GRAD, kLfLut>(ctx, d_frames, n, d_heads, c.lds, units, s);
