@@ -71,13 +71,14 @@ def test_two_rank_tile_gather_reassembles_the_frame(tmp_path, rotate):
         assert np.array_equal(f, ref)
 
 
-def _batch_worker(rank, port, out_path):
+def _batch_worker(rank, port, out_path, host_staging=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:
         scene, _, proj, _ = _scene()
         frames_per_launch = 3
-        g = multigpu.BatchTileGather(dist, rank, WORLD, FRAME, 16, 4, device="cpu", frames=frames_per_launch, n_sets=2, any_root=True)
+        g = multigpu.BatchTileGather(dist, rank, WORLD, FRAME, 16, 4, device="cpu", frames=frames_per_launch, n_sets=2, any_root=True,
+                                     host_staging=host_staging)
         opts = abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0)
         done = []
         launches = [(0, 3, (25.0, 100.0, 190.0)), (1, 2, (280.0, 330.0))]  # (buffer set, frames in the launch, their azimuths)
@@ -102,13 +103,15 @@ def _batch_worker(rank, port, out_path):
         dist.destroy_process_group()
 
 
-def test_two_rank_batch_gather_reassembles_every_frame_of_a_launch(tmp_path):
-    """BatchTileGather: the compact tile buffers of all frames of a launch travel in one collective to the launch's owner."""
+@pytest.mark.parametrize("host_staging", [False, True])
+def test_two_rank_batch_gather_reassembles_every_frame_of_a_launch(tmp_path, host_staging):
+    """BatchTileGather: the compact tile buffers of all frames of a launch travel in one collective to the launch's owner
+    (host_staging: through host copies, the path bench.py --backend gloo takes for device buffers)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "batch")
-    mp.spawn(_batch_worker, args=(port, out), nprocs=WORLD, join=True)
+    mp.spawn(_batch_worker, args=(port, out, host_staging), nprocs=WORLD, join=True)
     scene, _, proj, _ = _scene()
     opts = abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0)
     seen = 0
