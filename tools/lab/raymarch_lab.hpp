@@ -35,6 +35,8 @@ constexpr uint32_t kLabBrickMap = 524288u;   // (round 4) the distance map the p
                                              // vkv_lab_brick_map lays it out; the cell id compared with u_last_alpha is the bricked index (any injective id works)
 constexpr uint32_t kLabProbeOnly = 1048576u; // (round 4, timing / cache-counter runs only: the frame is WRONG) the footprint gathers are not issued (the filter sees zeros),
                                              // so that the probes are the only vector memory traffic of the loop
+constexpr uint32_t kLabHalfRows = 2097152u;  // (round 4, timing only: the frame is WRONG) two of the four footprint gathers are not issued (rows y1 reuse rows y0's
+                                             // dwords): what a layout that delivers a footprint in two gathers could gain at unchanged VALU work
 constexpr uint32_t kLabDefault = kLabUniform | kLabBranch | kLabCvt;
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -649,7 +651,7 @@ __device__ __forceinline__ void lab_lean_march(const RayMarchArgs &A, Ray &R, co
 	               kGradSkip = (LF & kLabGradSkip) != 0 && kTf && GRAD == 1, kFloatI = (LF & kLabFloatI) != 0 && kBranch, kWb = (LF & kLabWb) != 0,
 	               kFloatCell = (LF & kLabFloatCell) != 0 && SKIP != VKV_SKIP_NONE, kPrefetch = (LF & kLabPrefetch) != 0 && kHoist && kNest,
 	               kFmt = (LF & kLabFmt) != 0 && kFull && kTf && !kPrefetch, kFmtScalar = kFmt && (LF & kLabFmtVec) == 0,
-	               kBrick = (LF & kLabBrickMap) != 0 && kScalar && !kFloatCell, kProbeOnly = (LF & kLabProbeOnly) != 0;
+	               kBrick = (LF & kLabBrickMap) != 0 && kScalar && !kFloatCell, kProbeOnly = (LF & kLabProbeOnly) != 0, kHalfRows = (LF & kLabHalfRows) != 0;
 	// bricked map: index = x + 4 y + 16 z + 60 (x >> 2) + (64 bw - 16) (y >> 2) + (64 bw bh - 64) (z >> 2), bw / bh = bricks per row / column
 	const uint32_t brick_cy = 64u * (((uint32_t) A.mw + 3u) >> 2) - 16u, brick_cz = 64u * (((uint32_t) A.mw + 3u) >> 2) * (((uint32_t) A.mh + 3u) >> 2) - 64u;
 	using idx_t = std::conditional_t<kFloatI, float, int>;
@@ -764,6 +766,13 @@ __device__ __forceinline__ void lab_lean_march(const RayMarchArgs &A, Ray &R, co
 			{
 				(void) footprint_of(posx, posy, posz, wx, wy, wz);
 				q00 = q10 = q01 = q11 = 0u;
+			}
+			else if (kHalfRows)
+			{
+				const uint8_t *ba = footprint_of(posx, posy, posz, wx, wy, wz);
+				q00 = load_row<kNt>(ba);
+				q01 = load_row<kNt>(ba + 50);
+				q10 = q00, q11 = q01;
 			}
 			else
 			{

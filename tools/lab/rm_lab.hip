@@ -111,6 +111,7 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 		case 41: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabProbeOnly>(a, s);
 		case 42: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabProbeOnly | kLabBrickMap>(a, s);
 		case 43: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabStamp | kLabBrickMap>(a, s);
+		case 44: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabHalfRows>(a, s);
 		case 23: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabScalar | kLabNest | kLabKeep | kLabFull | kLabTf | kLabWb | kLabFloatI | kLabPrefetch>(a, s);
 		case 17: return launch_lean<SKIP, ERT, GRAD, true, kLabDefault | kLabLut | kLabFull>(a, s);
 		// the product's lean_march (raymarch_core.hpp), instantiated here: 30 = kLeanLut | kLeanFull as shipped, 31 = + per-iteration stamps

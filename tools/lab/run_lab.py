@@ -69,7 +69,7 @@ def set_outputs(p, b, only_rgba8=False):
 
 
 BRICK_VARIANTS = (40, 42, 43)   # read a bricked distance map (vkv_lab_brick_map); 41 / 42: probes only (the frame is wrong by design: not compared)
-NOT_COMPARED = (41, 42)
+NOT_COMPARED = (41, 42, 44)   # 44: two of the four footprint gathers skipped
 LAB.vkv_lab_brick_map.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
 _me = v.map_extent
 _bricked = []

@@ -21,6 +21,21 @@ __global__ void __launch_bounds__(256) k(const uint8_t *buf, uint32_t nrec_mask,
 		if (MODE == 2) { uint2 v = *reinterpret_cast<const uint2 *>(p); acc += v.x ^ v.y; }
 		if (MODE == 3) { uint4 v = *reinterpret_cast<const uint4 *>(p); acc += v.x ^ v.y ^ v.z ^ v.w; }
 		if (MODE == 4) { const uint32_t *q = reinterpret_cast<const uint32_t *>(p); acc += q[0] ^ q[1] ^ q[2] ^ q[3]; }   // may merge
+		if (MODE >= 6 && MODE <= 9)
+		{   // round 4: a 16-byte gather that is NOT 16-byte aligned - 8, 4, 2 bytes off a record boundary (an empty asm keeps it one instruction)
+			typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+			typedef const __attribute__((address_space(1))) u4 __attribute__((aligned(2))) *gp;
+			const uint32_t off = MODE == 6 ? 8u : MODE == 7 ? 4u : MODE == 8 ? 2u : 10u;
+			u4 v = *(gp) (uintptr_t) (buf + (uint64_t) (rec & (nrec_mask >> 1)) * 16 + off);
+			acc += v.x ^ v.y ^ v.z ^ v.w;
+		}
+		if (MODE == 10)
+		{   // dwordx2 at 4-byte alignment
+			typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+			typedef const __attribute__((address_space(1))) u2 __attribute__((aligned(4))) *gp;
+			u2 v = *(gp) (uintptr_t) (buf + (uint64_t) (rec & (nrec_mask >> 1)) * 16 + 4);
+			acc += v.x ^ v.y;
+		}
 		if (MODE == 5)
 		{   // 4 separate dwords the compiler cannot merge (different records), like the packed brick rows
 			const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
@@ -37,7 +52,8 @@ int main()
 	const int blocks = 256 * 8 * 4;
 	uint32_t *out; hipMalloc(&out, blocks * 256 * 4);
 	hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-	const char *names[] = {"1 byte", "1 dword", "1 dwordx2", "1 dwordx4", "4 dword (same record)", "4 dword (4 records)"};
+	const char *names[] = {"1 byte", "1 dword", "1 dwordx2", "1 dwordx4", "4 dword (same record)", "4 dword (4 records)", "1 dwordx4, 8 bytes off", "1 dwordx4, 4 bytes off",
+	                       "1 dwordx4, 2 bytes off", "1 dwordx4, 10 bytes off", "1 dwordx2, 4 bytes off"};
 	for (uint64_t log2rec : {10, 18, 26})
 	{
 		const uint64_t nrec = 1ull << log2rec; uint8_t *buf;
@@ -52,6 +68,7 @@ int main()
 			printf("  %-24s %.3f ms  %.1f cycles/CU per wave-iteration (2.4 GHz, 256 CUs)\n", name, ms, ms * 1e-3 * 2.4e9 * 256 / wave_iters);
 		};
 		run(k<0>, names[0]); run(k<1>, names[1]); run(k<2>, names[2]); run(k<3>, names[3]); run(k<4>, names[4]); run(k<5>, names[5]);
+		run(k<6>, names[6]); run(k<7>, names[7]); run(k<8>, names[8]); run(k<9>, names[9]); run(k<10>, names[10]);
 		hipFree(buf);
 	}
 	return 0;
