@@ -909,6 +909,20 @@ static struct
 	int             n_threads;          /* pool threads created so far */
 } g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0, 0, 0, 0};
 
+/* a forked child inherits the pool's bookkeeping but none of its threads: start over (a parent that forks while a render is running is
+ * on its own, as with any lock held across fork) */
+static void pool_after_fork_in_child(void)
+{
+	pthread_mutex_init(&g_pool.job_mutex, NULL);
+	pthread_mutex_init(&g_pool.m, NULL);
+	pthread_cond_init(&g_pool.wake, NULL);
+	pthread_cond_init(&g_pool.done, NULL);
+	g_pool.job = NULL, g_pool.generation = 0, g_pool.participants = 0, g_pool.running = 0, g_pool.n_threads = 0;
+}
+
+static pthread_once_t g_pool_once = PTHREAD_ONCE_INIT;
+static void           pool_init_once(void) { pthread_atfork(NULL, NULL, pool_after_fork_in_child); }
+
 static void *pool_thread(void *arg)
 {
 	const int id   = (int) (intptr_t) arg;
@@ -950,6 +964,7 @@ uint64_t vkvo_render(const VkvRenderParams *P, int n_threads, uint32_t pixel_str
 		render_items(&job);
 		return job.rays;
 	}
+	pthread_once(&g_pool_once, pool_init_once);
 	pthread_mutex_lock(&g_pool.job_mutex);
 	pthread_mutex_lock(&g_pool.m);
 	while (g_pool.n_threads < n_threads - 1)
