@@ -488,7 +488,7 @@ def test_render_depth_attachment_and_blending(ctx, shell_scene, skipping_type, b
 # ------------------------------------------------------------------------------------------------------
 # randomised configurations: every knob of the path drawn at random, HIP vs oracle
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("seed", range(36))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "36"))))  # a soak run sets more (profiles/r4_fuzz_soak.txt)
 def test_render_fuzz(ctx, seed):
     """Random volume shape / content, voxel size and rotation, TF window, sampling and alpha factors, block size, skipping mode, ERT,
     gradient variant, clip distance, camera (sometimes inside the box) and frame size: counters bit-exact, colour and depth within the
