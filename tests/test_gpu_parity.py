@@ -220,6 +220,37 @@ def test_distance_map_anisotropic_parity(ctx, shape_dhw, p):
             assert np.array_equal(got, T.brute_force_chebyshev_octant(occ, k)), "octant %d vs brute force" % k
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "16"))))
+def test_distance_transform_fuzz(ctx, seed):
+    """Random map extents across every launch configuration of the transforms (line groups of 16 / 8 / 4, whole lines up to 512 cells, chunked
+    longer ones, rows beyond 1024 cells, odd widths and unaligned rows), random density, sometimes arbitrary bytes: both transforms against
+    the oracle, every cell."""
+    rng = np.random.default_rng(7000 + seed)
+    edges = [1, 2, 3, 7, 16, 17, 61, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 700, 1023, 1024, 1025, 1400]
+    while True:
+        dims = [int(rng.choice(edges)) if rng.random() < 0.5 else int(rng.integers(1, 200)) for _ in range(3)]
+        if dims[0] * dims[1] * dims[2] <= 1500000:
+            break
+    shape_dhw = tuple(dims)
+    cells = dims[0] * dims[1] * dims[2]
+    p = float(min(1.0, rng.choice([0.0, 1.0, 3.0, 30.0, 3000.0]) / cells + rng.choice([0.0, 0.0, 0.001, 0.05])))
+    occ = np.where(rng.random(shape_dhw) < p, 0, 255).astype(np.uint8)
+    if rng.random() < 0.25:        # any byte input is defined (test_distance_transforms_on_arbitrary_bytes)
+        raw = rng.integers(0, 256, size=shape_dhw, dtype=np.uint8)
+        occ = np.where(rng.random(shape_dhw) < 0.3, raw, occ).astype(np.uint8)
+    d, h, w = shape_dhw
+    st = torch.cuda.current_stream().cuda_stream
+    d_map, d_swap = dev(occ), torch.empty(shape_dhw, dtype=torch.uint8, device="cuda")
+    ctx.distance_map(d_map.data_ptr(), d_swap.data_ptr(), abi.Extent3D(w, h, d), st)
+    assert np.array_equal(d_map.cpu().numpy(), O.distance_map(occ)), "isotropic, shape %s" % (shape_dhw,)
+    maps = [torch.empty(shape_dhw, dtype=torch.uint8, device="cuda") for _ in range(8)]
+    maps[7].copy_(dev(occ))
+    ctx.distance_map_anisotropic([m.data_ptr() for m in maps], d_swap.data_ptr(), abi.Extent3D(w, h, d), st)
+    expect = O.distance_map_anisotropic(occ)
+    for k in range(8):
+        assert np.array_equal(maps[k].cpu().numpy(), expect[k]), "octant %d, shape %s" % (k, shape_dhw)
+
+
 @pytest.mark.parametrize("skipping_type", [abi.SKIP_NONE, abi.SKIP_BLOCK, abi.SKIP_DISTANCE, abi.SKIP_ANISOTROPIC_DISTANCE])
 def test_compute_distance_map_chain(ctx, skipping_type):
     """ComputeDistanceMap::compute end to end (occupancy -> transform) on a synthetic shell volume."""
