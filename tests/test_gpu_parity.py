@@ -148,6 +148,40 @@ def test_occupancy_map_parity(ctx, shape, block, variant):
     assert np.array_equal(d_map.cpu().numpy(), expect)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "16"))))
+def test_gradient_and_occupancy_fuzz(ctx, seed):
+    """Random volume extents (widths around the dword / 64-voxel tile / 1024-voxel row boundaries of the kernels), content, transfer function
+    window, gradient variant and block size: the gradient map and the occupancy map, every byte against the oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    edges = [1, 2, 3, 4, 5, 8, 9, 63, 64, 65, 68, 127, 128, 132, 255, 256, 260, 1024, 1028, 2052]
+    while True:
+        shape = tuple(int(rng.choice(edges)) if rng.random() < 0.4 else int(rng.integers(1, 150)) for _ in range(3))  # w, h, d
+        if shape[0] * shape[1] * shape[2] <= 1200000:
+            break
+    kind = int(rng.integers(0, 3))
+    vol = T.random_volume(shape, seed=seed, sparsity=float(rng.uniform(0.5, 0.999))) if kind == 2 else O.synth_volume(shape, kind, int(rng.integers(1, 1 << 30)))
+    variant = ("precomputed", "on_the_fly", "no_gradient")[int(rng.integers(0, 3))]
+    imin = float(rng.uniform(0.0, 0.5))
+    tfo = dict(intensity_min=imin, intensity_max=float(rng.uniform(imin + 0.02, 1.0)))
+    if variant == "no_gradient":
+        opt = abi.VolumeOptions(gradient_min=0.0, gradient_max=0.0, **tfo)
+    else:
+        gmin = float(rng.uniform(0.0, 0.2))
+        opt = abi.VolumeOptions(gradient_min=gmin, gradient_max=float(rng.uniform(gmin + 0.02, 0.8)), use_precomputed_gradient=(variant == "precomputed"), **tfo)
+    block = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 6, 7, 8, 9, 33]))
+    scene = T.OracleScene(vol, opt, block)
+    v, tf = make_gpu_volume(ctx, scene)
+    what = "shape %s block %d %s" % (shape, block, variant)
+    if opt.use_precomputed_gradient:
+        assert np.array_equal(v.gradient.cpu().numpy(), scene.grad), "gradient map, " + what
+    expect = O.occupancy_map(scene.vol, scene.grad, scene.tex, scene.tf, block)
+    d_map = torch.empty(expect.shape, dtype=torch.uint8, device="cuda")
+    grad = v.gradient if opt.use_precomputed_gradient else None
+    ctx.occupancy_map(v.volume.data_ptr(), None if grad is None else grad.data_ptr(), v.transfer_function.data_ptr(), tf,
+                      v.extent, d_map.data_ptr(), v.map_extent, torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(d_map.cpu().numpy(), expect), "occupancy map, " + what
+
+
 def sparse_occupancy(shape_dhw, seed, p):
     rng = np.random.default_rng(seed)
     return np.where(rng.random(shape_dhw) < p, 0, 255).astype(np.uint8)
