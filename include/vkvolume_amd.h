@@ -330,9 +330,11 @@ int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_transfer_function,
  * plain tile order / address arithmetic in registers, same bits) - vkv_prepare_render only moves that work to set-up time.  Call it
  * before capturing `stream` into a hipGraph: a launch that still has to create a table records and queries an event, which a capture
  * does not allow.  Captured launches replay with the parameter blocks they were captured with (camera included: capture one graph per
- * view, or re-capture); a captured vkv_render_batch keeps its argument blocks in one of 32 pinned slots of the context until vkv_destroy,
- * because the graph's copy node reads its source at every replay (the 33rd captured batch launch of a context is refused).  The graph
- * must be destroyed before the context. */
+ * view, or re-capture); a captured vkv_render_batch keeps its argument blocks in pinned host memory of the context, because the graph's
+ * copy node reads its source at every replay: the first 32 captured batch launches use slots set aside by vkv_create (nothing is allocated
+ * during the capture), later ones a pinned block each (<= 96 KiB, allocated during the capture with the thread's capture mode relaxed for
+ * that call).  vkv_trim and vkv_destroy free these blocks and the tables the captured launches point to: graphs captured before either
+ * call must not be launched after it. */
 int vkv_prepare_render(vkv_ctx *ctx, const VkvRenderParams *params, uint32_t count, void *stream);
 
 /* Start-order feedback needs device state per render target (one uint32 cost and one uint32 order entry per tile of the
@@ -350,7 +352,8 @@ int vkv_forget_target(vkv_ctx *ctx, const void *d_target);
 /* Set-up call: waits for the device, then drops every cached table (tile start orders, address tables) and empties the arena's table
  * region; the next launches create what they need again (asynchronously, as on first use).  For a renderer whose window or volume sizes
  * keep changing: call it at a quiet point (a resize, a scene change) - like vkv_forget_target it must not run concurrently with a launch
- * from another thread.  Stream scratch blocks and registered targets are not touched. */
+ * from another thread.  Stream scratch blocks and registered targets are not touched.  Also returns the pinned argument blocks of launches
+ * captured into hipGraphs (vkv_prepare_render): a graph captured before the call points to tables and blocks that are gone - re-capture. */
 int vkv_trim(vkv_ctx *ctx);
 
 /* Gives the 128 KiB scratch block vkv_render_batch / vkv_compute_distance_map / ... keep per HIP stream back to the context's pool.

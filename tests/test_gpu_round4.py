@@ -101,12 +101,15 @@ def test_table_region_fills_up_falls_back_and_trims(ctx):
     draw(small)
     torch.cuda.synchronize()
     assert np.array_equal(rgba8.view(-1)[:small[0] * small[1] * 4].view(small[1], small[0], 4).cpu().numpy(), ref.rgba8)
+    s2 = torch.cuda.Stream()  # created AND used before the reading below: a stream's first work makes the RUNTIME allocate its queue
+    with torch.cuda.stream(s2):
+        rgba8[:1].fill_(0)
+    torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
     for i in range(300):  # 300 x 32 KiB > the region: the later ones run without a start-order table
         draw((big[0], big[1] + i))
     torch.cuda.synchronize()
     # a stream the context has never seen still gets a scratch block and renders a batch
-    s2 = torch.cuda.Stream()
     q = draw(small, s2.cuda_stream)
     ctx.render_batch([q, q], s2.cuda_stream)
     torch.cuda.synchronize()
@@ -226,3 +229,57 @@ def test_render_launches_captured_into_a_hip_graph_replay_the_same_frames(ctx):
         churn = [c[::-1].copy() for c in churn]
     del graphs
     ctx.release_stream(s.cuda_stream)
+
+
+def test_more_captured_batch_launches_than_pinned_slots_and_trim(ctx):
+    """A renderer that re-captures when the camera moves: 40 vkv_render_batch launches captured by one context (vkv_create sets 32 pinned
+    slots aside; the later ones allocate their block during the capture), every graph replays its own frames; vkv_trim gives the blocks
+    back and a capture after it works again."""
+    opt = abi.VolumeOptions(**T.APP_TF)
+    scene = T.OracleScene(O.synth_volume((64, 56, 48), 1, 0x5EED0009), opt, 4)
+    v, tf = make_gpu_volume(ctx, scene)
+    V.ComputeDistanceMap(ctx).compute(v, tf, abi.SKIP_DISTANCE)
+    size = (160, 96)
+    ro = abi.RenderOptions(skipping_type=abi.SKIP_DISTANCE, clip_distance=1.0)
+    sp = V.VolumeRenderSubpass(ctx, v, ro, size)
+    bufs = [torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    s = torch.cuda.Stream()
+
+    def pair(k):
+        out = []
+        for j in range(2):
+            view, proj = T.orbit(9.0 * k + 4.0 * j, image_size=size)
+            p = sp.bind(scene.params(view, proj, size, ro))
+            p.d_out_rgba8, p.d_out_color, p.d_out_counts, p.d_out_depth = bufs[j].data_ptr(), None, None, None
+            out.append(p)
+        return out
+
+    def capture(plist):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            ctx.render_batch(plist, torch.cuda.current_stream().cuda_stream)
+        return g
+
+    def check(g, plist, what):
+        for b in bufs:
+            b.fill_(7)
+        g.replay()
+        torch.cuda.synchronize()
+        for j in range(2):
+            ref = scene.render(plist[j], want_rgba8=True)
+            assert np.array_equal(bufs[j].cpu().numpy(), ref.rgba8), what
+
+    ctx.prepare_render(pair(0), s.cuda_stream)
+    torch.cuda.synchronize()
+    graphs = [(capture(pl), pl) for pl in (pair(k) for k in range(40))]
+    torch.cuda.synchronize()
+    for k in (0, 31, 32, 39):
+        check(graphs[k][0], graphs[k][1], "captured launch %d" % k)
+    del graphs
+    ctx.trim()
+    ctx.prepare_render(pair(41), s.cuda_stream)
+    torch.cuda.synchronize()
+    pl = pair(41)
+    check(capture(pl), pl, "capture after vkv_trim")
+    ctx.release_stream(s.cuda_stream)
+

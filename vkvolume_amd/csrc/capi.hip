@@ -367,6 +367,15 @@ static void drop_tables(vkv_ctx *ctx)
 	ctx->table_used = 0;
 }
 
+// the pinned argument blocks of captured vkv_render_batch launches: the graphs that read them are the caller's, who promised not to replay them
+static void drop_capture_blocks(vkv_ctx *ctx)
+{
+	for (void *p : ctx->capture_overflow)
+		(void) hipHostFree(p);
+	ctx->capture_overflow.clear();
+	ctx->capture_slots_used = 0;
+}
+
 int vkv_trim(vkv_ctx *ctx)
 {
 	if (!ctx)
@@ -377,6 +386,7 @@ int vkv_trim(vkv_ctx *ctx)
 		return set_error(ctx, (int) e, "trim: %s", hipGetErrorString(e));
 	std::lock_guard<std::mutex> lock(ctx->mutex);
 	drop_tables(ctx);
+	drop_capture_blocks(ctx);
 	return VKV_OK;
 }
 
@@ -441,6 +451,7 @@ void vkv_destroy(vkv_ctx *ctx)
 		}
 		for (void *p : ctx->overflow_scratch)
 			(void) hipFree(p);
+		drop_capture_blocks(ctx);
 		if (ctx->capture_pool)
 			(void) hipHostFree(ctx->capture_pool);
 		if (ctx->table_mirror)
@@ -999,6 +1010,7 @@ int vkv_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, uint3
 }
 
 // ---- RCCL, resolved at run time (the library is not a link-time dependency of the product) ---------------------------------
+extern "C++" {
 namespace
 {
 typedef int (*nccl_gather_fn)(const void *, void *, size_t, int /* ncclDataType_t */, int, void * /* ncclComm_t */, hipStream_t);
@@ -1050,6 +1062,7 @@ const Rccl &rccl()
 	return g_rccl;
 }
 }        // namespace
+}        // extern "C++"
 
 int vkv_gather_tiles(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, size_t bytes_per_rank, int32_t root, void *nccl_comm, void *stream)
 {

@@ -418,15 +418,27 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	std::memcpy(upload.data() + kPullHeadsBytes, host.data(), n * sizeof(RayMarchArgs));
 	const void *upload_src = upload.data();
 	{        // A stream that is being captured into a hipGraph records the copy's SOURCE POINTER and reads it at every replay: the block then has to
-		 // outlive the call - a pinned slot the context keeps until vkv_destroy
+		 // outlive the call - a pinned slot the context keeps until vkv_trim / vkv_destroy
 		hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
 		if (hipStreamIsCapturing(s, &capture) == hipSuccess && capture == hipStreamCaptureStatusActive)
 		{
-			// (no allocation inside a capture: it would invalidate it.  vkv_create set kCaptureSlots pinned slots aside; a slot is never re-used)
+			// vkv_create set kCaptureSlots pinned slots aside, so that the usual capture allocates nothing.  Beyond them: a pinned block of its
+			// own, allocated with this thread's capture mode relaxed for the one call (an allocation under the global / thread-local mode
+			// would invalidate the capture).  vkv_trim and vkv_destroy give all of them back.
 			std::lock_guard<std::mutex> lock(ctx->mutex);
-			if (!ctx->capture_pool || ctx->capture_slots_used >= kCaptureSlots)
-				return set_error(ctx, VKV_E_UNSUPPORTED, "render_batch: more than %u vkv_render_batch launches captured into hipGraphs by this context", kCaptureSlots);
-			void *pinned = ctx->capture_pool + (size_t) ctx->capture_slots_used++ * kCaptureSlotBytes;
+			void *                      pinned = nullptr;
+			if (ctx->capture_pool && ctx->capture_slots_used < kCaptureSlots)
+				pinned = ctx->capture_pool + (size_t) ctx->capture_slots_used++ * kCaptureSlotBytes;
+			else
+			{
+				hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+				(void) hipThreadExchangeStreamCaptureMode(&mode);
+				const hipError_t ea = hipHostMalloc(&pinned, upload.size(), hipHostMallocDefault);
+				(void) hipThreadExchangeStreamCaptureMode(&mode);
+				if (ea != hipSuccess || !pinned)
+					return set_error(ctx, VKV_E_UNSUPPORTED, "render_batch: no pinned block for the argument upload of a captured launch: %s", hipGetErrorString(ea));
+				ctx->capture_overflow.push_back(pinned);
+			}
 			std::memcpy(pinned, upload.data(), upload.size());
 			upload_src = pinned;
 		}

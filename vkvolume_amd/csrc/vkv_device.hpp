@@ -183,7 +183,8 @@ struct vkv_ctx
 	std::vector<void *> overflow;                // hipMalloc blocks set-up calls took for tables when the region was full; freed by vkv_trim / vkv_destroy
 	std::vector<void *> overflow_scratch;        // ... for scratch blocks beyond the reserve; freed by vkv_destroy
 	uint8_t *           capture_pool = nullptr;  // pinned slots for the argument blocks of vkv_render_batch launches captured into hipGraphs (the graph's
-	uint32_t            capture_slots_used = 0;  // copy node reads its source at every replay); a slot is never re-used; freed by vkv_destroy
+	uint32_t            capture_slots_used = 0;  // copy node reads its source at every replay); handed out in turn, all returned by vkv_trim / vkv_destroy
+	std::vector<void *> capture_overflow;        // pinned blocks of captured launches beyond kCaptureSlots (allocated during the capture); same lifetime
 	std::unordered_map<hipStream_t, uint8_t *> scratch;        // stream -> kScratchBytes of device memory
 	std::vector<uint8_t *>                     free_scratch;   // blocks given back by vkv_release_stream
 	// an immutable device table with its host copy (the source of the asynchronous upload: it must outlive the call)
