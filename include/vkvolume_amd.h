@@ -325,7 +325,9 @@ int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_transfer_function,
 /* VolumeRenderSubpass::prepare, src/volume_render_subpass.cpp:95-157 (where the reference builds its pipelines and descriptor layouts).
  * Set-up call: creates, for `count` parameter blocks as a later vkv_render / vkv_render_batch on `stream` will pass them, everything that
  * launch takes from the context: the stream's scratch block, the address tables of the packed image's extent, the tile start order of the
- * schedule; uploads are waited for before it returns.  A launch that finds one of them missing still creates it on the fly out of the
+ * schedule - and from the HIP runtime: the code objects of the kernels those blocks select are loaded onto the device now (the runtime
+ * loads a code object at the first use of one of its kernels, which allocates device memory and takes milliseconds); uploads are
+ * waited for before it returns.  A launch that finds one of them missing still creates it on the fly out of the
  * arena with an asynchronous upload on its own stream (no device-wide wait; if the arena is exhausted the launch runs without the table:
  * plain tile order / address arithmetic in registers, same bits) - vkv_prepare_render only moves that work to set-up time.  Call it
  * before capturing `stream` into a hipGraph: a launch that still has to create a table records and queries an event, which a capture

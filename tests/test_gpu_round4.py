@@ -1,4 +1,6 @@
 """Round 4 GPU tests (through the C ABI)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -9,6 +11,7 @@ from tests.test_gpu_parity import gpu_render, make_gpu_volume
 from vkvolume_amd import abi, volume as V
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("skipping_type", [abi.SKIP_BLOCK, abi.SKIP_DISTANCE, abi.SKIP_ANISOTROPIC_DISTANCE])
@@ -283,3 +286,54 @@ def test_more_captured_batch_launches_than_pinned_slots_and_trim(ctx):
     check(capture(pl), pl, "capture after vkv_trim")
     ctx.release_stream(s.cuda_stream)
 
+
+
+def test_first_launches_of_a_process_after_set_up_take_no_device_memory():
+    """The runtime loads a translation unit's code object (device memory, milliseconds) at the first use of one of its kernels.
+    vkv_prepare_render and vkv_register_target do that for the kernels the parameter blocks will launch, so the very first vkv_render /
+    vkv_render_batch of a PROCESS neither allocates nor stalls on a load: checked in a fresh interpreter (in this one the kernels are
+    long loaded) with hipMemGetInfo around the launches."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import vkv_oracle as O
+from tests import helpers as T
+from vkvolume_amd import abi, lib, volume as V
+c = lib.Context(0)
+scene = T.OracleScene(O.synth_volume((64, 56, 48), 1, 77), abi.VolumeOptions(**T.APP_TF), 4)
+v = V.Volume(c); v.options = scene.options
+v.load_from_array(scene.vol, scene.block, scene.image_transform); v.node_transform = scene.node_transform
+tf = v.get_transfer_function_uniform()
+V.ComputeGradientMap(c).compute(v, tf); v.update_transfer_function_texture()
+V.ComputeDistanceMap(c).compute(v, tf, abi.SKIP_ANISOTROPIC_DISTANCE)
+size = (208, 112)
+ro = abi.RenderOptions(skipping_type=abi.SKIP_ANISOTROPIC_DISTANCE, clip_distance=1.0)
+sp = V.VolumeRenderSubpass(c, v, ro, size)
+s = torch.cuda.Stream()
+targets = [torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+with torch.cuda.stream(s):
+    targets[0][:1].fill_(0)  # the stream's queue exists
+plist = []
+for j, az in enumerate((10.0, 70.0)):
+    p = sp.make_params(*T.orbit(az, image_size=size))
+    p.d_out_rgba8, p.d_out_color, p.d_out_counts, p.d_out_depth = targets[j].data_ptr(), None, None, None
+    plist.append(p)
+c.prepare_render(plist, s.cuda_stream)
+for t in targets:
+    c.register_target(t.data_ptr(), size, plist[0].tiles)
+torch.cuda.synchronize()
+free0 = torch.cuda.mem_get_info()[0]
+c.render(plist[0], s.cuda_stream)
+c.render_batch(plist, s.cuda_stream)
+c.render_batch(plist, s.cuda_stream)
+torch.cuda.synchronize()
+free1 = torch.cuda.mem_get_info()[0]
+ref = scene.render(plist[1], want_rgba8=True)
+assert np.array_equal(targets[1].cpu().numpy(), ref.rgba8)
+print("device memory taken by the first launches:", free0 - free1)
+assert free1 >= free0
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]

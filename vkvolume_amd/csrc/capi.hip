@@ -30,6 +30,7 @@ int launch_synth_volume(vkv_ctx *, uint8_t *, VkvExtent3D, uint32_t, uint32_t, h
 int launch_scatter_tiles(vkv_ctx *, const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 int launch_scatter_tiles_frames(vkv_ctx *, const void *, void *const *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
 int prepare_render(vkv_ctx *, const VkvRenderParams *, uint32_t, hipStream_t);
+void load_feedback_code();
 int launch_render(vkv_ctx *, const VkvRenderParams *, const float *, hipStream_t);
 int launch_render_batch(vkv_ctx *, const VkvRenderParams *, uint32_t, const float *, hipStream_t);
 int launch_pack_volume(vkv_ctx *, const uint8_t *, const uint8_t *, VkvExtent3D, void *, hipStream_t);
@@ -540,6 +541,7 @@ int vkv_register_target(vkv_ctx *ctx, const void *d_target, uint32_t image_width
 		(void) hipFree(order);
 		return set_error(ctx, e != hipSuccess ? (int) e : VKV_E_UNSUPPORTED, "register_target: %s", e != hipSuccess ? hipGetErrorString(e) : "out of memory");
 	}
+	load_feedback_code();        // the sort kernels' code object on this device now, not inside the first launch into the target
 	std::lock_guard<std::mutex> lock(ctx->mutex);
 	f->period = ctx->tuning.feedback_period;
 	ctx->feedback.push_back(f);

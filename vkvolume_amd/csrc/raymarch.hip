@@ -131,6 +131,25 @@ static int launch_single(vkv_ctx *ctx, int skip, bool ert, int sched, const VkvT
 	}
 }
 
+static void load_render_code(int skip, bool ert)
+{
+	switch (skip)
+	{
+		case VKV_SKIP_NONE: ert ? RayMarchLaunchers<VKV_SKIP_NONE, true>::load() : RayMarchLaunchers<VKV_SKIP_NONE, false>::load(); break;
+		case VKV_SKIP_BLOCK: ert ? RayMarchLaunchers<VKV_SKIP_BLOCK, true>::load() : RayMarchLaunchers<VKV_SKIP_BLOCK, false>::load(); break;
+		case VKV_SKIP_DISTANCE: ert ? RayMarchLaunchers<VKV_SKIP_DISTANCE, true>::load() : RayMarchLaunchers<VKV_SKIP_DISTANCE, false>::load(); break;
+		case VKV_SKIP_ANISOTROPIC_DISTANCE: ert ? RayMarchLaunchers<VKV_SKIP_ANISOTROPIC_DISTANCE, true>::load() : RayMarchLaunchers<VKV_SKIP_ANISOTROPIC_DISTANCE, false>::load(); break;
+		default: break;
+	}
+}
+
+// the start-order kernels of this file (vkv_register_target: the first launch into a registered target would load them otherwise)
+void load_feedback_code()
+{
+	hipFuncAttributes at;
+	(void) hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_tile_order_from_cost));
+}
+
 static bool launch_batch(int skip, bool ert, int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, LeanChoice c, bool no_counts, hipStream_t s)
 {
 	switch (skip)
@@ -374,7 +393,9 @@ int prepare_render(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, hipStream
 		const int    rc = fill_render_args(ctx, &P[i], lut, a, s, T, true);
 		if (rc != VKV_OK)
 			return rc;
+		load_render_code(P[i].options.skipping_type, P[i].options.early_ray_termination != 0);
 	}
+	load_feedback_code();
 	if (!stream_scratch(ctx, s, true))
 		return VKV_E_UNSUPPORTED;
 	return VKV_OK;

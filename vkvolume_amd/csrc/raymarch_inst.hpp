@@ -44,6 +44,9 @@ struct RayMarchLaunchers
 	static void batch(int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t grid, uint32_t gpf, LeanChoice c, bool no_counts, hipStream_t s);
 	// the same with resident workgroups whose waves pull their units; returns the grid size
 	static uint32_t pull(vkv_ctx *ctx, int grad, const RayMarchArgs *d_frames, uint32_t n, uint32_t *d_heads, LeanChoice c, uint64_t units, hipStream_t s);
+	// set-up: the runtime loads a translation unit's code object (device memory, milliseconds) at the first use of one of its kernels - make
+	// that now, on the current device, instead of inside the first launch (vkv_prepare_render)
+	static void load();
 };
 
 #ifdef VKV_RAYMARCH_INSTANTIATE
@@ -110,6 +113,13 @@ int RayMarchLaunchers<SKIP, ERT>::single(vkv_ctx *ctx, int sched, const VkvTunin
 	if (a.packed)
 		return grad == 0 ? launch_one<SKIP, ERT, 0, true>(ctx, sched, T, a, s) : (grad == 1 ? launch_one<SKIP, ERT, 1, true>(ctx, sched, T, a, s) : launch_one<SKIP, ERT, 2, true>(ctx, sched, T, a, s));
 	return grad == 0 ? launch_one<SKIP, ERT, 0, false>(ctx, sched, T, a, s) : (grad == 1 ? launch_one<SKIP, ERT, 1, false>(ctx, sched, T, a, s) : launch_one<SKIP, ERT, 2, false>(ctx, sched, T, a, s));
+}
+
+template <int SKIP, bool ERT>
+void RayMarchLaunchers<SKIP, ERT>::load()
+{
+	hipFuncAttributes at;        // any kernel of this translation unit: the code object is loaded as a whole
+	(void) hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_raymarch_lean<SKIP, ERT, 0, true, kLfPlain>));
 }
 
 // ---- several frames in one launch --------------------------------------------------------------------------------
