@@ -144,7 +144,8 @@ typedef struct VkvRenderOptions
  * The launch renders tiles tile_first + k*tile_stride, k = 0 .. tile_count-1.
  * compact == 0: outputs are indexed by image pixel  (y*image_width + x);
  * compact != 0: outputs are indexed by (k*tile_height + ly)*tile_width + lx  (the per-rank
- *               buffer that is gathered over RCCL and de-interleaved by vkv_scatter_tiles). */
+ *               buffer that is gathered over RCCL and de-interleaved by vkv_scatter_tiles); the
+ *               slots of a partial tile's pixels beyond the image edge are never written. */
 typedef struct VkvTileSchedule
 {
 	uint32_t tile_width, tile_height; /* multiples of 16 (one 256-thread workgroup marches 16x16 pixels) */

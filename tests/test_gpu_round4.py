@@ -337,3 +337,59 @@ assert free1 >= free0
 ''' % ROOT
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "12"))))
+def test_tile_schedule_fuzz(ctx, seed):
+    """The multi-GPU decomposition with one GPU playing every rank, all knobs random: frame size (ragged against the tiles), tile size
+    (multiples of 16, x and y apart), number of ranks 1..9 (more ranks than tiles included), frames per vkv_render_batch launch 1..4
+    (different views), skipping mode, ERT.  Each rank renders its interleaved compact schedule; the [rank][frame][tiles] blocks are
+    de-interleaved by vkv_scatter_tiles as the owner of the launch does after the gather.  Every assembled frame == the oracle's
+    full-frame RGBA8, and each rank's counters == the oracle's for its schedule."""
+    rng = np.random.default_rng(12000 + seed)
+    shape = tuple(int(x) for x in rng.integers(24, 72, size=3))
+    scene = T.OracleScene(O.synth_volume(shape, int(rng.integers(0, 2)), int(rng.integers(1, 1 << 30))), abi.VolumeOptions(**T.APP_TF), int(rng.integers(2, 6)))
+    v, tf = make_gpu_volume(ctx, scene)
+    st_mode = int(rng.integers(1, 4))
+    V.ComputeDistanceMap(ctx).compute(v, tf, st_mode)
+    tw, th = 16 * int(rng.integers(1, 4)), 16 * int(rng.integers(1, 3))
+    size = (int(rng.integers(17, 200)), int(rng.integers(17, 120)))
+    world, frames = int(rng.integers(1, 10)), int(rng.integers(1, 5))
+    ro = abi.RenderOptions(skipping_type=st_mode, clip_distance=1.0, early_ray_termination=bool(rng.integers(0, 2)))
+    views = [T.orbit(float(rng.uniform(0, 360)), elevation=float(rng.uniform(-60, 60)), image_size=size) for _ in range(frames)]
+    tiles_x, tiles_y = -(-size[0] // tw), -(-size[1] // th)
+    per_rank = -(-(tiles_x * tiles_y) // world)
+    n = per_rank * tw * th
+    st = torch.cuda.current_stream().cuda_stream
+    gathered = torch.full((world, frames, n, 4), 0x5A, dtype=torch.uint8, device="cuda")        # as the launch's owner receives it
+    what = "seed %d: frame %s tiles %dx%d world %d frames %d mode %d" % (seed, size, tw, th, world, frames, st_mode)
+    for r in range(world):
+        sched = abi.full_frame_tiles(size[0], size[1], tw, th, r, world, compact=True)
+        if sched.tile_count == 0:
+            continue        # more ranks than tiles: this one has nothing to render (bench.py's ranks pass such schedules too)
+        plist, counts = [], []
+        for f, (view, proj) in enumerate(views):
+            p = T_bind(ctx, v, scene, view, proj, size, ro, sched)
+            c = torch.zeros((sched.tile_count * tw * th, 3), dtype=torch.int32, device="cuda")  # (slots beyond the image edge stay unwritten)
+            p.d_out_rgba8, p.d_out_color, p.d_out_counts, p.d_out_depth = gathered[r, f].data_ptr(), None, c.data_ptr(), None
+            plist.append(p)
+            counts.append(c)
+        if frames == 1:
+            ctx.render(plist[0], st)
+        else:
+            ctx.render_batch(plist, st)
+        torch.cuda.synchronize()
+        for f, (view, proj) in enumerate(views):
+            ref = scene.render(scene.params(view, proj, size, ro, tiles=sched))
+            assert np.array_equal(counts[f].cpu().numpy().astype(np.uint32).reshape(ref.counts.shape), ref.counts), what + ", rank %d frame %d counters" % (r, f)
+    for f, (view, proj) in enumerate(views):
+        image = torch.full((size[1], size[0], 4), 3, dtype=torch.uint8, device="cuda")
+        ctx.scatter_tiles(gathered.data_ptr() + f * n * 4, image.data_ptr(), size, (tw, th), world, frames * per_rank, 4, st)
+        torch.cuda.synchronize()
+        full = scene.render(scene.params(view, proj, size, ro, tiles=abi.full_frame_tiles(size[0], size[1], tw, th)), want_rgba8=True)
+        assert np.array_equal(image.cpu().numpy(), full.rgba8), what + ", assembled frame %d" % f
+
+
+def T_bind(ctx, v, scene, view, proj, size, ro, sched):
+    sp = V.VolumeRenderSubpass(ctx, v, ro, size)
+    return sp.bind(scene.params(view, proj, size, ro, tiles=sched))
