@@ -553,11 +553,11 @@ def test_render_depth_attachment_and_blending(ctx, shell_scene, skipping_type, b
 # ------------------------------------------------------------------------------------------------------
 # randomised configurations: every knob of the path drawn at random, HIP vs oracle
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "36"))))  # a soak run sets more (profiles/r4_fuzz_soak.txt)
-def test_render_fuzz(ctx, seed):
-    """Random volume shape / content, voxel size and rotation, TF window, sampling and alpha factors, block size, skipping mode, ERT,
-    gradient variant, clip distance, camera (sometimes inside the box) and frame size: counters bit-exact, colour and depth within the
-    stated tolerance (observed 0), and all four {sampling layout} x {scheduler} variants identical (gpu_render)."""
+def fuzz_case(ctx, seed):
+    """One random configuration of the ray-march path (test_render_fuzz, tests/test_gpu_round4.py::test_launch_variants_fuzz): volume shape /
+    content, voxel size and rotation, TF window, sampling and alpha factors, block size, skipping mode, ERT, gradient variant, clip distance,
+    camera (sometimes inside the box, for seeds >= 24 beside it) and frame size.  Returns the oracle scene, the device volume, the parameter
+    block, the oracle's frame and a label."""
     rng = np.random.default_rng(1000 + seed)
     shape = tuple(int(x) for x in rng.integers(5, 46, size=3))  # w, h, d
     kind = int(rng.integers(0, 3))
@@ -594,7 +594,14 @@ def test_render_fuzz(ctx, seed):
     opts = abi.RenderOptions(skipping_type=st, clip_distance=float(rng.choice([0.1, 1.0, 1.0, 20.0, 70.0])), early_ray_termination=bool(rng.integers(0, 2)))
     params = scene.params(view, proj, size, opts)
     ref = scene.render(params)
-    compare_render(gpu_render(ctx, v, params), ref, "fuzz %d: shape %s block %d mode %d %s" % (seed, shape, block, st, grad_variant))
-    print("fuzz %d: shape %s block %d mode %d %s ert %d: %d samples, %d probes, %d pixels with colour" % (
-        seed, shape, block, st, grad_variant, opts.early_ray_termination, int(ref.counts[..., 0].sum()), int(ref.counts[..., 1].sum()),
-        int((ref.color[..., 3] > 0).sum())))
+    label = "fuzz %d: shape %s block %d mode %d %s ert %d" % (seed, shape, block, st, grad_variant, opts.early_ray_termination)
+    return scene, v, params, ref, label
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "36"))))  # a soak run sets more (profiles/r4_fuzz_soak.txt)
+def test_render_fuzz(ctx, seed):
+    """Random configurations (fuzz_case): counters bit-exact, colour and depth within the stated tolerance (observed 0), and all four
+    {sampling layout} x {scheduler} variants identical (gpu_render)."""
+    scene, v, params, ref, label = fuzz_case(ctx, seed)
+    compare_render(gpu_render(ctx, v, params), ref, label)
+    print("%s: %d samples, %d probes, %d pixels with colour" % (label, int(ref.counts[..., 0].sum()), int(ref.counts[..., 1].sum()), int((ref.color[..., 3] > 0).sum())))

@@ -393,3 +393,56 @@ def test_tile_schedule_fuzz(ctx, seed):
 def T_bind(ctx, v, scene, view, proj, size, ro, sched):
     sp = V.VolumeRenderSubpass(ctx, v, ro, size)
     return sp.bind(scene.params(view, proj, size, ro, tiles=sched))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "24"))))
+def test_launch_variants_fuzz(ctx, seed):
+    """The kernels a renderer actually launches, on the random configurations of test_render_fuzz: for every address-table kind
+    (VkvTuning.address_tables 2 = per-voxel tables, 1 = two-level tables, 0 = address arithmetic in registers) a counted single launch
+    (three counters == the oracle, colour / depth within tolerance), then the launches WITHOUT a counter buffer - the loop without the
+    per-pixel counters where that instantiation exists (ESS + ERT + precomputed gradient), the counted loop elsewhere - as vkv_render and
+    as a vkv_render_batch of three frames (the frame between two copies of a second view): float colour, RGBA8 and depth must be the
+    counted launch's bits."""
+    from tests.test_gpu_parity import COLOR_TOL, DEPTH_TOL, fuzz_case
+    scene, v, params, ref, label = fuzz_case(ctx, 5000 + seed)
+    size = (params.image_width, params.image_height)
+    sp = V.VolumeRenderSubpass(ctx, v, params.options, size)
+    st = torch.cuda.current_stream().cuda_stream
+    other = abi.RenderParams.from_buffer_copy(params)        # a second view for the batch: the same camera mirrored in x (ddx negated)
+    for i in range(3):
+        other.ray_gen.dir00[i] = params.ray_gen.dir00[i] + (size[0] - 1) * params.ray_gen.ddx[i]
+        other.ray_gen.ddx[i] = -params.ray_gen.ddx[i]
+
+    def outputs():
+        return (torch.full((size[1], size[0], 4), -1.0, dtype=torch.float32, device="cuda"), torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda"),
+                torch.full((size[1], size[0]), -1.0, dtype=torch.float32, device="cuda"))
+
+    try:
+        for tables in (2, 1, 0):
+            ctx.set_tuning(address_tables=tables)
+            what = "%s, address_tables %d" % (label, tables)
+            p = sp.bind(params)
+            col, rgba, dep = outputs()
+            cnt = torch.full((size[1], size[0], 3), 0xFFFF, dtype=torch.int32, device="cuda")
+            sp.draw(p, col, rgba, cnt, dep)
+            torch.cuda.synchronize()
+            assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), ref.counts), what + ": counters"
+            assert float(np.abs(col.cpu().numpy() - ref.color).max()) <= COLOR_TOL and float(np.abs(dep.cpu().numpy() - ref.depth).max()) <= DEPTH_TOL, what
+            col2, rgba2, dep2 = outputs()
+            sp.draw(sp.bind(params), col2, rgba2, None, dep2)        # no counter buffer
+            torch.cuda.synchronize()
+            assert torch.equal(col2, col) and torch.equal(rgba2, rgba) and torch.equal(dep2, dep), what + ": launch without counters"
+            plist, outs = [], []
+            for q in (other, params, other):
+                b = sp.bind(q)
+                o = outputs()
+                b.d_out_color, b.d_out_rgba8, b.d_out_depth, b.d_out_counts = o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), None
+                b.d_in_depth, b.blend_over_target = None, 0
+                plist.append(b)
+                outs.append(o)
+            ctx.render_batch(plist, st)
+            torch.cuda.synchronize()
+            assert torch.equal(outs[1][0], col) and torch.equal(outs[1][1], rgba) and torch.equal(outs[1][2], dep), what + ": batch launch without counters"
+            assert torch.equal(outs[0][1], outs[2][1]) and torch.equal(outs[0][0], outs[2][0]), what + ": the two copies of the second view differ"
+    finally:
+        ctx.set_tuning(address_tables=2)
