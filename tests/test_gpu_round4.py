@@ -446,3 +446,43 @@ def test_launch_variants_fuzz(ctx, seed):
             assert torch.equal(outs[0][1], outs[2][1]) and torch.equal(outs[0][0], outs[2][0]), what + ": the two copies of the second view differ"
     finally:
         ctx.set_tuning(address_tables=2)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "16"))))
+def test_depth_attachment_and_blend_fuzz(ctx, seed):
+    """options.depth_attachment (frag:122-165: fragments behind the scene depth are discarded, rays end at it) and the subpass's blend state
+    (volume_render_subpass.cpp:176-190: premultiplied 'over' onto the target's contents) on the random configurations of test_render_fuzz,
+    with a random scene depth buffer (reverse-Z walls of random depth in random columns, 'far' elsewhere) and random target contents:
+    counters, float colour, RGBA8 and depth against the oracle, with and without a counter buffer."""
+    from tests.test_gpu_parity import COLOR_TOL, DEPTH_TOL, dev, fuzz_case
+    scene, v, params, _, label = fuzz_case(ctx, 9000 + seed)
+    rng = np.random.default_rng(77000 + seed)
+    size = (params.image_width, params.image_height)
+    p = abi.RenderParams.from_buffer_copy(params)
+    p.options.depth_attachment = 1
+    in_depth = np.zeros((size[1], size[0]), np.float32)
+    for _ in range(int(rng.integers(1, 4))):
+        x0 = int(rng.integers(0, size[0]))
+        in_depth[:, x0:x0 + int(rng.integers(1, size[0]))] = float(rng.choice([0.1 / 90.0, 0.1 / 110.0, 0.1 / 150.0, 0.5, 1e-6]))
+    blend = bool(rng.integers(0, 2))
+    tgt_color = rng.random((size[1], size[0], 4), dtype=np.float32) if blend else None
+    tgt_rgba8 = rng.integers(0, 256, (size[1], size[0], 4), dtype=np.uint8) if blend else None
+    ref = scene.render(p, in_depth=in_depth, target_color=tgt_color, target_rgba8=tgt_rgba8, want_rgba8=True)
+    sp = V.VolumeRenderSubpass(ctx, v, p.options, size)
+    for with_counts in (True, False):
+        q = sp.bind(p)
+        color = torch.from_numpy(tgt_color).cuda() if blend else torch.full((size[1], size[0], 4), -1.0, dtype=torch.float32, device="cuda")
+        rgba8 = torch.from_numpy(tgt_rgba8).cuda() if blend else torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda")
+        counts = torch.full((size[1], size[0], 3), 77, dtype=torch.int32, device="cuda") if with_counts else None
+        depth = torch.full((size[1], size[0]), -1.0, dtype=torch.float32, device="cuda")
+        sp.draw(q, color, rgba8, counts, depth, in_depth=dev(in_depth), blend=blend)
+        torch.cuda.synchronize()
+        what = "%s, blend %d, counters %d" % (label, blend, with_counts)
+        if with_counts:
+            assert np.array_equal(counts.cpu().numpy().astype(np.uint32), ref.counts), what
+        assert float(np.abs(color.cpu().numpy() - ref.color).max()) <= COLOR_TOL, what
+        assert np.array_equal(rgba8.cpu().numpy(), ref.rgba8), what
+        got = depth.cpu().numpy()
+        frag = got != -1.0
+        if frag.any():
+            assert float(np.abs(got[frag] - ref.depth[frag]).max()) <= DEPTH_TOL, what
