@@ -36,6 +36,35 @@ def test_occupied_voxel_count_parity(ctx, opts, use_map, shape):
     assert int(d_count.item()) == O.occupied_voxel_count(vol, grad, tf)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "16"))))
+def test_device_loader_conversion_fuzz(ctx, tmp_path, seed):
+    """vkv_convert_volume against the oracle's CPU loader (src/load_volume.cpp:112-172) on random files: voxel type, byte order, extent
+    (odd voxel counts: the device path converts several voxels per thread), normalisation range - inside, around and beyond the type's
+    range, sometimes a single value wide."""
+    rng = np.random.default_rng(21000 + seed)
+    ctype, npt = [("uint8_t", "u1"), ("int8_t", "i1"), ("uint16_t", "u2"), ("int16_t", "i2")][int(rng.integers(0, 4))]
+    endian = ("little", "big")[int(rng.integers(0, 2))]
+    w, h, d = (int(x) for x in rng.integers(1, 40, size=3))
+    info = np.iinfo(npt)
+    span = float(info.max) - float(info.min)
+    lo = float(np.round(rng.uniform(info.min - 0.2 * span, info.max), int(rng.integers(0, 3))))
+    hi = lo + float(rng.choice([1.0, 0.25 * span, span, 3.0 * span])) * float(rng.uniform(0.2, 1.0))
+    raw = rng.integers(info.min, info.max + 1, size=(d, h, w)).astype(npt)
+    if rng.random() < 0.3:        # a narrow band of values around the range's ends
+        raw = np.clip(np.round(rng.normal(lo, 2.0, size=(d, h, w))), info.min, info.max).astype(npt)
+    f = tmp_path / "v.raw"
+    file_bytes = raw.astype(("<" if endian == "little" else ">") + npt)
+    file_bytes.tofile(f)
+    (tmp_path / "v.raw.header").write_text("%d %d %d\n1 1 1\n%r %r\n%s %s\n1 0 0 0\n" % (w, h, d, lo, hi, ctype, endian))
+    hdr = O.load_header(str(f) + ".header")
+    expect = O.load_data(str(f), hdr)
+    d_raw = torch.from_numpy(np.frombuffer(file_bytes.tobytes(), np.uint8).copy()).cuda()
+    d_out = torch.full((d, h, w), 7, dtype=torch.uint8, device="cuda")
+    ctx.convert_volume(d_raw.data_ptr(), abi.VOXEL_TYPES[ctype], endian == "big", hdr.normalisation_range[0], hdr.normalisation_range[1], w * h * d,
+                       d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(d_out.cpu().numpy(), expect), "%s %s %dx%dx%d range %r..%r" % (ctype, endian, w, h, d, lo, hi)
+
+
 @pytest.mark.parametrize("ctype,npt", [("uint8_t", "u1"), ("int8_t", "i1"), ("uint16_t", "u2"), ("int16_t", "i2")])
 @pytest.mark.parametrize("endian", ["little", "big"])
 @pytest.mark.parametrize("n_shape", [(33, 21, 17), (64, 16, 4), (1, 1, 1)])

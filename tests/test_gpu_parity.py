@@ -180,6 +180,10 @@ def test_gradient_and_occupancy_fuzz(ctx, seed):
     ctx.occupancy_map(v.volume.data_ptr(), None if grad is None else grad.data_ptr(), v.transfer_function.data_ptr(), tf,
                       v.extent, d_map.data_ptr(), v.map_extent, torch.cuda.current_stream().cuda_stream)
     assert np.array_equal(d_map.cpu().numpy(), expect), "occupancy map, " + what
+    # the occupied-voxel count of the reference's benchmark mode (analytic transfer function, src/compute_occupied_voxel_count.cpp)
+    d_count = torch.full((1,), 12345, dtype=torch.int64, device="cuda")
+    ctx.occupied_voxel_count(v.volume.data_ptr(), None if grad is None else grad.data_ptr(), tf, v.extent, d_count.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert int(d_count.item()) == O.occupied_voxel_count(scene.vol, scene.grad, scene.tf), "occupied voxel count, " + what
 
 
 def sparse_occupancy(shape_dhw, seed, p):
