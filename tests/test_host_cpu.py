@@ -175,6 +175,39 @@ def test_loader_c_abi_matches_oracle_loader(tmp_path):
         lib.load_data(str(tmp_path / "f32.raw"), lib.load_header(str(tmp_path / "f32.raw.header")))  # unsupported type
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "24"))))
+def test_loader_fuzz(tmp_path, seed):
+    """The product's C++ LoadVolume (vkv_load_header / vkv_load_data) against the oracle's C loader on random files: voxel type, byte order,
+    extent, voxel size, normalisation range (inside / around / beyond the type's range), rotation axis and angle, comments or none in the
+    header: header fields equal, image transform within 1e-6 (two float evaluations of the same formula), every data byte equal."""
+    rng = np.random.default_rng(33000 + seed)
+    ctype, npt = [("uint8_t", "u1"), ("int8_t", "i1"), ("uint16_t", "u2"), ("int16_t", "i2")][int(rng.integers(0, 4))]
+    endian = ("little", "big")[int(rng.integers(0, 2))]
+    w, h, d = (int(x) for x in rng.integers(1, 24, size=3))
+    info = np.iinfo(npt)
+    span = float(info.max) - float(info.min)
+    lo = float(np.round(rng.uniform(info.min - 0.2 * span, info.max), int(rng.integers(0, 3))))
+    hi = lo + float(rng.choice([1.0, 0.25 * span, span, 3.0 * span])) * float(rng.uniform(0.2, 1.0))
+    raw = rng.integers(info.min, info.max + 1, size=(d, h, w)).astype(npt)
+    f = tmp_path / "v.raw"
+    raw.astype(("<" if endian == "little" else ">") + npt).tofile(f)
+    vs = [float(np.round(x, 5)) for x in rng.uniform(0.0002, 3.0, size=3)]
+    axis = [float(np.round(x, 3)) for x in rng.normal(size=3)]
+    if all(a == 0.0 for a in axis):
+        axis = [1.0, 0.0, 0.0]
+    angle = float(np.round(rng.uniform(-360, 360), 2))
+    c = (lambda t: " # " + t) if rng.random() < 0.5 else (lambda t: "")
+    (tmp_path / "v.raw.header").write_text("%d %d %d%s\n%r %r %r%s\n%r %r%s\n%s %s%s\n%r %r %r %r%s\n" % (
+        w, h, d, c("extents"), vs[0], vs[1], vs[2], c("voxel size"), lo, hi, c("range"), ctype, endian, c("type"), axis[0], axis[1], axis[2], angle, c("rotation")))
+    hp, ho = lib.load_header(str(f) + ".header"), O.load_header(str(f) + ".header")
+    assert hp.extent.as_tuple() == ho.extent.as_tuple() == (w, h, d)
+    assert hp.type == ho.type == ctype.encode() and hp.endianness == ho.endianness == endian.encode()
+    assert list(hp.voxel_size) == list(ho.voxel_size) and list(hp.normalisation_range) == list(ho.normalisation_range)
+    scale = max(1.0, float(np.abs(np.array(list(ho.image_transform))).max()))
+    assert np.allclose(list(hp.image_transform), list(ho.image_transform), rtol=0, atol=1e-6 * scale)
+    assert np.array_equal(lib.load_data(str(f), hp), O.load_data(str(f), ho))
+
+
 def test_bench_spreads_the_frames_of_a_block_evenly_over_its_launches():
     import bench
     assert bench.split_frames(20, 8) == [7, 7, 6]
