@@ -97,6 +97,36 @@ def test_build_uniforms_matches_double_precision_oracle(az, el, radius, clip):
     assert abs(np.dot(list(a[1].plane)[:3], cam_pos) + a[1].plane[3] + clip) < 1e-3
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "24"))))
+def test_build_uniforms_fuzz(seed):
+    """vkv_build_uniforms (the product's fp32 statement of src/volume_render_subpass.cpp:219-249) against the oracle's double-precision one on
+    random scenes: extent, block size, voxel size, rotation, camera position / field of view / aspect, clip distance.  Same front-face
+    index, same block size, every float within 1e-5 of the largest entry of its block (fp32 products of 4x4 matrices and an inverse)."""
+    rng = np.random.default_rng(55000 + seed)
+    ext = abi.Extent3D(*(int(x) for x in rng.integers(8, 1200, size=3)))
+    block = int(rng.integers(1, 9))
+    me = O.map_extent(ext, block)
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    ixf = camera.image_transform(tuple(float(x) for x in rng.uniform(0.0003, 2.0, size=3)), ext.as_tuple(),
+                                 (float(axis[0]), float(axis[1]), float(axis[2]), float(rng.uniform(0, 360))))
+    node = camera.benchmark_node_transform(ixf)
+    size = (int(rng.integers(16, 4000)), int(rng.integers(16, 2200)))
+    view = camera.orbit_camera(float(rng.uniform(0, 360)), float(rng.uniform(-85, 85)), float(rng.choice([40.0, 95.0, 150.0, 400.0])))
+    proj = camera.perspective_vulkan(float(rng.uniform(20, 110)), size[0] / size[1])
+    clip = float(rng.choice([0.1, 1.0, 12.0, 50.0]))
+    a = lib.build_uniforms(view, proj, node, ixf, clip, size, ext, me)
+    b = O.build_uniforms(view, proj, node, ixf, clip, size, ext, me)
+    assert a[1].front_index == b[1].front_index
+    assert list(a[1].block_size) == list(b[1].block_size)
+    for x, y in zip(a, b):
+        n = C.sizeof(x) // 4 * 4
+        fa, fb = np.frombuffer(bytes(x)[:n], np.float32)[:16 * 5], np.frombuffer(bytes(y)[:n], np.float32)[:16 * 5]
+        if isinstance(x, abi.RayCastUniform):
+            fa, fb = fa[:16], fb[:16]
+        assert np.abs(fa - fb).max() <= 1e-5 * max(1.0, np.abs(fb).max()), type(x).__name__
+
+
 def test_map_extent_is_ceil_div():
     assert O.map_extent(abi.Extent3D(1024, 1024, 795), 4).as_tuple() == (256, 256, 199)  # SURVEY.md §8 C3
     assert O.map_extent(abi.Extent3D(64, 64, 64), 4).as_tuple() == (16, 16, 16)
