@@ -211,11 +211,13 @@ typedef struct VkvTuning
 	int32_t  screen_cull;              /* 1 = pixels outside the screen bound of the volume's box skip the ray set-up (default)   VKV_RAYMARCH_CULL=0 */
 	int32_t  feedback;                 /* 1 = registered targets start their tiles in the order their last measured frame suggests (default)   VKV_RAYMARCH_FEEDBACK=0 */
 	uint32_t feedback_period;          /* frames between two cost measurements of a target (8)                            VKV_RAYMARCH_FEEDBACK_PERIOD */
-	int32_t  reserved0;                /* ignored (round 3's ray-order experiment lived here; it lost 3 % and left the product)                        */
+	int32_t  clamp_always;             /* 1 = the march loop never takes its clamp-free iterations (A/B switch, same bits)   VKV_RAYMARCH_CLAMP=always  */
 	float    tile_mix_heavy;           /* experiment: central share of the tiles spread over the first tile_mix_spread of the order (0 = off)   VKV_RAYMARCH_TILE_MIX=h,s */
 	float    tile_mix_spread;
 	uint32_t gradient_segment;         /* vkv_gradient_map: tiles a workgroup marches in z; 0 = automatic                 VKV_GRADIENT_SEGMENT */
 	int32_t  pack_tile;                /* vkv_pack_volume: 0 automatic, 2 / 4 = bricks per workgroup edge                 VKV_PACK_TILE */
+	int32_t  format_rows;              /* vkv_render (one frame per launch): footprint rows through buffer FORMAT loads - 0 automatic (when the packed image
+	                                      is below 4 GiB), 1 never, 2 also in vkv_render_batch                              VKV_RAYMARCH_FORMAT_ROWS */
 	uint32_t arena_bytes;              /* read-only: size of the device arena vkv_create allocated                        VKV_ARENA_BYTES */
 } VkvTuning;
 int vkv_get_tuning(const vkv_ctx *ctx, VkvTuning *out);

@@ -301,6 +301,25 @@ extern "C" {
 
 const char *vkv_version(void) { return "vkvolume_amd 0.1.0 (gfx950)"; }
 
+// Range checks of a tuning block, shared by vkv_set_tuning (which rejects a bad block) and default_tuning (which falls back to the
+// built-in value of a field the environment set out of range).  Returns null when the block is fine, else what is wrong with it.
+static const char *tuning_problem(const VkvTuning &t)
+{
+	if (t.scheduler < 0 || t.scheduler > 1 || t.batch_mode < 0 || t.batch_mode > 1 || t.address_tables < 0 || t.address_tables > 2 || t.feedback_period == 0 ||
+	    t.gradient_segment > 255u || (t.pack_tile != 0 && t.pack_tile != 2 && t.pack_tile != 4) || t.clamp_always < 0 || t.clamp_always > 1 ||
+	    t.format_rows < 0 || t.format_rows > 2)
+		return "field out of range";
+	// a tile mix that is not a number never compares equal to a cached schedule's: every launch would build a new table
+	if (!std::isfinite(t.tile_mix_heavy) || !std::isfinite(t.tile_mix_spread) || t.tile_mix_heavy < 0.0f || t.tile_mix_heavy > 1.0f || t.tile_mix_spread < 0.0f ||
+	    t.tile_mix_spread > 1.0f)
+		return "tile_mix_heavy / tile_mix_spread must be numbers in [0, 1]";
+	return nullptr;
+}
+
+// the kernels request their whole LDS layout as dynamic LDS without raising the 64 KiB default limit: a larger figure would make every
+// launch fail instead of choosing the smaller tables
+static void clamp_tuning(VkvTuning &t) { t.full_table_lds_limit = std::min<uint32_t>(t.full_table_lds_limit, kMaxDynamicLds); }
+
 // defaults of the tuning block, then the environment (read HERE, once per context, and nowhere else)
 static void default_tuning(VkvTuning &t)
 {
@@ -343,6 +362,22 @@ static void default_tuning(VkvTuning &t)
 		t.pack_tile = std::atoi(e);
 	if (const char *e = env("VKV_ARENA_BYTES"))
 		t.arena_bytes = (uint32_t) std::min(std::max(std::atol(e), 1l << 20), 1l << 30);
+	if (const char *e = env("VKV_RAYMARCH_CLAMP"))
+		t.clamp_always = e[0] == 'a';
+	if (const char *e = env("VKV_RAYMARCH_FORMAT_ROWS"))
+		t.format_rows = std::atoi(e);
+	// the environment gets the checks vkv_set_tuning applies: an out-of-range value falls back to the built-in default of its group
+	clamp_tuning(t);
+	if (tuning_problem(t))
+	{
+		if (!std::isfinite(t.tile_mix_heavy) || !std::isfinite(t.tile_mix_spread) || t.tile_mix_heavy < 0.0f || t.tile_mix_heavy > 1.0f || t.tile_mix_spread < 0.0f ||
+		    t.tile_mix_spread > 1.0f)
+			t.tile_mix_heavy = t.tile_mix_spread = 0.0f;
+		if (t.pack_tile != 0 && t.pack_tile != 2 && t.pack_tile != 4)
+			t.pack_tile = 0;
+		if (t.format_rows < 0 || t.format_rows > 2)
+			t.format_rows = 0;
+	}
 }
 
 // every cached table gone, the table region of the arena empty again (caller: the device is idle, ctx->mutex held or nobody else around)
@@ -382,10 +417,11 @@ int vkv_trim(vkv_ctx *ctx)
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
 	DeviceGuard      guard(ctx->device);
+	// the lock first: the launch paths take it to look their tables up, so no launch can slip in between the wait and the drop
+	std::lock_guard<std::mutex> lock(ctx->mutex);
 	const hipError_t e = hipDeviceSynchronize();        // launches that still read a table
 	if (e != hipSuccess)
 		return set_error(ctx, (int) e, "trim: %s", hipGetErrorString(e));
-	std::lock_guard<std::mutex> lock(ctx->mutex);
 	drop_tables(ctx);
 	drop_capture_blocks(ctx);
 	return VKV_OK;
@@ -477,21 +513,13 @@ int vkv_set_tuning(vkv_ctx *ctx, const VkvTuning *tuning)
 		return VKV_E_INVALID_ARGUMENT;
 	if (!tuning || tuning->struct_size != sizeof(VkvTuning))
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "set_tuning: struct_size must be sizeof(VkvTuning) = %zu (start from vkv_get_tuning)", sizeof(VkvTuning));
-	if (tuning->scheduler < 0 || tuning->scheduler > 1 || tuning->batch_mode < 0 || tuning->batch_mode > 1 || tuning->address_tables < 0 ||
-	    tuning->address_tables > 2 || tuning->feedback_period == 0 || tuning->gradient_segment > 255u ||
-	    (tuning->pack_tile != 0 && tuning->pack_tile != 2 && tuning->pack_tile != 4))
-		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "set_tuning: field out of range");
-	// a transfer-function mix that is not a number never compares equal to a cached schedule's: every launch would build a new table
-	if (!std::isfinite(tuning->tile_mix_heavy) || !std::isfinite(tuning->tile_mix_spread) || tuning->tile_mix_heavy < 0.0f || tuning->tile_mix_heavy > 1.0f ||
-	    tuning->tile_mix_spread < 0.0f || tuning->tile_mix_spread > 1.0f)
-		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "set_tuning: tile_mix_heavy / tile_mix_spread must be numbers in [0, 1]");
+	if (const char *why = tuning_problem(*tuning))
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "set_tuning: %s", why);
 	std::lock_guard<std::mutex> lock(ctx->mutex);
 	const uint32_t              arena = ctx->tuning.arena_bytes;
 	ctx->tuning                       = *tuning;
 	ctx->tuning.arena_bytes           = arena;        // read-only
-	// the kernels request their whole LDS layout as dynamic LDS without raising the 64 KiB default limit: a larger figure would make every
-	// launch fail instead of choosing the smaller tables
-	ctx->tuning.full_table_lds_limit = std::min<uint32_t>(ctx->tuning.full_table_lds_limit, kMaxDynamicLds);
+	clamp_tuning(ctx->tuning);
 	return VKV_OK;
 }
 

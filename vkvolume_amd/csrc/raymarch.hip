@@ -273,6 +273,12 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 	a.tile_cost = nullptr, a.order_out = nullptr;        // start-order feedback: attached by the launchers
 	a.trace       = reinterpret_cast<unsigned long long *>(ctx->d_trace);
 	a.back        = (int) std::ceil(P->transfer_function.sampling_factor);
+	a.clamp_always = T.clamp_always != 0 ? 1u : 0u;
+	{
+		const float m[3] = {(float) a.mw, (float) a.mh, (float) a.md};
+		for (int k = 0; k < 3; ++k)
+			a.mapf[k] = m[k], a.mapb[k] = std::nextafterf(m[k], 0.0f);
+	}
 	a.addr_lut = nullptr, a.lut_y = a.lut_z = a.lut_words = 0;
 	if (a.packed && T.address_tables != 0)
 		a.addr_lut = packed_addr_lut(ctx, a.W, a.H, a.D, &a.lut_y, &a.lut_z, &a.lut_words, s, setup);

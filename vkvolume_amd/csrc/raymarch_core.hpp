@@ -56,6 +56,8 @@ struct RayMarchArgs
 	int             test;
 	unsigned long long *trace;      // diagnostic (tools/wave_trace.py): kTraceWords x u64 per wave {t_start, t_end, iterations, unit, phase sums}, or null
 	int             back;           // ceil(sampling_factor): the step back after a probe that found an occupied cell (frag:253)
+	uint32_t        clamp_always;   // k_raymarch_lean: 1 = no clamp-free march loop (VkvTuning.clamp_always: A/B switch, same bits)
+	float           mapf[3], mapb[3];        // k_raymarch_lean, clamp-free loop: the map extent as floats, and the largest floats below them
 	const uint32_t *addr_lut;       // k_raymarch_lean: per-axis byte offsets of the packed image (packed_addr_lut, vkv_device.hpp), or null
 	uint32_t        lut_y, lut_z, lut_words;        // word offsets of the y and z tables inside addr_lut and its total length
 	uint32_t        cull_x0, cull_x1, cull_y0, cull_y1;        // k_raymarch_lean: pixels outside [x0, x1] x [y0, y1] cannot see the volume's box
@@ -960,6 +962,15 @@ __device__ __forceinline__ int clamp0_i32(int x, int hi)
 	return r;
 }
 
+// the clamp of lean_march's rare iterations (a ray's first and last loop positions): volatile, so that the compiler keeps it behind its
+// wave-uniform branch instead of executing it always and selecting
+__device__ __forceinline__ float clamp0_f32_cold(float x, float hi)
+{        // clamp(x, 0, hi), hi wave-uniform (a scalar operand)
+	float r;
+	asm volatile("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+	return r;
+}
+
 __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
 {        // a * b + c for a, b < 2^24 and a wave-uniform b: one half-rate instruction (the compiler picks v_mad_u64_u32 + v_mul_u32_u24 + add)
 	uint32_t r;
@@ -975,6 +986,8 @@ constexpr uint32_t kLeanFull     = 2u;        // with kLeanLut and the separable
 constexpr uint32_t kLeanNoCounts = 4u;        // the three per-pixel counters (volume samples, map probes, empty samples) are not kept: for launches without
                                               // d_out_counts and outside Test::NumTextureSamples - the reference keeps them only in its test modes - two
                                               // additions and the EXEC-masked else-branch of the empty sample leave the loop
+constexpr uint32_t kLeanSafe     = 16u;       // with kLeanFull: waves whose rays provably never meet a clamp between their first and last loop position march
+                                              // without the nine clamps of an iteration (lean_march: "clamp-free march loop")
 constexpr uint32_t kLeanStamp    = 8u;        // (diagnostic, instantiated by tools/lab only, with the trace buffer) s_memtime at the top of every iteration,
                                               // summed per wave by the iteration's kind: only probing lanes / only sampling lanes / both
 constexpr size_t   kMaxLutBytes  = 8 * 1024;  // LDS budget of the two-level address tables (1.2 KB at 1024 voxels per axis, 1.9 KB at 2048)
@@ -1155,14 +1168,16 @@ __device__ __forceinline__ FullLutConsts full_lut_consts(const RayMarchArgs &A)
 }
 
 // LDS byte address of X[clamp(ix, -1, W) + 1] straight from the float: fma(clamped floor, 4, 4 + table offset) is exact (small integers)
+// FREE: the caller knows -1 <= floor(c) <= extent on every axis (lean_march's clamp-free loop)
+template <bool FREE = false>
 __device__ __forceinline__ const uint8_t *packed_footprint_full(const FullLutConsts &C, const RmLds &L, float px, float py, float pz, float &wx, float &wy, float &wz)
 {
 	const float cx = __builtin_fmaf(px, C.w, -0.5f), cy = __builtin_fmaf(py, C.h, -0.5f), cz = __builtin_fmaf(pz, C.d, -0.5f);
 	const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy), fz = __builtin_floorf(cz);
 	wx = cx - fx, wy = cy - fy, wz = cz - fz;
-	const int      tx = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fx, -1.0f, C.w), 4.0f, 4.0f);
-	const int      ty = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fy, -1.0f, C.h), 4.0f, C.oy);
-	const int      tz = (int) __builtin_fmaf(__builtin_amdgcn_fmed3f(fz, -1.0f, C.d), 4.0f, C.oz);
+	const int   tx = (int) __builtin_fmaf(FREE ? fx : __builtin_amdgcn_fmed3f(fx, -1.0f, C.w), 4.0f, 4.0f);
+	const int   ty = (int) __builtin_fmaf(FREE ? fy : __builtin_amdgcn_fmed3f(fy, -1.0f, C.h), 4.0f, C.oy);
+	const int   tz = (int) __builtin_fmaf(FREE ? fz : __builtin_amdgcn_fmed3f(fz, -1.0f, C.d), 4.0f, C.oz);
 	const char *   lut = reinterpret_cast<const char *>(full_lut_base(L));
 	const uint32_t xo = *reinterpret_cast<const uint32_t *>(lut + tx), yo = *reinterpret_cast<const uint32_t *>(lut + ty);
 	const uint32_t zo = *reinterpret_cast<const uint32_t *>(lut + tz);
@@ -1194,11 +1209,51 @@ struct LeanStamp
 	uint32_t sum[3], cnt[3];        // shader-clock cycles and iterations of this wave by kind: 0 probe lanes only, 1 sample lanes only, 2 both
 };
 
+// ---- clamp-free march loop (kLeanSafe) -------------------------------------------------------------------------------------------
+// The frag clamps the map cell and the remainder r (frag:221) and - in the sampler - the texel index: nine half-rate instructions
+// per iteration that do nothing on all but the first and the last step of a ray.  Loop position i -> pos = fma(i, step, entry) ->
+// u = k * pos is a chain of correctly rounded, monotone operations, so every component of pos and of u is monotone in i, and a
+// condition "lo <= value < hi" that holds at two loop positions holds at every position between them.
+//   safe(i)  := 0 <= u < map extent on every axis.  Then int(u) = floor(u) IS the clamped cell coordinate and
+//               r = float(u_i) - u = -(u - floor(u)) = -fract(u) (both exact; the clamp to [-1, 0] cannot act).
+//   A ray is "free" when position 1 and its last position n - 1, or the one before it, are safe: it is then safe on [1, lhi], lhi = n - 1
+//   or n - 2 (position 0 lies ON the face the ray enters through, position n - 1 on the one it leaves through, give or take a
+//   rounding either way), and when pos stays within [-g, 1 + g] at positions 0 and n - 1, g = 0.25 / the longest extent: then
+//   c = fma(pos, extent, -0.5) is within [-0.75, extent - 0.25] at EVERY position: the sampler's clamp (floor(c) to [-1, extent]) cannot act.
+// A wave whose marching lanes are all free runs the loop without the nine clamps (lean_march<FREE = true>), any other wave the loop
+// with them.  At the (at most two) positions of a free ray that are not safe - 0, and n - 1 when lhi = n - 2 - u is first clamped to
+// [0, largest float below the extent] (one wave-uniform branch per iteration guards that): int(u) is then the frag's clamped cell.  r at
+// those positions differs from the frag's (fract of the clamped u), and that cannot be observed: position 0 is never probed (the
+// frag starts with voxel_occupied = true and i_min >= 1 afterwards), and a probe at the LAST position either finds the cell occupied (no
+// skip) or skips by max(1, .) >= 1 past the end of the ray - the loop position a ray ends with is not an output.
+__device__ __forceinline__ bool lean_safe_at(const RayMarchArgs &A, const Ray &R, float j, float kx, float ky, float kz)
+{
+	const float px = __builtin_fmaf(j, R.sx, R.ex), py = __builtin_fmaf(j, R.sy, R.ey), pz = __builtin_fmaf(j, R.sz, R.ez);
+	const float vx = kx * px, vy = ky * py, vz = kz * pz;
+	return __builtin_fminf(__builtin_fminf(vx, vy), vz) >= 0.0f && vx < A.mapf[0] && vy < A.mapf[1] && vz < A.mapf[2];
+}
+
+// wave-uniform: every marching lane's ray is free
+__device__ __forceinline__ bool lean_free_wave(const RayMarchArgs &A, const Ray &R)
+{
+	if (A.clamp_always)
+		return false;
+	const float kx = (float) A.W / A.block_size[0], ky = (float) A.H / A.block_size[1], kz = (float) A.D / A.block_size[2];
+	const float g  = 0.25f / (float) max(max(A.W, A.H), A.D);
+	const float last = (float) R.n_steps - 1.0f;
+	// pos at positions 0 (= the entry) and n - 1
+	const float lx = __builtin_fmaf(last, R.sx, R.ex), ly = __builtin_fmaf(last, R.sy, R.ey), lz = __builtin_fmaf(last, R.sz, R.ez);
+	const bool  inside = __builtin_fminf(__builtin_fminf(__builtin_fminf(R.ex, R.ey), R.ez), __builtin_fminf(__builtin_fminf(lx, ly), lz)) >= -g &&
+	                    __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(R.ex, R.ey), R.ez), __builtin_fmaxf(__builtin_fmaxf(lx, ly), lz)) <= 1.0f + g;
+	const bool free_ray = inside && lean_safe_at(A, R, 1.0f, kx, ky, kz) && (lean_safe_at(A, R, last, kx, ky, kz) || lean_safe_at(A, R, last - 1.0f, kx, ky, kz));
+	return __builtin_amdgcn_ballot_w64(!free_ray) == 0ull;
+}
+
 // The march loop of one ray (frag:215-312).  SEP: the transfer function is the reference's separable greyscale product (alpha byte from
 // the two LDS tables, one colour channel); otherwise the alpha > 0 bit table in LDS gates a dependent RGBA texel fetch.
 // kHoist (packed image, gradient from the map or unused): footprint loads issued ahead of the outcome blocks; the other variants (linear
 // volume, on-the-fly gradient: five trilinear taps) sample inside the sample block.
-template <int SKIP, bool ERT, int GRAD, bool PACKED, bool SEP, uint32_t LF>
+template <int SKIP, bool ERT, int GRAD, bool PACKED, bool SEP, uint32_t LF, bool FREE = false>
 __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const RmLds &L, uint32_t &iter, LeanStamp &stamp)
 {
 	constexpr bool kStamp = (LF & kLeanStamp) != 0, kCounts = (LF & kLeanNoCounts) == 0;
@@ -1209,6 +1264,10 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	const float    kx = SKIP != VKV_SKIP_NONE ? (float) W / A.block_size[0] : 0.0f, ky = SKIP != VKV_SKIP_NONE ? (float) H / A.block_size[1] : 0.0f,
 	            kz = SKIP != VKV_SKIP_NONE ? (float) D / A.block_size[2] : 0.0f;
 	const int   mw1 = A.mw - 1, mh1 = A.mh - 1, md1 = A.md - 1;
+	// (the multipliers of the cell index, pinned in scalar registers: the batch kernel's arguments sit in memory and the compiler would
+	// otherwise be free to load them again in every iteration)
+	uint32_t amw = (uint32_t) A.mw, amh = (uint32_t) A.mh;
+	asm volatile("" : "+s"(amw), "+s"(amh));
 	float       grey = 0.0f;
 	uint32_t    ul   = 0;
 	bool        occ  = true, done = false;
@@ -1216,10 +1275,15 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	const float ofx = R.six > 0.0f ? 0.0f : 1.0f, ofy = R.siy > 0.0f ? 0.0f : 1.0f, ofz = R.siz > 0.0f ? 0.0f : 1.0f;
 	FullLutConsts fullc = {};
 	if (kFull)
-		fullc = full_lut_consts(A);
+		fullc = full_lut_consts<FREE>(A);        // (the clamp-free loop keeps them in scalar registers: room for the per-ray map pointer of the anisotropic kernels)
 	// loop position, its bounds and the first hit as floats (exact: n_steps <= 2^24)
 	float       li = (float) R.i, li_min = (float) R.i_min, lfirst = (float) R.first_hit;
 	const float ln = (float) R.n_steps, lback = (float) A.back;
+	// the distance map of a launch without the anisotropic maps is the same for every ray: a scalar base for the probe's load
+	const uint8_t *const dmap = SKIP == VKV_SKIP_ANISOTROPIC_DISTANCE ? R.dmap : A.maps[0];
+	// FREE: the clamp-free form of the loop, for waves of free rays (lean_free_wave above)
+	float lhi_now = -1.0f;        // the last safe position of this lane's ray: -1 until the first iteration (i = 0) is done, then lhi
+	static_assert(!FREE || ((LF & kLeanSafe) != 0 && kFull && kHoist && SKIP != VKV_SKIP_NONE && !kStamp), "the clamp-free loop exists for kLeanSafe kernels only");
 	while (!done)
 	{
 		const float i    = li;
@@ -1230,10 +1294,25 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		if (SKIP != VKV_SKIP_NONE)
 		{        // frag:192, 220-221
 			ux = kx * posx, uy = ky * posy, uz = kz * posz;
-			if (kLut)
+			if (FREE)
+			{
+				if (__builtin_expect(__builtin_amdgcn_ballot_w64(i > lhi_now) != 0ull, 0))
+				{        // the first iteration of every wave, and the iterations in which a ray with lhi = n - 2 stands at its last position
+					ux = clamp0_f32_cold(ux, A.mapb[0]), uy = clamp0_f32_cold(uy, A.mapb[1]), uz = clamp0_f32_cold(uz, A.mapb[2]);        // to [0, largest float below the extent]
+					// lhi, worked out here, where it is rarely needed, instead of being kept in a register across the loop (the empty asm keeps the
+					// compiler from re-using - and spilling - what lean_free_wave computed from the same operands)
+					float last = ln;
+					asm volatile("" : "+v"(last));
+					last -= 1.0f;
+					lhi_now = lean_safe_at(A, R, last, kx, ky, kz) ? last : last - 1.0f;
+				}
+				uix = (int) ux, uiy = (int) uy, uiz = (int) uz;
+				cell = mad_u24(mad_u24((uint32_t) uiz, amh, (uint32_t) uiy), amw, (uint32_t) uix);
+			}
+			else if (kLut)
 			{
 				uix = clamp0_i32((int) ux, mw1), uiy = clamp0_i32((int) uy, mh1), uiz = clamp0_i32((int) uz, md1);
-				cell = mad_u24(mad_u24((uint32_t) uiz, (uint32_t) A.mh, (uint32_t) uiy), (uint32_t) A.mw, (uint32_t) uix);
+				cell = mad_u24(mad_u24((uint32_t) uiz, amh, (uint32_t) uiy), amw, (uint32_t) uix);
 			}
 			else
 			{
@@ -1264,10 +1343,10 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		         q11 = undefined_value<uint32_t>();
 		float    wx = undefined_value<float>(), wy = undefined_value<float>(), wz = undefined_value<float>();
 		if (SKIP != VKV_SKIP_NONE && probe)
-			dist = load_u8_global(R.dmap, cell);
+			dist = load_u8_global(dmap, cell);
 		if (kHoist && !probe)
 		{
-			const uint8_t *ba = kFull  ? packed_footprint_full(fullc, L, posx, posy, posz, wx, wy, wz)
+			const uint8_t *ba = kFull  ? packed_footprint_full<FREE>(fullc, L, posx, posy, posz, wx, wy, wz)
 			                    : kLut ? packed_footprint_lut(A, posx, posy, posz, wx, wy, wz)
 			                           : packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, wx, wy, wz);
 			q00 = load_row(ba);
@@ -1279,22 +1358,27 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		// ---- probe outcome (frag:234-247); needs the probe byte only ---------------------------------------------------
 		float skip = 0.0f;
 		auto  probe_outcome = [&]() {
-			const float rx = __builtin_amdgcn_fmed3f((float) uix - ux, -1.0f, 0.0f);
-			const float ry = __builtin_amdgcn_fmed3f((float) uiy - uy, -1.0f, 0.0f);
-			const float rz = __builtin_amdgcn_fmed3f((float) uiz - uz, -1.0f, 0.0f);
-			float       ax, ay, az;
+			// frag:221 r = clamp(float(u_i) - u, -1, 0); FREE: r = -fract(u) (above the loop), and "+ r" becomes "- fract(u)"
+			float bx, by, bz;        // frag:239 step(0, s) / frag:242 step(0, -s) + sign(s) * dist
 			if (SKIP == VKV_SKIP_BLOCK)
+				bx = (R.six < 0.0f) ? 0.0f : 1.0f, by = (R.siy < 0.0f) ? 0.0f : 1.0f, bz = (R.siz < 0.0f) ? 0.0f : 1.0f;
+			else
+			{        // = fd for s > 0, 1 - fd for s < 0: one fma with per-ray constants (exact: the product is exact)
+				const float fd = (float) dist;
+				bx = __builtin_fmaf(sgx, fd, ofx), by = __builtin_fmaf(sgy, fd, ofy), bz = __builtin_fmaf(sgz, fd, ofz);
+			}
+			float ax, ay, az;
+			if (FREE)
 			{
-				ax = (((R.six < 0.0f) ? 0.0f : 1.0f) + rx) * R.six;
-				ay = (((R.siy < 0.0f) ? 0.0f : 1.0f) + ry) * R.siy;
-				az = (((R.siz < 0.0f) ? 0.0f : 1.0f) + rz) * R.siz;
+				ax = (bx - __builtin_amdgcn_fractf(ux)) * R.six;
+				ay = (by - __builtin_amdgcn_fractf(uy)) * R.siy;
+				az = (bz - __builtin_amdgcn_fractf(uz)) * R.siz;
 			}
 			else
-			{        // step(0, -s) + sign(s) * dist = fd for s > 0, 1 - fd for s < 0: one fma with per-ray constants (exact: the product is exact)
-				const float fd = (float) dist;
-				ax = (__builtin_fmaf(sgx, fd, ofx) + rx) * R.six;
-				ay = (__builtin_fmaf(sgy, fd, ofy) + ry) * R.siy;
-				az = (__builtin_fmaf(sgz, fd, ofz) + rz) * R.siz;
+			{
+				ax = (bx + __builtin_amdgcn_fmed3f((float) uix - ux, -1.0f, 0.0f)) * R.six;
+				ay = (by + __builtin_amdgcn_fmed3f((float) uiy - uy, -1.0f, 0.0f)) * R.siy;
+				az = (bz + __builtin_amdgcn_fmed3f((float) uiz - uz, -1.0f, 0.0f)) * R.siz;
 			}
 			// a NaN component (0 * inf on an axis-parallel ray) counts as +inf: minNum ignores it; all three cannot be NaN, and if
 			// they were the comparison caps the result exactly as the select chain of the oracle does
@@ -1526,7 +1610,18 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 		if (marched)
 		{
 			if (sep)
-				lean_march<SKIP, ERT, GRAD, PACKED, true, LF>(A, R, L, iter, stamp);
+			{
+				constexpr bool kSafe = (LF & kLeanSafe) != 0 && (LF & kLeanFull) != 0 && PACKED && GRAD != 2 && SKIP != VKV_SKIP_NONE && (LF & kLeanStamp) == 0;
+				if constexpr (kSafe)
+				{
+					if (lean_free_wave(A, R))
+						lean_march<SKIP, ERT, GRAD, PACKED, true, LF, true>(A, R, L, iter, stamp);
+					else
+						lean_march<SKIP, ERT, GRAD, PACKED, true, LF>(A, R, L, iter, stamp);
+				}
+				else
+					lean_march<SKIP, ERT, GRAD, PACKED, true, LF>(A, R, L, iter, stamp);
+			}
 			else
 				lean_march<SKIP, ERT, GRAD, PACKED, false, LF>(A, R, L, iter, stamp);
 		}
@@ -1597,7 +1692,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((GRAD 
 	const uint32_t g = blockIdx.x >> 3;
 	// groups_per_frame == 0: frames interleaved in groups of eight workgroups; otherwise one frame after the other (A/B switch of the launcher)
 	const uint32_t f = groups_per_frame == 0 ? g % n : g / groups_per_frame, gi = groups_per_frame == 0 ? g / n : g % groups_per_frame;
-	lean_block<SKIP, ERT, GRAD, true, LF>(frames[f], (gi << 3) | (blockIdx.x & 7u), L);
+	// (the anisotropic kernels that keep the per-pixel counters have no room under the 64-VGPR cap for the second march loop: they would spill)
+	constexpr uint32_t kLfBatch = (SKIP == VKV_SKIP_ANISOTROPIC_DISTANCE && (LF & kLeanNoCounts) == 0) ? (LF & ~kLeanSafe) : LF;
+	lean_block<SKIP, ERT, GRAD, true, kLfBatch>(frames[f], (gi << 3) | (blockIdx.x & 7u), L);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ enum Scheduler
 // The instantiations of the lean kernel a launch chooses from (raymarch_core.hpp explains the flags):
 constexpr uint32_t kLfPlain  = 0;                                // footprint address worked out in registers: any volume, any map
 constexpr uint32_t kLfLut    = kLeanLut;                         // two-level address tables in LDS (volumes up to ~2500 voxels per axis)
-constexpr uint32_t kLfFull   = kLeanLut | kLeanFull;             // + one entry per voxel index with the separable transfer function
+constexpr uint32_t kLfFull   = kLeanLut | kLeanFull | kLeanSafe; // + one entry per voxel index with the separable transfer function, clamp-free iterations
 constexpr uint32_t kLfFullNc = kLfFull | kLeanNoCounts;          // the same without the per-pixel counters (what a renderer launches)
 constexpr uint32_t kLfLutNc  = kLfLut | kLeanNoCounts;
 
