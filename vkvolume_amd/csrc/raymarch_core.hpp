@@ -988,6 +988,8 @@ constexpr uint32_t kLeanNoCounts = 4u;        // the three per-pixel counters (v
                                               // additions and the EXEC-masked else-branch of the empty sample leave the loop
 constexpr uint32_t kLeanSafe     = 16u;       // with kLeanFull: waves whose rays provably never meet a clamp between their first and last loop position march
                                               // without the nine clamps of an iteration (lean_march: "clamp-free march loop")
+constexpr uint32_t kLeanAsync    = 32u;       // separable transfer function + empty-space skipping: the loop's global loads are issued through inline asm and waited
+                                              // for with hand-set counts, so that the probe outcome runs while the footprint gathers are still in flight
 constexpr uint32_t kLeanStamp    = 8u;        // (diagnostic, instantiated by tools/lab only, with the trace buffer) s_memtime at the top of every iteration,
                                               // summed per wave by the iteration's kind: only probing lanes / only sampling lanes / both
 constexpr size_t   kMaxLutBytes  = 8 * 1024;  // LDS budget of the two-level address tables (1.2 KB at 1024 voxels per axis, 1.9 KB at 2048)
@@ -1204,6 +1206,43 @@ __device__ __forceinline__ uint32_t load_row(const uint8_t *p)
 	return *g;
 }
 
+// ---- the march loop's loads with hand-set wait counts (kLeanAsync) --------------------------------------------------------------
+// The compiler waits for a load with s_waitcnt vmcnt(n), n = the number of YOUNGER loads that may still be outstanding.  The probe
+// byte and the four footprint dwords of an iteration are issued under different EXEC masks, each behind a branch that skips it when
+// no lane takes part, so at the probe outcome the compiler cannot know whether four younger loads follow the byte or none: it waits
+// for everything (vmcnt(0)) - the probe outcome, a third of an iteration's instructions, then starts only when the slowest footprint
+// gather has come back.  Loads return in order, so with the loads hidden from the compiler's bookkeeping (inline asm) and one
+// wave-uniform test (does any lane sample in this iteration?) the wait can be exact: vmcnt(4) when footprints follow, vmcnt(0) when none
+// do.  The waits take the loaded registers as in/out operands: every use of a loaded value is ordered behind its wait.
+// (Other loads the compiler issues itself can only make these waits stricter, never weaker: a count includes them.)
+__device__ __forceinline__ void load_u8_async(uint32_t &dst, const uint8_t *base_uniform, uint32_t index)
+{
+	asm volatile("global_load_ubyte %0, %1, %2" : "=v"(dst) : "v"(index), "s"(base_uniform));
+}
+__device__ __forceinline__ void load_u8_async_lane(uint32_t &dst, const uint8_t *base_lane, uint32_t index)
+{
+	const uint8_t *p = base_lane + index;
+	asm volatile("global_load_ubyte %0, %1, off" : "=v"(dst) : "v"(p));
+}
+__device__ __forceinline__ void load_rows_async(uint32_t &q00, uint32_t &q10, uint32_t &q01, uint32_t &q11, const uint8_t *p)
+{        // (early-clobber outputs: none of them may share a register with the address)
+	asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %4, off offset:10\n\tglobal_load_dword %2, %4, off offset:50\n\tglobal_load_dword %3, %4, off offset:60"
+	             : "=&v"(q00), "=&v"(q10), "=&v"(q01), "=&v"(q11)
+	             : "v"(p));
+}
+// Wait for the oldest load in flight, inside the EXEC-masked probe side: four younger loads are behind it when some live lane of the
+// iteration does NOT probe (EXEC here = the probing lanes, `live` = EXEC at the top of the iteration), none otherwise.  One asm statement
+// with its own scalar branch: as two statements on the two sides of a C++ branch the loaded register comes out as two values the compiler
+// merges with moves, and a flag worked out in C++ from a ballot costs two vector instructions.
+__device__ __forceinline__ void wait_oldest_of_five_or_one(uint32_t &a, unsigned long long live)
+{
+	asm volatile("s_cmp_lg_u64 exec, %1\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(0)\n\ts_branch 2f\n1:\n\ts_waitcnt vmcnt(4)\n2:" : "+v"(a) : "s"(live) : "scc");
+}
+__device__ __forceinline__ void wait_rows(uint32_t &q00, uint32_t &q10, uint32_t &q01, uint32_t &q11)
+{
+	asm volatile("s_waitcnt vmcnt(0)" : "+v"(q00), "+v"(q10), "+v"(q01), "+v"(q11));
+}
+
 struct LeanStamp
 {
 	uint32_t sum[3], cnt[3];        // shader-clock cycles and iterations of this wave by kind: 0 probe lanes only, 1 sample lanes only, 2 both
@@ -1259,6 +1298,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	constexpr bool kStamp = (LF & kLeanStamp) != 0, kCounts = (LF & kLeanNoCounts) == 0;
 	constexpr bool kHoist = PACKED && GRAD != 2;
 	constexpr bool kLut = (LF & kLeanLut) != 0, kFull = (LF & kLeanFull) != 0 && SEP, kTf = SEP && kHoist;
+	constexpr bool kAsync = (LF & kLeanAsync) != 0 && kTf && SKIP != VKV_SKIP_NONE;        // (not the texture path: its texel fetch is a load the compiler issues)
 	uint32_t       stamp_prev = 0, stamp_kind = 3;
 	const int      W = A.W, H = A.H, D = A.D;
 	const float    kx = SKIP != VKV_SKIP_NONE ? (float) W / A.block_size[0] : 0.0f, ky = SKIP != VKV_SKIP_NONE ? (float) H / A.block_size[1] : 0.0f,
@@ -1342,17 +1382,32 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		uint32_t dist = undefined_value<uint32_t>(), q00 = undefined_value<uint32_t>(), q10 = undefined_value<uint32_t>(), q01 = undefined_value<uint32_t>(),
 		         q11 = undefined_value<uint32_t>();
 		float    wx = undefined_value<float>(), wy = undefined_value<float>(), wz = undefined_value<float>();
+		unsigned long long live = 0ull;
+		if (kAsync)
+			live = __builtin_amdgcn_read_exec();        // the lanes whose rays are alive in this iteration
 		if (SKIP != VKV_SKIP_NONE && probe)
-			dist = load_u8_global(dmap, cell);
+		{
+			if (kAsync && SKIP == VKV_SKIP_ANISOTROPIC_DISTANCE)
+				load_u8_async_lane(dist, dmap, cell);
+			else if (kAsync)
+				load_u8_async(dist, dmap, cell);
+			else
+				dist = load_u8_global(dmap, cell);
+		}
 		if (kHoist && !probe)
 		{
 			const uint8_t *ba = kFull  ? packed_footprint_full<FREE>(fullc, L, posx, posy, posz, wx, wy, wz)
 			                    : kLut ? packed_footprint_lut(A, posx, posy, posz, wx, wy, wz)
 			                           : packed_footprint(A.packed, W, H, D, A.pmx, A.pmy, posx, posy, posz, wx, wy, wz);
-			q00 = load_row(ba);
-			q10 = load_row(ba + 10);
-			q01 = load_row(ba + 50);
-			q11 = load_row(ba + 60);
+			if (kAsync)
+				load_rows_async(q00, q10, q01, q11, ba);
+			else
+			{
+				q00 = load_row(ba);
+				q10 = load_row(ba + 10);
+				q01 = load_row(ba + 50);
+				q11 = load_row(ba + 60);
+			}
 		}
 
 		// ---- probe outcome (frag:234-247); needs the probe byte only ---------------------------------------------------
@@ -1486,6 +1541,10 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		                                        // compiler sinks each load into its block: the footprint would be requested after the probe outcome)
 		if (probe)
 		{
+			if (kAsync)
+			{        // the byte is the oldest load in flight: behind it the four footprint dwords, or nothing
+				wait_oldest_of_five_or_one(dist, live);
+			}
 			probe_outcome();        // an empty side is skipped by the branch the compiler puts around it (s_cbranch_execz)
 			if (kCounts)
 				++R.n_dist;
@@ -1500,8 +1559,12 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			ul   = hit ? cell : ul;
 			done = li >= ln;
 		}
-		else
+		if (kAsync)        // the probe side FIRST (its byte is the oldest load): a statement every lane executes between the two sides, so that
+			asm volatile("");        // they stay two regions in this order instead of an if / else whose sides the compiler may swap
+		if (!probe)
 		{
+			if (kAsync)
+				wait_rows(q00, q10, q01, q11);
 			sample_outcome();
 			if (kCounts)
 				++R.n_vol;

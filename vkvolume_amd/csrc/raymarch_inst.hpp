@@ -18,7 +18,11 @@ enum Scheduler
 // The instantiations of the lean kernel a launch chooses from (raymarch_core.hpp explains the flags):
 constexpr uint32_t kLfPlain  = 0;                                // footprint address worked out in registers: any volume, any map
 constexpr uint32_t kLfLut    = kLeanLut;                         // two-level address tables in LDS (volumes up to ~2500 voxels per axis)
-constexpr uint32_t kLfFull   = kLeanLut | kLeanFull | kLeanSafe; // + one entry per voxel index with the separable transfer function, clamp-free iterations
+#ifdef VKV_LEAN_NO_ASYNC        // A/B builds only
+constexpr uint32_t kLfFull   = kLeanLut | kLeanFull | kLeanSafe;
+#else
+constexpr uint32_t kLfFull   = kLeanLut | kLeanFull | kLeanSafe | kLeanAsync; // + one entry per voxel index with the separable transfer function, clamp-free loop, hand-set load waits
+#endif
 constexpr uint32_t kLfFullNc = kLfFull | kLeanNoCounts;          // the same without the per-pixel counters (what a renderer launches)
 constexpr uint32_t kLfLutNc  = kLfLut | kLeanNoCounts;
 
