@@ -172,7 +172,7 @@ def kernel_source_digest():
     return h.hexdigest()
 
 
-def build_scene(ctx, name, tf_preset="app"):
+def build_scene(ctx, name, tf_preset="app", empty=False):
     extent, seed, voxel, axis_angle, frame, skip = WORKLOADS[name][:6]
     v = V.Volume(ctx)
     if tf_preset == "intensity":  # the reference CSVs' intensity-only rows (gmin = gmax = 0: no gradient term, 8 B per volume sample)
@@ -180,6 +180,8 @@ def build_scene(ctx, name, tf_preset="app"):
     else:
         v.options = abi.VolumeOptions(intensity_min=0.1, intensity_max=1.0, gradient_min=0.0, gradient_max=0.2)  # volume_render.cpp:67-70
     v.load_synthetic(extent, kind=1, seed=seed, distance_map_block_size=4)
+    if empty:  # the probe-only asymptote: every voxel below the transfer function's threshold, every map cell empty
+        v.volume.zero_()
     V.default_scene(v, voxel, axis_angle)
     tf = v.get_transfer_function_uniform()
     V.ComputeGradientMap(ctx).compute(v, tf)
@@ -262,6 +264,15 @@ def main():
                     "started and exits with status 124 (0 = never)")
     ap.add_argument("--c5-block", default="auto", choices=["auto", "on", "off"], help="after the headline blocks, a short block of BASELINE.json configs[4] (c5: "
                     "2048^3, anisotropic maps, the fixed 7680x4320 frame dealt over the ranks), reported as \"c5_strong\" in the same line; auto = at N > 1")
+    ap.add_argument("--virtual-rank", default=None, metavar="R/N", help="N = 1: render only the tile share rank R of N would render (compact schedule tile_first = R, "
+                    "tile_stride = N, no exchange) - what one of N GPUs would be busy with per frame; tools/virtual_ranks.py turns the shares into a "
+                    "PREDICTED scaling curve")
+    ap.add_argument("--extras", default="auto", choices=["auto", "on", "off"], help="N = 1, after the headline blocks: a short block of the literal 1024^3 (\"c3cube\") and "
+                    "the two asymptotes of the integrator - dense sampling and probes only (\"asymptotes\"); auto = with --workload c3 and the default options")
+    ap.add_argument("--native-block", default="auto", choices=["auto", "on", "off"], help="N > 1 with --exchange torch: after each measurement a short block of the "
+                    "same launches with the C ABI's exchange (vkv_assemble_frames), reported as \"native_exchange\"; a failure becomes an \"error\" string there")
+    ap.add_argument("--native-timeout", type=float, default=120.0, help="seconds after which a native-exchange block that has not finished is given up: rank 0 "
+                    "prints the line it has (with the timeout as the block's \"error\"), every rank exits")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -294,23 +305,117 @@ def main():
 
     ctx = lib.Context(device)  # raises if the HIP library is missing: there is no fallback path
     env = {"world": world, "rank": rank, "local_rank": device, "dist": dist, "ctx": ctx, "use_gather": use_gather, "submit": submit}
+    import copy
+    import threading
+    printed = threading.Lock()
+    state = {"out": None, "done": False}
+
+    def emit():
+        """rank 0's ONE line (whoever gets here first: the main thread at the end, or a watchdog that gave a side block up)"""
+        with printed:
+            if not state["done"] and rank == 0 and state["out"] is not None:
+                print(json.dumps(state["out"]), file=json_out, flush=True)
+            state["done"] = True
+
+    def side_block(key, holder, **over):
+        """A short extra measurement with some options replaced, reported as holder[key].  It can never cost the headline: an exception becomes
+        {"error": ...} (on every rank: the ranks agree on the outcome through one all-reduce), and a block that hangs - a collective one rank never
+        enters - is given up after --native-timeout seconds by a watchdog that prints the line as it stands and ends the process (fresh
+        processes were started by the launcher; nothing is re-executed)."""
+        a2 = copy.copy(args)
+        for k, val in over.items():
+            setattr(a2, k, val)
+        a2.no_cpu_baseline, a2.no_depth_block = True, True
+
+        def give_up():
+            if rank == 0 and holder is not None:
+                holder[key] = {"error": "gave up after %.0f s (--native-timeout): the block did not finish" % args.native_timeout}
+            emit()
+            os._exit(0)
+
+        dog = threading.Timer(args.native_timeout, give_up) if (world > 1 or use_gather) and args.native_timeout > 0 else None
+        if dog:
+            dog.daemon = True
+            dog.start()
+        res, err = None, None
+        try:
+            torch.cuda.empty_cache()
+            res = job(a2, env)
+        except BaseException as e:  # SystemExit (a failed --verify) as well
+            err = "%s: %s" % (type(e).__name__, e)
+        try:
+            if dist is not None and world > 1:
+                flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if flag.item() > 0 and err is None:
+                    err = "another rank failed"
+        except BaseException as e:
+            err = err or ("%s: %s" % (type(e).__name__, e))
+        if dog:
+            dog.cancel()
+        if rank == 0 and holder is not None:
+            holder[key] = {"error": err} if err else res
+        return None if err else res
+
+    def brief(o, extra=()):
+        d = {k: o[k] for k in ("ms_per_step", "value", "unit", "steps", "warmup", "repeats", "scaling", "covered_Mray_per_s", "phases", "rccl_ranks",
+                                "rccl_ranks_source", "volume_samples_per_s", "distance_probes_per_s") + tuple(extra) if k in o}
+        d.update(frac=o["roofline"]["frac"], achieved=o["roofline"]["achieved"], workload=o["config"]["workload"], parallelism=o["config"]["parallelism"])
+        return d
+
+    def with_native(o, **over):
+        """N > 1, torch exchange: the same launches once more, briefly, through the C ABI's own exchange (vkv_assemble_frames) - so that the first
+        run on real links carries the product's gather next to torch.distributed's"""
+        if not (use_gather and args.exchange == "torch" and submit == "batch" and (args.native_block == "on" or (args.native_block == "auto" and args.backend == "nccl"))):
+            return
+        tmp = {}
+        side_block("n", tmp if rank == 0 else None, exchange="native", steps=min(args.steps, 16), warmup=min(args.warmup, 8), min_seconds=min(args.min_seconds, 0.5), **over)
+        if rank == 0 and o is not None:
+            r = tmp.get("n")
+            o["native_exchange"] = r if (r is None or "error" in r) else brief(r)
+
     out = job(args, env)
+    state["out"] = out
+    with_native(out)
     # BASELINE.json configs[4] is the configuration north_star names for 8 GPUs: at N > 1 the same ranks then time a short block of it (strong
     # scaling: the 7680x4320 frame is fixed, its tiles are dealt over the ranks); c3 stays the headline so that N = 1 agrees with BENCH
     if args.c5_block == "on" or (args.c5_block == "auto" and world > 1 and args.workload != "c5"):
-        import copy
-        a2 = copy.copy(args)
-        a2.workload, a2.scaling, a2.skip, a2.tf, a2.no_ert = "c5", "strong", None, "app", False
-        a2.steps, a2.warmup, a2.min_seconds = min(args.steps, 16), min(args.warmup, 8), min(args.min_seconds, 1.0)
-        a2.verify, a2.no_cpu_baseline, a2.no_depth_block = args.verify, True, True
-        torch.cuda.empty_cache()
-        o2 = job(a2, env)
+        c5 = dict(workload="c5", scaling="strong", skip=None, tf="app", no_ert=False, steps=min(args.steps, 16), warmup=min(args.warmup, 8),
+                  min_seconds=min(args.min_seconds, 1.0))
+        tmp = {}
+        o2 = side_block("c5", tmp if rank == 0 else None, **c5)
         if rank == 0:
-            out["c5_strong"] = {k: o2[k] for k in ("ms_per_step", "value", "unit", "steps", "warmup", "repeats", "scaling", "covered_Mray_per_s", "phases") if k in o2}
-            out["c5_strong"].update(frac=o2["roofline"]["frac"], achieved=o2["roofline"]["achieved"], workload=o2["config"]["workload"],
-                                    parallelism=o2["config"]["parallelism"])
-    if rank == 0:
-        print(json.dumps(out), file=json_out, flush=True)
+            out["c5_strong"] = brief(o2) if o2 is not None else tmp.get("c5")
+        if o2 is not None or rank != 0:
+            with_native(out["c5_strong"] if rank == 0 and o2 is not None else None, **{k: c5[k] for k in ("workload", "scaling", "skip", "tf", "no_ert")})
+    # N = 1: the literal 1024^3 of BASELINE.json's metric line on the same clock, and the integrator's two asymptotes
+    default_run = args.workload == "c3" and args.skip is None and args.tf == "app" and not args.no_ert and submit == "batch"
+    if world == 1 and not use_gather and not args.virtual_rank and (args.extras == "on" or (args.extras == "auto" and default_run)):
+        short = dict(steps=min(args.steps, 16), warmup=min(args.warmup, 4), min_seconds=min(args.min_seconds, 0.5))
+        o3 = side_block("c3cube", out, workload="c3cube", **short)
+        if o3 is not None:
+            out["c3cube"] = brief(o3, ("single_frame",))
+            out["c3cube"]["note"] = "BASELINE.json's metric line names 1024^3: the same submission on the literal cube, a short block behind the headline"
+        asym = {}
+        o4 = side_block("dense", asym, workload=args.workload, skip="none", no_ert=True, steps=min(args.steps, 8), warmup=2, min_seconds=min(args.min_seconds, 0.3))
+        if o4 is not None:
+            asym["dense"] = {"ms_per_step": o4["ms_per_step"], "frac": o4["roofline"]["frac"], "volume_samples_per_s": o4["volume_samples_per_s"],
+                             "what": "no empty-space skipping, no early termination: every lane samples at every step of its ray (16 B per sample)"}
+        o5 = side_block("probe_only", asym, workload=args.workload, skip="block", empty_volume=True, **short)
+        if o5 is not None:
+            asym["probe_only"] = {"ms_per_step": o5["ms_per_step"], "frac": o5["roofline"]["frac"], "distance_probes_per_s": o5["distance_probes_per_s"],
+                                  "volume_samples_per_s": o5["volume_samples_per_s"],
+                                  "what": "the same box with every voxel empty and the 0 / 255 block map: a ray samples once, then walks one map cell per probe "
+                                          "to the far side (1 B per probe)"}
+        # lanes per block execution and the gain if every block execution were full: from the oracle's event traces of the bench views, priced with the
+        # shipped loop's block costs (profiles/HISTORY.md section 5.2; tools/sim_traces.py + tools/sched_policies_sim.py) - a property of the frag's
+        # event sequences on this scene, not of a kernel build
+        asym["lane_occupancy"] = {"probe_block": 27, "sample_block": 28, "of": 64, "mixed_iterations": 0.62,
+                                  "source": "oracle event traces of the 8 bench views, profiles/HISTORY.md 5.2"}
+        asym["ideal_full_blocks"] = {"speedup": 2.11, "frac": round(2.11 * out["roofline"]["frac"], 4),
+                                     "what": "the unreachable ideal of lane = ray: every probe / sample block execution with 64 live lanes; the north-star 0.70 is above it"}
+        out["asymptotes"] = asym
+    emit()
     if dist is not None:
         dist.destroy_process_group()
 
@@ -319,7 +424,7 @@ def job(args, env):
     """One measurement (scene set-up, pre-pass, warm-up, the timed blocks) of args.workload on the ranks of `env`; returns the result
     line as a dict on rank 0, None elsewhere."""
     world, rank, local_rank, dist, ctx, use_gather, submit = (env[k] for k in ("world", "rank", "local_rank", "dist", "ctx", "use_gather", "submit"))
-    v, tf, frame, skip = build_scene(ctx, args.workload, args.tf)
+    v, tf, frame, skip = build_scene(ctx, args.workload, args.tf, empty=getattr(args, "empty_volume", False))
     if args.skip is not None:
         skip = {"none": abi.SKIP_NONE, "block": abi.SKIP_BLOCK, "distance": abi.SKIP_DISTANCE, "anisotropic": abi.SKIP_ANISOTROPIC_DISTANCE}[args.skip]
         V.ComputeDistanceMap(ctx).compute(v, tf, skip)
@@ -330,10 +435,19 @@ def job(args, env):
     views = cameras(v, frame[0] / frame[1])  # the SAME frustum for every N
     opts = abi.RenderOptions(skipping_type=skip, clip_distance=1.0, early_ray_termination=not args.no_ert)
     sp = V.VolumeRenderSubpass(ctx, v, opts, (fw, fh))
-    tiles = abi.full_frame_tiles(fw, fh, TILE, TILE, rank, world, compact=use_gather)
+    virtual = None
+    if getattr(args, "virtual_rank", None):
+        if world != 1 or use_gather:
+            raise SystemExit("--virtual-rank is a one-GPU proxy: not with --gpus > 1 or --force-gather")
+        virtual = tuple(int(x) for x in args.virtual_rank.split("/"))
+        if len(virtual) != 2 or not (0 <= virtual[0] < virtual[1]):
+            raise SystemExit("--virtual-rank R/N needs 0 <= R < N")
+    compact = use_gather or virtual is not None
+    tiles = abi.full_frame_tiles(fw, fh, TILE, TILE, virtual[0] if virtual else rank, virtual[1] if virtual else world, compact=compact)
     params = [sp.make_params(view, proj, tiles) for view, proj in views]
-    my_pixels = tiles.tile_count * TILE * TILE if use_gather else fw * fh
-    rays_per_frame_all = fw * fh  # every pixel of the frame is a ray (covered or not), summed over ranks
+    my_pixels = tiles.tile_count * TILE * TILE if compact else fw * fh
+    # every pixel of the frame is a ray (covered or not), summed over ranks; a virtual rank counts its own share only
+    rays_per_frame_all = my_pixels if virtual else fw * fh
 
     # ---- pre-pass (untimed): frag counters per view -> algorithmic bytes per frame ---------------------------------
     counts = torch.zeros((my_pixels, 3), dtype=torch.int32, device="cuda")
@@ -382,7 +496,10 @@ def job(args, env):
     else:
         # per-frame submission: as many targets as keep every target on ONE of the orbit views (like the slots of the batch path)
         nbuf = fpl * nbs if submit == "batch" else -(-fif // N_VIEWS) * N_VIEWS
-        bufs, my_rays = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)], fw * fh
+        if virtual:
+            bufs, my_rays = [torch.zeros((my_pixels, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)], my_pixels
+        else:
+            bufs, my_rays = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)], fw * fh
     # set-up: the per-target state of the start-order feedback (vkv_render itself never allocates)
     for t in bufs:
         ctx.register_target(t.data_ptr(), (fw, fh), tiles)
@@ -417,7 +534,7 @@ def job(args, env):
     # the same parameter blocks with gl_FragDepth written as well (frag:315-321; the reference's subpass always writes depth): timed in a
     # block of its own after the headline blocks, reported as ms_per_step_with_depth
     depth_bufs, batch_params_depth = None, None
-    if submit == "batch" and not use_gather and not args.no_depth_block:
+    if submit == "batch" and not use_gather and not args.no_depth_block and not virtual:
         depth_bufs = [torch.zeros((fh, fw), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
         batch_params_depth = []
         for view_i in range(N_VIEWS):
@@ -604,7 +721,7 @@ def job(args, env):
 
     # ---- one frame at a time (outside the timed region): the latency of a single frame's launch ---------------------
     single = None
-    if not use_gather:
+    if not use_gather and not virtual:
         # one target per view (a static camera per target, as in the timed loop), 2 untimed + 5 timed launches of a view back to back as in
         # the earlier rounds' figure; the median per view (one frame in eight also measures tile costs and is followed by the 20 us sort
         # kernel: inside the bracket, outside the median)
@@ -722,7 +839,10 @@ def job(args, env):
     except (OSError, ValueError, KeyError):
         pass
 
-    if world == 1 and not args.no_cpu_baseline:
+    if virtual:
+        out["virtual_rank"] = {"rank": virtual[0], "of": virtual[1], "tiles": int(tiles.tile_count), "rays_per_frame": my_pixels,
+                               "note": "one GPU rendering the tile share of rank %d of %d (compact schedule, no exchange): value and ms_per_step are this share's" % virtual}
+    if world == 1 and not args.no_cpu_baseline and not virtual:
         out["cpu_baseline"] = cpu_baseline(ctx, sp, v, params, (fw, fh), args.cpu_seconds, not args.no_verify_cpu, out)
     if native:
         gather.close()
@@ -821,7 +941,8 @@ def cpu_baseline(ctx, sp, v, params, frame, target_seconds, verify_cpu, out):
     dt1 = max(r1.seconds, 1e-9)
     quota = cpu_quota_cores()
     best = max(r.rays / max(r.seconds, 1e-9) for r in last) / 1e6  # the fastest single call of the last pass: what the pool delivers while the quota lasts
-    return {"value": round(rays / dt / 1e6, 4), "unit": "Mray/s", "cores": cores, "kind": "port",
+    # `cores` = the CPUs the figure can actually use: the cgroup's quota when one applies (host_cpus = what the container sees, threads = what ran)
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mray/s", "cores": (min(cores, int(math.ceil(quota))) if quota else cores), "host_cpus": cores, "threads": cores, "kind": "port",
             "value_1_thread": round(r1.rays / dt1 / 1e6, 5),
             # a container may see every CPU of the host and still be held to a CFS quota (cpu.max): the sustained figure is then the quota's, whatever
             # the thread count (the GPU boxes of this pool: 256 CPUs visible, quota 16 - a 2 M-ray view takes 6 ms when it fits a 100 ms period's

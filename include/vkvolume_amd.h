@@ -335,12 +335,18 @@ int vkv_transfer_function_bits(vkv_ctx *ctx, const uint8_t *d_transfer_function,
  * plain tile order / address arithmetic in registers, same bits) - vkv_prepare_render only moves that work to set-up time.  Call it
  * before capturing `stream` into a hipGraph: a launch that still has to create a table records and queries an event, which a capture
  * does not allow.  Captured launches replay with the parameter blocks they were captured with (camera included: capture one graph per
- * view, or re-capture); a captured vkv_render_batch keeps its argument blocks in pinned host memory of the context, because the graph's
- * copy node reads its source at every replay: the first 32 captured batch launches use slots set aside by vkv_create (nothing is allocated
- * during the capture), later ones a pinned block each (<= 96 KiB, allocated during the capture with the thread's capture mode relaxed for
- * that call).  vkv_trim and vkv_destroy free these blocks and the tables the captured launches point to: graphs captured before either
- * call must not be launched after it. */
+ * view, or re-capture).  A captured vkv_render_batch owns a slot of the context - a pinned host block (the graph's copy node reads its
+ * source at every replay) and a device block of its own (the copy's target and the kernels' argument pointer) - so graphs may be replayed on
+ * any stream, next to each other and next to live launches.  32 slots are set aside by vkv_create (nothing is allocated during such a
+ * capture), later ones are allocated during the capture (2 x 96 KiB, with the thread's capture mode relaxed for the calls).  A slot stays
+ * with the stream it was captured on until vkv_release_captured(stream); vkv_trim and vkv_destroy free the slots and the tables the
+ * captured launches point to: graphs captured before either call must not be launched after it. */
 int vkv_prepare_render(vkv_ctx *ctx, const VkvRenderParams *params, uint32_t count, void *stream);
+
+/* The graphs captured on `stream` so far have been destroyed (or will not be launched again): the slots their vkv_render_batch launches
+ * own return to the context.  A renderer that re-captures when its camera moves calls this after hipGraphExecDestroy and before the next
+ * capture; without it every capture takes new slots until vkv_trim.  Does not wait and frees nothing. */
+int vkv_release_captured(vkv_ctx *ctx, void *stream);
 
 /* Start-order feedback needs device state per render target (one uint32 cost and one uint32 order entry per tile of the
  * schedule): a renderer draws into the same swap-chain images again and again with a camera that moves little, so the tiles that took longest in the

@@ -558,7 +558,7 @@ def test_render_depth_attachment_and_blending(ctx, shell_scene, skipping_type, b
 # randomised configurations: every knob of the path drawn at random, HIP vs oracle
 # ------------------------------------------------------------------------------------------------------
 def fuzz_case(ctx, seed):
-    """One random configuration of the ray-march path (test_render_fuzz, tests/test_gpu_round4.py::test_launch_variants_fuzz): volume shape /
+    """One random configuration of the ray-march path (test_render_fuzz, tests/test_gpu_fuzz.py::test_launch_variants_fuzz): volume shape /
     content, voxel size and rotation, TF window, sampling and alpha factors, block size, skipping mode, ERT, gradient variant, clip distance,
     camera (sometimes inside the box, for seeds >= 24 beside it) and frame size.  Returns the oracle scene, the device volume, the parameter
     block, the oracle's frame and a label."""

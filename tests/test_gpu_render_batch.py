@@ -1,0 +1,217 @@
+"""GPU: vkv_render_batch against single launches (tile-per-workgroup and pulling kernels), launches without the per-pixel counters, the sample-count test output."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vkv_oracle as O
+from tests import helpers as T
+from tests.test_gpu_fullsize_oracle import build, orbit
+from tests.test_gpu_parity import compare_render, gpu_render, make_gpu_volume
+from vkvolume_amd import abi, lib, multigpu, volume as V
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "vkvolume_amd", "csrc", "vkv_offscreen")
+FLAG_WORD, AI_WORD, AG_WORD = 2048, 2052, 2308
+
+
+@pytest.mark.parametrize("skipping_type", [abi.SKIP_NONE, abi.SKIP_DISTANCE, abi.SKIP_ANISOTROPIC_DISTANCE])
+def test_render_batch_equals_single_launches(ctx, skipping_type):
+    """vkv_render_batch: n frames (different cameras, one of them another volume) in one launch == n vkv_render calls, bit for bit."""
+    opt = abi.VolumeOptions(**T.APP_TF)
+    scenes = [T.OracleScene(O.synth_volume((80, 72, 64), 1, 70 + k), opt, 4) for k in range(2)]
+    vols = [make_gpu_volume(ctx, s) for s in scenes]
+    for v, tf in vols:
+        V.ComputeDistanceMap(ctx).compute(v, tf, skipping_type)
+    size = (144, 80)
+    ro = abi.RenderOptions(skipping_type=skipping_type, clip_distance=1.0)
+    frames = []
+    for k, az in enumerate((0.0, 50.0, 111.0, 200.0, 290.0)):
+        scene, (v, tf) = scenes[k % 2], vols[k % 2]
+        view, proj = T.orbit(az, image_size=size)
+        p = V.VolumeRenderSubpass(ctx, v, ro, size).bind(scene.params(view, proj, size, ro))
+        frames.append((scene, p))
+    st = torch.cuda.current_stream().cuda_stream
+
+    def outputs():
+        return [dict(color=torch.full((size[1], size[0], 4), -1.0, dtype=torch.float32, device="cuda"),
+                     counts=torch.full((size[1], size[0], 3), 9, dtype=torch.int32, device="cuda"),
+                     depth=torch.full((size[1], size[0]), -1.0, dtype=torch.float32, device="cuda"),
+                     rgba8=torch.full((size[1], size[0], 4), 7, dtype=torch.uint8, device="cuda")) for _ in frames]
+
+    def point(p, o):
+        p.d_out_color, p.d_out_counts, p.d_out_depth, p.d_out_rgba8 = (o[k].data_ptr() for k in ("color", "counts", "depth", "rgba8"))
+
+    single, batch = outputs(), outputs()
+    for (scene, p), o in zip(frames, single):
+        point(p, o)
+        ctx.render(p, st)
+    plist = []
+    for (scene, p), o in zip(frames, batch):
+        q = abi.RenderParams.from_buffer_copy(p)
+        point(q, o)
+        plist.append(q)
+    ctx.render_batch(plist, st)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(single, batch)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), "frame %d: %s differs between the batch and the single launch" % (i, k)
+    ref = frames[3][0].render(frames[3][1])
+    assert np.array_equal(batch[3]["counts"].cpu().numpy().astype(np.uint32), ref.counts)
+    # a frame that needs another kernel variant is refused
+    bad = abi.RenderParams.from_buffer_copy(plist[1])
+    bad.options.early_ray_termination = 0
+    with pytest.raises(lib.VkvError):
+        ctx.render_batch([plist[0], bad], st)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("skipping_type", [abi.SKIP_NONE, abi.SKIP_DISTANCE, abi.SKIP_ANISOTROPIC_DISTANCE])
+def test_render_batch_pull_kernel_equals_single_launches(ctx, skipping_type):
+    """VkvTuning.batch_mode = 1 (resident workgroups, waves pull 8x8 units from per-XCD ticket counters): same frames, bit for bit."""
+    opt = abi.VolumeOptions(**T.APP_TF)
+    scene = T.OracleScene(O.synth_volume((96, 80, 72), 1, 91), opt, 4)
+    v, tf = make_gpu_volume(ctx, scene)
+    V.ComputeDistanceMap(ctx).compute(v, tf, skipping_type)
+    size = (208, 112)
+    ro = abi.RenderOptions(skipping_type=skipping_type, clip_distance=1.0)
+    st = torch.cuda.current_stream().cuda_stream
+    params = []
+    for az in (0.0, 40.0, 95.0, 170.0, 230.0, 300.0, 345.0):
+        view, proj = T.orbit(az, image_size=size)
+        params.append(V.VolumeRenderSubpass(ctx, v, ro, size).bind(scene.params(view, proj, size, ro)))
+
+    def outputs():
+        return [dict(color=torch.full((size[1], size[0], 4), -1.0, dtype=torch.float32, device="cuda"),
+                     counts=torch.full((size[1], size[0], 3), 9, dtype=torch.int32, device="cuda"),
+                     depth=torch.full((size[1], size[0]), -1.0, dtype=torch.float32, device="cuda"),
+                     rgba8=torch.full((size[1], size[0], 4), 7, dtype=torch.uint8, device="cuda")) for _ in params]
+
+    def point(p, o):
+        p.d_out_color, p.d_out_counts, p.d_out_depth, p.d_out_rgba8 = (o[k].data_ptr() for k in ("color", "counts", "depth", "rgba8"))
+
+    single, pulled = outputs(), outputs()
+    for p, o in zip(params, single):
+        point(p, o)
+        ctx.render(p, st)
+    plist = []
+    for p, o in zip(params, pulled):
+        q = abi.RenderParams.from_buffer_copy(p)
+        point(q, o)
+        plist.append(q)
+    ctx.set_tuning(batch_mode=1)
+    try:
+        for _ in range(2):  # twice: the ticket counters are re-armed by every launch
+            ctx.render_batch(plist, st)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_tuning(batch_mode=0)
+    for i, (a, b) in enumerate(zip(single, pulled)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), "frame %d: %s differs between the pull kernel and the single launch" % (i, k)
+
+
+@pytest.mark.parametrize("skipping_type", [abi.SKIP_BLOCK, abi.SKIP_DISTANCE, abi.SKIP_ANISOTROPIC_DISTANCE])
+def test_launch_without_counters_renders_the_same_frame(ctx, skipping_type):
+    """A launch without d_out_counts (what a renderer submits: the reference keeps the per-pixel sample counters only in its test modes,
+    src/volume_render_subpass.h Test::NumTextureSamples) runs the integrator WITHOUT the three counters (kLeanNoCounts).  Its float
+    colour, depth and RGBA8 must be the counted launch's bits - through vkv_render and through vkv_render_batch - and the oracle's."""
+    opt = abi.VolumeOptions(**T.APP_TF)
+    scene = T.OracleScene(O.synth_volume((88, 72, 64), 1, 0x5EED0003), opt, 4)
+    v, tf = make_gpu_volume(ctx, scene)
+    V.ComputeDistanceMap(ctx).compute(v, tf, skipping_type)
+    size = (160, 96)
+    ro = abi.RenderOptions(skipping_type=skipping_type, clip_distance=1.0, early_ray_termination=True)
+    st = torch.cuda.current_stream().cuda_stream
+    plist = []
+    for az in (10.0, 77.0, 200.0):
+        view, proj = T.orbit(az, image_size=size)
+        plist.append(V.VolumeRenderSubpass(ctx, v, ro, size).bind(scene.params(view, proj, size, ro)))
+
+    def outputs(with_counts):
+        return [dict(color=torch.full((size[1], size[0], 4), -1.0, dtype=torch.float32, device="cuda"),
+                     depth=torch.full((size[1], size[0]), -1.0, dtype=torch.float32, device="cuda"),
+                     rgba8=torch.full((size[1], size[0], 4), 7, dtype=torch.uint8, device="cuda"),
+                     counts=torch.full((size[1], size[0], 3), 9, dtype=torch.int32, device="cuda") if with_counts else None) for _ in plist]
+
+    def point(p, o):
+        q = abi.RenderParams.from_buffer_copy(p)
+        q.d_out_color, q.d_out_depth, q.d_out_rgba8 = o["color"].data_ptr(), o["depth"].data_ptr(), o["rgba8"].data_ptr()
+        q.d_out_counts = o["counts"].data_ptr() if o["counts"] is not None else None
+        return q
+
+    counted = outputs(True)
+    for p, o in zip(plist, counted):
+        ctx.render(point(p, o), st)
+    torch.cuda.synchronize()
+    assert int(counted[0]["counts"][..., 0].sum().item()) > 0 and int(counted[0]["counts"][..., 1].sum().item()) > 0
+    try:
+        for tables in (2, 1):        # one table entry per voxel index / the two-level tables: each has its own kernel without counters
+            ctx.set_tuning(address_tables=tables)
+            single, batch = outputs(False), outputs(False)
+            for p, o in zip(plist, single):
+                ctx.render(point(p, o), st)
+            ctx.render_batch([point(p, o) for p, o in zip(plist, batch)], st)
+            torch.cuda.synchronize()
+            for i in range(len(plist)):
+                for k in ("color", "depth", "rgba8"):
+                    assert torch.equal(counted[i][k], single[i][k]), "tables %d frame %d: %s of the launch without counters differs" % (tables, i, k)
+                    assert torch.equal(counted[i][k], batch[i][k]), "tables %d frame %d: %s of the batch launch without counters differs" % (tables, i, k)
+    finally:
+        ctx.set_tuning(address_tables=2)
+    ref = scene.render(plist[1], want_rgba8=True)
+    assert np.array_equal(single[1]["rgba8"].cpu().numpy(), ref.rgba8), "RGBA8 of the launch without counters differs from the oracle's"
+    assert np.array_equal(counted[1]["counts"].cpu().numpy().astype(np.uint32), ref.counts)
+
+
+@pytest.mark.parametrize("skipping_type", [abi.SKIP_BLOCK, abi.SKIP_DISTANCE, abi.SKIP_ANISOTROPIC_DISTANCE])
+def test_sample_count_test_mode_without_a_counter_buffer(ctx, skipping_type):
+    """Test::NumTextureSamples (frag:324-334: the pixel's colour is (volume samples + map probes) / n_steps_max) with early ray
+    termination ON and NO d_out_counts - the reference's GUI switches the test mode independently of ERT and of the skipping type
+    (src/volume_render.cpp:539).  The launchers run the loop without the per-pixel counters for launches that have no counter buffer;
+    this mode needs them whatever the outputs are (every marched pixel came out (0, 0, 0, 1)).  Single launch and batch
+    launch, both address-table kinds, float colour and RGBA8 against the oracle."""
+    opt = abi.VolumeOptions(**T.APP_TF)
+    scene = T.OracleScene(O.synth_volume((88, 72, 64), 1, 0x5EED0004), opt, 4)
+    v, tf = make_gpu_volume(ctx, scene)
+    V.ComputeDistanceMap(ctx).compute(v, tf, skipping_type)
+    size = (160, 96)
+    ro = abi.RenderOptions(skipping_type=skipping_type, clip_distance=1.0, early_ray_termination=True, test=abi.TEST_NUM_TEXTURE_SAMPLES)
+    st = torch.cuda.current_stream().cuda_stream
+    plist, refs = [], []
+    for az in (10.0, 200.0):
+        view, proj = T.orbit(az, image_size=size)
+        params = scene.params(view, proj, size, ro)
+        plist.append(V.VolumeRenderSubpass(ctx, v, ro, size).bind(params))
+        refs.append(scene.render(params, want_rgba8=True))
+    assert refs[0].counts[..., 0].sum() > 0 and refs[0].counts[..., 1].sum() > 0
+    assert float(refs[0].color[..., 0].max()) > 0.0  # the grey level of the count output
+
+    def outputs():
+        return [dict(color=torch.full((size[1], size[0], 4), -1.0, dtype=torch.float32, device="cuda"),
+                     rgba8=torch.full((size[1], size[0], 4), 7, dtype=torch.uint8, device="cuda")) for _ in plist]
+
+    def point(p, o):
+        q = abi.RenderParams.from_buffer_copy(p)
+        q.d_out_color, q.d_out_rgba8, q.d_out_counts, q.d_out_depth = o["color"].data_ptr(), o["rgba8"].data_ptr(), None, None
+        return q
+
+    try:
+        for tables in (2, 1, 0):
+            ctx.set_tuning(address_tables=tables)
+            single, batch = outputs(), outputs()
+            for p, o in zip(plist, single):
+                ctx.render(point(p, o), st)
+            ctx.render_batch([point(p, o) for p, o in zip(plist, batch)], st)
+            torch.cuda.synchronize()
+            for i, ref in enumerate(refs):
+                for name, got in (("vkv_render", single[i]), ("vkv_render_batch", batch[i])):
+                    assert np.array_equal(got["color"].cpu().numpy(), ref.color), "%s, tables %d, view %d: count colour differs from the oracle" % (name, tables, i)
+                    assert np.array_equal(got["rgba8"].cpu().numpy(), ref.rgba8), "%s, tables %d, view %d: RGBA8 differs from the oracle" % (name, tables, i)
+    finally:
+        ctx.set_tuning(address_tables=2)

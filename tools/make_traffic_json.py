@@ -48,9 +48,9 @@ def main():
     if simd_cycles and all(avg.get(k) for k in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_INT32")):
         import subprocess
         model = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "valu_issue_model.py")], text=True))
-        n = {"CVT": avg["SQ_INSTS_VALU_CVT"], "FMA_F32": avg["SQ_INSTS_VALU_FMA_F32"], "INT32": avg["SQ_INSTS_VALU_INT32"]}
-        n["OTHER"] = avg["SQ_INSTS_VALU"] - sum(n.values())
-        issue = sum(n[k] * model[k]["cycles_per_instruction"] for k in n) / simd_cycles
+        insts = {"CVT": avg["SQ_INSTS_VALU_CVT"], "FMA_F32": avg["SQ_INSTS_VALU_FMA_F32"], "INT32": avg["SQ_INSTS_VALU_INT32"]}
+        insts["OTHER"] = avg["SQ_INSTS_VALU"] - sum(insts.values())
+        issue = sum(insts[k] * model[k]["cycles_per_instruction"] for k in insts) / simd_cycles
     if avg.get("SQ_WAIT_ANY") and avg.get("SQ_WAVE_CYCLES"):
         wait = avg["SQ_WAIT_ANY"] / avg["SQ_WAVE_CYCLES"]
         if simd_cycles:

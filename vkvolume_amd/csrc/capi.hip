@@ -403,13 +403,35 @@ static void drop_tables(vkv_ctx *ctx)
 	ctx->table_used = 0;
 }
 
-// the pinned argument blocks of captured vkv_render_batch launches: the graphs that read them are the caller's, who promised not to replay them
+// the argument blocks of captured vkv_render_batch launches: the graphs that read them are the caller's, who promised not to replay them
 static void drop_capture_blocks(vkv_ctx *ctx)
 {
-	for (void *p : ctx->capture_overflow)
-		(void) hipHostFree(p);
-	ctx->capture_overflow.clear();
-	ctx->capture_slots_used = 0;
+	std::vector<vkv_ctx::CaptureSlot> kept;
+	for (auto &c : ctx->capture_slots)
+	{
+		if (c.pooled)
+		{
+			c.in_use = false, c.owner = nullptr;
+			kept.push_back(c);
+		}
+		else
+		{
+			(void) hipHostFree(c.pinned);
+			(void) hipFree(c.device);
+		}
+	}
+	ctx->capture_slots.swap(kept);
+}
+
+int vkv_release_captured(vkv_ctx *ctx, void *stream)
+{
+	if (!ctx)
+		return VKV_E_INVALID_ARGUMENT;
+	std::lock_guard<std::mutex> lock(ctx->mutex);
+	for (auto &c : ctx->capture_slots)
+		if (c.in_use && c.owner == (hipStream_t) stream)
+			c.in_use = false, c.owner = nullptr;
+	return VKV_OK;
 }
 
 int vkv_trim(vkv_ctx *ctx)
@@ -464,9 +486,20 @@ int vkv_create(int device_ordinal, vkv_ctx **out_ctx)
 		void *m = nullptr;
 		if (hipHostMalloc(&m, ctx->arena_bytes - ctx->table_base, hipHostMallocDefault) == hipSuccess)
 			ctx->table_mirror = static_cast<uint8_t *>(m);        // (without it uploads fall back to the entry's own vector + a wait)
-		void *cp = nullptr;
-		if (hipHostMalloc(&cp, (size_t) kCaptureSlots * kCaptureSlotBytes, hipHostMallocDefault) == hipSuccess)
-			ctx->capture_pool = static_cast<uint8_t *>(cp);        // (without it vkv_render_batch cannot be captured into a hipGraph)
+		void *cp = nullptr, *cd = nullptr;
+		if (hipHostMalloc(&cp, (size_t) kCaptureSlots * kCaptureSlotBytes, hipHostMallocDefault) == hipSuccess &&
+		    hipMalloc(&cd, (size_t) kCaptureSlots * kCaptureSlotBytes) == hipSuccess)
+		{        // (without them a captured vkv_render_batch allocates its blocks during the capture)
+			ctx->capture_pool = static_cast<uint8_t *>(cp), ctx->capture_pool_device = static_cast<uint8_t *>(cd);
+			for (uint32_t i = 0; i < kCaptureSlots; ++i)
+			{
+				vkv_ctx::CaptureSlot c;
+				c.pinned = ctx->capture_pool + (size_t) i * kCaptureSlotBytes, c.device = ctx->capture_pool_device + (size_t) i * kCaptureSlotBytes, c.pooled = true;
+				ctx->capture_slots.push_back(c);
+			}
+		}
+		else if (cp)
+			(void) hipHostFree(cp);
 	}
 	*out_ctx      = ctx;        // the caller's current device is left as it is: every entry point switches to ctx->device itself
 	return VKV_OK;
@@ -491,6 +524,8 @@ void vkv_destroy(vkv_ctx *ctx)
 		drop_capture_blocks(ctx);
 		if (ctx->capture_pool)
 			(void) hipHostFree(ctx->capture_pool);
+		if (ctx->capture_pool_device)
+			(void) hipFree(ctx->capture_pool_device);
 		if (ctx->table_mirror)
 			(void) hipHostFree(ctx->table_mirror);
 		(void) hipFree(ctx->arena);

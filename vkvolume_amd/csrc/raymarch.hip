@@ -449,25 +449,44 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 		hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
 		if (hipStreamIsCapturing(s, &capture) == hipSuccess && capture == hipStreamCaptureStatusActive)
 		{
-			// vkv_create set kCaptureSlots pinned slots aside, so that the usual capture allocates nothing.  Beyond them: a pinned block of its
-			// own, allocated with this thread's capture mode relaxed for the one call (an allocation under the global / thread-local mode
-			// would invalidate the capture).  vkv_trim and vkv_destroy give all of them back.
+			// A captured launch gets a slot of its own - pinned source AND device target of the upload: the graph can be replayed on any stream,
+			// concurrently with other graphs and with live launches on the capture stream, so it must not go through that stream's scratch block
+			// (whose users are serialised by the stream, which a replay elsewhere is not).  vkv_create set kCaptureSlots slots aside, so that the
+			// usual capture allocates nothing; beyond them a slot is allocated here, with this thread's capture mode relaxed for the calls (an
+			// allocation under the global / thread-local mode would invalidate the capture).  Slots return with vkv_release_captured(stream),
+			// vkv_trim and vkv_destroy.
 			std::lock_guard<std::mutex> lock(ctx->mutex);
-			void *                      pinned = nullptr;
-			if (ctx->capture_pool && ctx->capture_slots_used < kCaptureSlots)
-				pinned = ctx->capture_pool + (size_t) ctx->capture_slots_used++ * kCaptureSlotBytes;
-			else
+			vkv_ctx::CaptureSlot *      slot = nullptr;
+			for (auto &c : ctx->capture_slots)
+				if (!c.in_use)
+				{
+					slot = &c;
+					break;
+				}
+			if (!slot)
 			{
+				vkv_ctx::CaptureSlot c;
+				void *               hp = nullptr, *dp = nullptr;
 				hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
 				(void) hipThreadExchangeStreamCaptureMode(&mode);
-				const hipError_t ea = hipHostMalloc(&pinned, upload.size(), hipHostMallocDefault);
+				const hipError_t ea = hipHostMalloc(&hp, kCaptureSlotBytes, hipHostMallocDefault);
+				const hipError_t eb = ea == hipSuccess ? hipMalloc(&dp, kCaptureSlotBytes) : ea;
 				(void) hipThreadExchangeStreamCaptureMode(&mode);
-				if (ea != hipSuccess || !pinned)
-					return set_error(ctx, VKV_E_UNSUPPORTED, "render_batch: no pinned block for the argument upload of a captured launch: %s", hipGetErrorString(ea));
-				ctx->capture_overflow.push_back(pinned);
+				if (ea != hipSuccess || eb != hipSuccess || !hp || !dp)
+				{
+					if (hp)
+						(void) hipHostFree(hp);
+					return set_error(ctx, VKV_E_UNSUPPORTED, "render_batch: no argument block for a captured launch: %s", hipGetErrorString(ea != hipSuccess ? ea : eb));
+				}
+				c.pinned = static_cast<uint8_t *>(hp), c.device = static_cast<uint8_t *>(dp);
+				ctx->capture_slots.push_back(c);
+				slot = &ctx->capture_slots.back();
 			}
-			std::memcpy(pinned, upload.data(), upload.size());
-			upload_src = pinned;
+			slot->in_use = true, slot->owner = s;
+			std::memcpy(slot->pinned, upload.data(), upload.size());
+			upload_src = slot->pinned;
+			d_heads    = reinterpret_cast<uint32_t *>(slot->device);
+			d_frames   = reinterpret_cast<RayMarchArgs *>(slot->device + kPullHeadsBytes);
 		}
 	}
 	const hipError_t e = hipMemcpyAsync(d_heads, upload_src, upload.size(), hipMemcpyHostToDevice, s);

@@ -182,9 +182,19 @@ struct vkv_ctx
 	uint8_t *           table_mirror = nullptr;  // pinned host twin of the table region: the source of every asynchronous table upload
 	std::vector<void *> overflow;                // hipMalloc blocks set-up calls took for tables when the region was full; freed by vkv_trim / vkv_destroy
 	std::vector<void *> overflow_scratch;        // ... for scratch blocks beyond the reserve; freed by vkv_destroy
-	uint8_t *           capture_pool = nullptr;  // pinned slots for the argument blocks of vkv_render_batch launches captured into hipGraphs (the graph's
-	uint32_t            capture_slots_used = 0;  // copy node reads its source at every replay); handed out in turn, all returned by vkv_trim / vkv_destroy
-	std::vector<void *> capture_overflow;        // pinned blocks of captured launches beyond kCaptureSlots (allocated during the capture); same lifetime
+	// Argument blocks of vkv_render_batch launches captured into hipGraphs.  A captured launch owns a SLOT: a pinned host block (the graph's copy
+	// node reads its source at every replay) and a device block of its own (the copy's target and the kernels' argument pointer: a graph may be
+	// replayed on any stream, next to other graphs and to live launches, so it must not share the capture stream's scratch block).  kCaptureSlots
+	// slots are set aside by vkv_create; later ones are allocated during the capture.  A slot belongs to the stream it was captured on until
+	// vkv_release_captured(stream), vkv_trim or vkv_destroy.
+	struct CaptureSlot
+	{
+		uint8_t *   pinned = nullptr, *device = nullptr;
+		hipStream_t owner = nullptr;
+		bool        in_use = false, pooled = false;
+	};
+	uint8_t *                capture_pool = nullptr, *capture_pool_device = nullptr;
+	std::vector<CaptureSlot> capture_slots;
 	std::unordered_map<hipStream_t, uint8_t *> scratch;        // stream -> kScratchBytes of device memory
 	std::vector<uint8_t *>                     free_scratch;   // blocks given back by vkv_release_stream
 	// an immutable device table with its host copy (the source of the asynchronous upload: it must outlive the call)

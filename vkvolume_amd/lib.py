@@ -19,7 +19,7 @@ EXPORTS = [
     "vkv_packed_volume_bytes", "vkv_pack_volume", "vkv_transfer_function_bits", "vkv_transfer_function_tables",
     "vkv_occupied_voxel_count", "vkv_load_header", "vkv_load_data", "vkv_convert_volume", "vkv_gather_tiles", "vkv_assemble_frame",
     "vkv_assemble_frames", "vkv_get_tuning", "vkv_set_tuning", "vkv_prepare_render", "vkv_register_target", "vkv_forget_target",
-    "vkv_release_stream", "vkv_trim",
+    "vkv_release_stream", "vkv_trim", "vkv_release_captured",
 ]
 # include/vkvolume_amd_debug.h (diagnostics: tools/ and the exhaustive numerics tests)
 DEBUG_EXPORTS = ["vkv_debug_trace", "vkv_debug_tile_orders", "vkv_debug_check"]
@@ -77,6 +77,7 @@ def load():
     L.vkv_forget_target.argtypes = [vp, vp]
     L.vkv_release_stream.argtypes = [vp, vp]
     L.vkv_trim.argtypes = [vp]
+    L.vkv_release_captured.argtypes = [vp, vp]
     L.vkv_debug_trace.argtypes = [vp, vp]
     L.vkv_debug_tile_orders.argtypes = [vp, vp, u32, u32]
     L.vkv_debug_check.argtypes = [vp, i32, u32, C.c_uint64, vp, vp]
@@ -200,6 +201,10 @@ class Context:
     def trim(self):
         """vkv_trim: wait for the device, drop every cached table, empty the arena's table region"""
         self.check(self._lib.vkv_trim(self.handle))
+
+    def release_captured(self, stream):
+        """vkv_release_captured: the argument slots of the vkv_render_batch launches captured on `stream` return to the context"""
+        self.check(self._lib.vkv_release_captured(self.handle, stream))
 
     def render_rc(self, params, stream=0):
         """Like render() but returns the status code instead of raising (error-path tests)."""
