@@ -21,10 +21,10 @@ pytestmark = pytest.mark.gpu
 COLOR_TOL = 1e-5
 
 
-def build(ctx, extent, seed, skip, voxel=(1.0, 1.0, 1.0), axis_angle=(1.0, 0.0, 0.0, 0.0), kind=1, options=None):
+def build(ctx, extent, seed, skip, voxel=(1.0, 1.0, 1.0), axis_angle=(1.0, 0.0, 0.0, 0.0), kind=1, options=None, block=4):
     v = V.Volume(ctx)
     v.options = options or abi.VolumeOptions(intensity_min=0.1, intensity_max=1.0, gradient_min=0.0, gradient_max=0.2)
-    v.load_synthetic(extent, kind=kind, seed=seed)
+    v.load_synthetic(extent, kind=kind, seed=seed, distance_map_block_size=block)
     V.default_scene(v, voxel, axis_angle)
     tf = v.get_transfer_function_uniform()
     V.ComputeGradientMap(ctx).compute(v, tf)
@@ -131,6 +131,27 @@ def test_c3_full_size_against_the_oracle(ctx):
     iso = v.distance_maps[0].cpu().numpy()
     assert np.array_equal(iso, O.distance_map(occ)), "isotropic distance map (whole map) differs from the oracle"
     check_frames(ctx, v, tf, tex, vol, grad, [iso], abi.SKIP_DISTANCE, (1920, 1080), 8, (0.0, 135.0))
+
+
+def test_c3_whole_occupancy_and_distance_maps_at_block_sizes_3_5_6(ctx):
+    """The block sizes of the reference's sweep that are not a power of two (scripts/benchmark.py:27-34; 3 is where its best frame rates are):
+    the WHOLE occupancy map of the bench volume against the oracle for each of them (k_occupancy_map_rows: cells that straddle dwords, 9 / 25 /
+    36 voxel rows per cell row, the ragged last cell layer), the isotropic distance map behind it, and a frame per block size."""
+    host = None
+    for block in (3, 5, 6):
+        v, tf = build(ctx, (1024, 1024, 795), 0xC0FFEE03, abi.SKIP_DISTANCE, (0.0003, 0.0003, 0.0007), (1.0, 0.0, 0.0, 90.0), block=block)
+        if host is None:
+            host = v.volume.cpu().numpy(), v.gradient.cpu().numpy(), v.transfer_function.cpu().numpy()
+        vol, grad, tex = host
+        iso = v.distance_maps[0].cpu().numpy()
+        occ = v_occupancy(v, tf)
+        ref = O.occupancy_map(vol, grad, tex, tf, block)
+        assert occ.shape == ref.shape and np.array_equal(occ, ref), "block %d: whole occupancy map differs from the oracle" % block
+        assert np.array_equal(iso, O.distance_map(ref)), "block %d: isotropic distance map (whole map) differs from the oracle" % block
+        V.ComputeDistanceMap(ctx).compute(v, tf, abi.SKIP_DISTANCE)
+        torch.cuda.synchronize()
+        check_frames(ctx, v, tf, tex, vol, grad, [iso], abi.SKIP_DISTANCE, (1920, 1080), 16, (45.0,))
+        del v
 
 
 def test_c3_literal_1024_cubed_against_the_oracle(ctx):

@@ -275,6 +275,20 @@ __global__ void __launch_bounds__(256) k_tf_bits(const uint8_t *__restrict__ tf_
 	bits[w] = v;
 }
 
+// Which INTENSITY bytes can be occupied at all (alpha > 0 for some gradient byte): 256 bits behind the bit table (words 2048..2055).  A voxel
+// whose intensity is not among them is empty whatever its gradient: k_occupancy_map_waves tests the lowest such byte against whole batches of
+// volume dwords before it touches the gradient map or the table.
+__global__ void __launch_bounds__(256) k_tf_columns(uint32_t *__restrict__ bits)
+{
+	const uint32_t v = threadIdx.x;        // intensity byte = texture column
+	uint32_t       any = 0;
+	for (uint32_t g = 0; g < 256; ++g)
+		any |= bits[g * 8u + (v >> 5)];
+	const unsigned long long m = __builtin_amdgcn_ballot_w64(((any >> (v & 31u)) & 1u) != 0u);
+	if ((v & 63u) == 0u)
+		bits[2048u + (v >> 5)] = (uint32_t) m, bits[2048u + (v >> 5) + 1u] = (uint32_t) (m >> 32);
+}
+
 // Block = 256 threads = 256 consecutive voxels in x of one cell row (cy, cz); it walks the by*bz voxel rows of
 // that cell row, every load being a coalesced 64-byte segment per wave, ORs "occupied" into one LDS flag per cell.
 // GRAD: 0 = use_gradient false (gradient = 1.0), 1 = precomputed map, 2 = on-the-fly tetrahedron.
@@ -338,6 +352,152 @@ __global__ void __launch_bounds__(256) k_occupancy_map_dword_any(const uint8_t *
 	__syncthreads();
 	for (int c = threadIdx.x; c < cpb && c0 + c < mw; c += 256)
 		map[((size_t) cz * mh + cy) * (size_t) mw + (size_t) (c0 + c)] = s_cell[c] ? 0 : 255;        // OCCUPIED = 0, EMPTY = 255
+}
+
+// Any block width at streaming rate (round 5; the sweep's block sizes 2, 3, 5, 6 - and 3 is where the reference publishes its best frame
+// rates).  What the two kernels around this one lose on small or odd blocks: a workgroup per cell row streams by * bz voxel rows (9 for a 3^3
+// block: 18 KB) for 8 KB of staged bit table, meets at barriers for every cell row, and fetches rows in eights, so a 9-row cell pays for 16.
+//   * The map is first filled with EMPTY (255) and the kernel only ever stores OCCUPIED (0): any number of lanes may then hit the same cell
+//     in any order, so nothing has to be aligned to cells and nothing is exchanged.
+//   * Every WAVE is on its own: it owns 64 consecutive dwords (256 voxels) in x and walks `cy_per_wave` consecutive cell rows of them; the
+//     bit table is staged once per workgroup, i.e. once per >= 256 KB of voxels, and that is the kernel's only barrier.
+//   * A wave fetches exactly ROWS voxel rows per batch - ROWS / CRB rows of each of CRB cell rows (the launcher picks ROWS from {8, 9, 10, 12}
+//     so that by * bz rows leave the fewest idle slots: 9 -> 9, 16 -> 8, 25 -> 27, 36 -> 36, 49 -> 50; cells of fewer than eight rows are
+//     taken CRB = 2, 4 or 8 cell rows at a time: a 2^3 block's four rows two cell rows at a time).
+//   * Short circuit: the VOLUME dwords of a batch come first.  If no byte of them reaches the lowest intensity the transfer function gives any
+//     alpha to (k_tf_columns; four bytes per SWAR test), every voxel of the batch is empty whatever its gradient: the wave goes on to the next
+//     batch without reading the gradient map or the table - on the bench volume that is most batches, i.e. close to half the bytes
+//     occupancy_map.comp reads.  Otherwise the gradient rows follow and every voxel is looked up (same result either way: the test is exact).
+//   * A lane ORs the occupied bits of its four voxels over a cell row's rows and stores a 0 into the cells of the voxels that have one (a
+//     lane's four voxels lie in the same cells in every cell row: the x -> cell division is done once).
+// a wave-uniform 64-bit value moved into scalar registers (the compiler does not always see the uniformity through the loops' counters)
+__device__ __forceinline__ size_t uniform_u64(size_t x)
+{
+	const uint32_t lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) x), hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (x >> 32));
+	return ((size_t) hi << 32) | lo;
+}
+
+template <int GRAD, int ROWS, int CRB>
+__global__ void __launch_bounds__(256) k_occupancy_map_waves(const uint8_t *__restrict__ vol, const uint8_t *__restrict__ grad, const uint32_t *__restrict__ tf_bits,
+                                                             uint8_t *__restrict__ map, int W, int H, int D, int mw, int mh, int bx, int by, int bz, uint32_t spans_x,
+                                                             int cy_per_wave)
+{
+	__shared__ uint32_t s_bits[2048];
+	for (int i = threadIdx.x; i < 2048; i += 256)
+		s_bits[i] = tf_bits[i];
+	// lowest intensity byte with any alpha (256: none - the map stays empty; 0: no short circuit possible)
+	uint32_t vmin = 256u;
+	for (int w = 7; w >= 0; --w)
+	{
+		const uint32_t m = tf_bits[2048 + w];        // wave-uniform scalar loads
+		if (m)
+			vmin = (uint32_t) w * 32u + (uint32_t) __builtin_ctz(m);
+	}
+	__syncthreads();
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint32_t task = blockIdx.x * 4u + wave;        // (span of 64 dwords in x, group of cell rows); blockIdx.y = cell slice
+	const int      xd = (int) (task % spans_x) * 64 + (int) lane, cy0 = (int) (task / spans_x) * cy_per_wave, cz = (int) blockIdx.y;
+	if (cy0 >= mh || xd * 4 >= W || vmin == 256u)
+		return;
+	const uint32_t xo = (uint32_t) xd * 4u;        // the lane's byte offset inside a row: scalar row base + 32-bit lane offset per load
+	// "some byte of x is >= vmin" for four bytes at once: byte + (256 - vmin) carries out of its eight bits.  The low seven bits are added
+	// per byte (no carry between bytes: 127 + 127 < 256), the carry out of bit 7 is then majority(byte's bit 7, the constant's bit 7, the
+	// sum's bit 7), i.e. an OR or an AND with the constant's bit 7 known
+	const uint32_t cadd = 256u - vmin, c_hi = cadd >> 7, c_lo4 = (cadd & 127u) * 0x01010101u;
+	// the cells of this lane's four voxels: cell0 = the first voxel's, step bit i = voxel i lies in the next cell (one store per cell)
+	uint32_t cell0 = (uint32_t) (4 * xd) / (uint32_t) bx, step = 0u;
+	{
+		uint32_t in = (uint32_t) (4 * xd) - cell0 * (uint32_t) bx;
+#pragma unroll
+		for (int i = 1; i < 4; ++i)
+			if (++in == (uint32_t) bx)
+				in = 0, step |= 1u << i;
+	}
+	const int    z_end = min((cz + 1) * bz, D), nz = z_end - cz * bz;
+	const int    cy_end = min(cy0 + cy_per_wave, mh);
+	const size_t zs = (size_t) H * (size_t) W;
+	for (int cy = cy0; cy < cy_end; cy += CRB)
+	{
+		uint32_t occ[CRB];
+#pragma unroll
+		for (int k = 0; k < CRB; ++k)
+			occ[k] = 0;
+		const int ny     = min((cy + 1) * by, H) - cy * by;        // CRB == 1: rows of this cell row in y (whole cells otherwise)
+		const int n_rows = CRB == 1 ? ny * nz : ROWS;
+		int       ry = 0, rz = 0;        // CRB == 1: the (y, z) of the next row inside the cell row (wave-uniform counters instead of a division per load)
+		for (int r0 = 0; r0 < n_rows; r0 += ROWS)
+		{
+			size_t   row[ROWS];
+			uint32_t v4[ROWS];
+#pragma unroll
+			for (int j = 0; j < ROWS; ++j)
+			{
+				if (CRB == 1)
+				{
+					row[j] = (size_t) (cz * bz + rz) * zs + (size_t) (cy * by + ry) * (size_t) W;
+					if (!(rz == nz - 1 && ry == ny - 1))        // the tail repeats the last row (idempotent OR; the line is in L1)
+					{
+						if (++ry == ny)
+							ry = 0, ++rz;
+					}
+				}
+				else
+				{        // by * bz = ROWS / CRB rows per cell row; the rows a ragged last cell row / slice does not have repeat its last one
+					constexpr int kPer = ROWS / CRB;
+					const int     c = min(cy + j / kPer, cy_end - 1), r = j % kPer;        // (a group's last batch repeats its last cell row)
+					row[j]          = (size_t) (cz * bz + min(r / by, nz - 1)) * zs + (size_t) min(c * by + r % by, H - 1) * (size_t) W;
+				}
+				row[j] = uniform_u64(row[j]);        // wave-uniform by construction: a scalar base for the two loads of this row
+				v4[j]  = *reinterpret_cast<const uint32_t *>(vol + row[j] + xo);
+			}
+			if (vmin != 0u)
+			{
+				uint32_t acc = 0;
+#pragma unroll
+				for (int j = 0; j < ROWS; ++j)
+				{
+					const uint32_t sum = (v4[j] & 0x7f7f7f7fu) + c_lo4;
+					acc |= c_hi ? (v4[j] | sum) : (v4[j] & sum);
+				}
+				if (__builtin_amdgcn_ballot_w64((acc & 0x80808080u) != 0u) == 0ull)
+					continue;        // the whole batch of the whole wave is below the transfer function's threshold
+			}
+			uint32_t g4[ROWS];
+#pragma unroll
+			for (int j = 0; j < ROWS; ++j)
+				g4[j] = GRAD == 1 ? *reinterpret_cast<const uint32_t *>(grad + row[j] + xo) : 0xffffffffu;
+#pragma unroll
+			for (int j = 0; j < ROWS; ++j)
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+				{
+					const uint32_t bit = ((g4[j] >> (8 * i)) & 255u) * 256u + ((v4[j] >> (8 * i)) & 255u);
+					occ[CRB == 1 ? 0 : j / (ROWS / CRB)] |= ((s_bits[bit >> 5] >> (bit & 31u)) & 1u) << i;
+				}
+		}
+#pragma unroll
+		for (int k = 0; k < CRB; ++k)
+		{
+			if (cy + k >= cy_end || occ[k] == 0u)
+				continue;
+			uint8_t *out = map + ((size_t) cz * mh + (size_t) (cy + k)) * (size_t) mw;
+			// OR the bits of the voxels that share a cell, then one store per occupied cell
+			uint32_t c = cell0, any = 0u;
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+			{
+				if (i > 0 && ((step >> i) & 1u))
+				{
+					if (any)
+						out[c] = 0;        // OCCUPIED
+					++c, any = 0u;
+				}
+				any |= (occ[k] >> i) & 1u;
+			}
+			if (any)
+				out[c] = 0;
+		}
+	}
 }
 
 template <int GRAD>
@@ -1294,6 +1454,7 @@ int launch_occupancy_map(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_gr
 		return VKV_E_UNSUPPORTED;
 	uint32_t *d_bits = reinterpret_cast<uint32_t *>(scratch + kTfBitsOffset);
 	hipLaunchKernelGGL(k_tf_bits, dim3(8), dim3(256), 0, s, d_tf, d_bits);
+	hipLaunchKernelGGL(k_tf_columns, dim3(1), dim3(256), 0, s, d_bits);        // words 2048..2055 of the scratch's table area
 	// src/compute_distance_map.cpp:110-113
 	const int bx = (int) ((e.width + me.width - 1) / me.width), by = (int) ((e.height + me.height - 1) / me.height),
 	          bz = (int) ((e.depth + me.depth - 1) / me.depth);
@@ -1304,7 +1465,8 @@ int launch_occupancy_map(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_gr
 	const dim3 grid(blocks_x * me.height, me.depth);
 	const int W = (int) e.width, H = (int) e.height, D = (int) e.depth, mw = (int) me.width, mh = (int) me.height, md = (int) me.depth;
 	const bool precomputed = tf->use_gradient && d_grad;
-	if ((bx == 1 || bx == 2 || bx == 4) && (e.width & 3u) == 0 && (!tf->use_gradient || precomputed) && (((uintptr_t) d_vol | (uintptr_t) d_grad) & 3u) == 0)
+	const VkvTuning T_occ = tuning_of(ctx);
+	if ((bx == 1 || bx == 2 || bx == 4) && T_occ.occupancy_kernel == 1 && (e.width & 3u) == 0 && (!tf->use_gradient || precomputed) && (((uintptr_t) d_vol | (uintptr_t) d_grad) & 3u) == 0)
 	{
 		const uint32_t dblocks = (e.width / 4 + 255) / 256;
 		const dim3     dgrid(dblocks * me.height, me.depth);
@@ -1320,6 +1482,55 @@ int launch_occupancy_map(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_gr
 		}
 #undef VKV_OCC_DWORD
 		return check_launch(ctx, "occupancy_map");
+	}
+	const bool dword_ok = (e.width & 3u) == 0 && (!tf->use_gradient || precomputed) && (((uintptr_t) d_vol | (uintptr_t) d_grad) & 3u) == 0;
+	if (dword_ok && T_occ.occupancy_kernel != 1)
+	{        // any block width: a wave per 64 dwords (k_occupancy_map_waves)
+		const uint32_t spans_x = (uint32_t) ((e.width / 4 + 63) / 64);
+		const int      n_rows  = by * bz;
+		int            rows = 8, crb = 1;
+		if (n_rows == 1 || n_rows == 2 || n_rows == 4)
+			crb = 8 / n_rows;        // eight rows per batch out of 8, 4 or 2 cell rows
+		else
+		{
+			int waste = 1 << 30;
+			for (int cand : {8, 9, 10, 12})
+			{
+				const int w = (n_rows + cand - 1) / cand * cand - n_rows;
+				if (w < waste)
+					waste = w, rows = cand;
+			}
+		}
+		// cell rows per wave: >= 64 KB of voxels behind a wave's share of the bit table's staging, but at least 32 waves per CU in the launch
+		const size_t row_bytes = (size_t) 256 * n_rows * (precomputed ? 2 : 1);
+		int          cyw       = (int) std::min<size_t>(std::max<size_t>(1, (64 * 1024 + row_bytes - 1) / row_bytes), me.height);
+		const uint64_t want = (uint64_t) 32 * (uint64_t) std::max(1, ctx->cu_count);
+		while (cyw > crb && (uint64_t) spans_x * ((me.height + cyw - 1) / cyw) * me.depth < want)
+			cyw >>= 1;
+		cyw = (cyw + crb - 1) / crb * crb;
+		const uint64_t tasks = (uint64_t) spans_x * ((me.height + cyw - 1) / cyw);
+		if ((tasks + 3) / 4 <= 0x7fffffffull && me.depth <= 65535u)
+		{
+			const hipError_t em = hipMemsetAsync(d_map, 255, (size_t) me.width * me.height * me.depth, s);        // EMPTY everywhere; the kernel stores the OCCUPIED cells
+			if (em != hipSuccess)
+				return set_error(ctx, (int) em, "occupancy_map: fill: %s", hipGetErrorString(em));
+			const dim3 wgrid((uint32_t) ((tasks + 3) / 4), me.depth);
+#define VKV_OCC_WAVES(G, R, C) hipLaunchKernelGGL((k_occupancy_map_waves<G, R, C>), wgrid, dim3(256), 0, s, d_vol, d_grad, d_bits, d_map, W, H, D, mw, mh, bx, by, bz, spans_x, cyw)
+#define VKV_OCC_WAVES_G(G)                                                                                                                             \
+	do                                                                                                                                                 \
+	{                                                                                                                                                  \
+		if (crb == 8) VKV_OCC_WAVES(G, 8, 8); else if (crb == 4) VKV_OCC_WAVES(G, 8, 4); else if (crb == 2) VKV_OCC_WAVES(G, 8, 2);                     \
+		else if (rows == 8) VKV_OCC_WAVES(G, 8, 1); else if (rows == 9) VKV_OCC_WAVES(G, 9, 1); else if (rows == 10) VKV_OCC_WAVES(G, 10, 1);           \
+		else VKV_OCC_WAVES(G, 12, 1);                                                                                                                  \
+	} while (0)
+			if (precomputed)
+				VKV_OCC_WAVES_G(1);
+			else
+				VKV_OCC_WAVES_G(0);
+#undef VKV_OCC_WAVES_G
+#undef VKV_OCC_WAVES
+			return check_launch(ctx, "occupancy_map");
+		}
 	}
 	if (bx <= 256 && (e.width & 3u) == 0 && (!tf->use_gradient || precomputed) && (((uintptr_t) d_vol | (uintptr_t) d_grad) & 3u) == 0)
 	{

@@ -263,8 +263,8 @@ constexpr size_t kScratchReserve   = 16;          // scratch blocks the arena ke
 constexpr uint32_t kCaptureSlots   = 32;          // vkv_render_batch launches one context may have captured into hipGraphs
 constexpr size_t   kCaptureSlotBytes = 96 * 1024;  // >= the pull heads + VKV_MAX_BATCH argument blocks (= the scratch block's argument area)
 constexpr uint32_t kMaxDynamicLds  = 64 * 1024 - 1024;        // what a lean kernel may ask for as dynamic LDS (its tables; no hipFuncSetAttribute is called)
-constexpr size_t kTfBitsOffset     = 0;           // 256*256 bits = 8 KiB: TF bit table of the map update / the voxel count
-constexpr size_t kQueueHeadsOffset = 8192;        // 8 x u32 tile-queue heads of the persistent ray-march scheduler
+constexpr size_t kTfBitsOffset     = 0;           // 256*256 bits = 8 KiB: TF bit table of the map update / the voxel count (+ 8 words behind it: its column mask)
+constexpr size_t kQueueHeadsOffset = 8192 + 64;       // 8 x u32 tile-queue heads of the persistent ray-march scheduler
 constexpr size_t kPullHeadsBytes   = 2048;        // 8 ticket counters of k_raymarch_lean_pull, 256 bytes apart (one memory channel each), directly in
                                                   // front of the argument blocks: one upload zeroes the counters and brings the arguments
 constexpr uint32_t kPullHeadStride = 64;         // in uint32 words
