@@ -216,8 +216,6 @@ typedef struct VkvTuning
 	float    tile_mix_spread;
 	uint32_t gradient_segment;         /* vkv_gradient_map: tiles a workgroup marches in z; 0 = automatic                 VKV_GRADIENT_SEGMENT */
 	int32_t  pack_tile;                /* vkv_pack_volume: 0 automatic, 2 / 4 = bricks per workgroup edge                 VKV_PACK_TILE */
-	int32_t  format_rows;              /* vkv_render (one frame per launch): footprint rows through buffer FORMAT loads - 0 automatic (when the packed image
-	                                      is below 4 GiB), 1 never (A/B switch, same bits)                                  VKV_RAYMARCH_FORMAT_ROWS=1 */
 	int32_t  occupancy_kernel;         /* vkv_occupancy_map: 0 automatic (a wave per span of whole cells for every block width but 4), 1 = the workgroup-per-cell-row
 	                                      kernels of rounds 1-4 (A/B switch, same map)                                     VKV_OCCUPANCY_KERNEL=rows */
 	uint32_t arena_bytes;              /* read-only: size of the device arena vkv_create allocated                        VKV_ARENA_BYTES */

@@ -60,8 +60,7 @@ def test_render_parity_screen_bound_cases(ctx, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["address_tables=0", "address_tables=1", "screen_cull=0", "tile_order_linear=1", "full_table_lds_limit=0", "clamp_always=1",
-                                    "format_rows=1"])
+@pytest.mark.parametrize("switch", ["address_tables=0", "address_tables=1", "screen_cull=0", "tile_order_linear=1", "full_table_lds_limit=0", "clamp_always=1"])
 def test_render_parity_under_each_kernel_selection_switch(switch):
     """The launcher picks one of three instantiations of the integrator (footprint address in registers / two-level LDS tables / one
     entry per voxel index), a tile start order and the screen bound by itself; small test volumes always get the same choice.  The
@@ -70,8 +69,8 @@ def test_render_parity_under_each_kernel_selection_switch(switch):
     test_tuning_block_switches_render_the_same_bits."""
     env_of = {"address_tables=0": ("VKV_RAYMARCH_LUT", "0"), "address_tables=1": ("VKV_RAYMARCH_LUT", "2"), "screen_cull=0": ("VKV_RAYMARCH_CULL", "0"),
               "tile_order_linear=1": ("VKV_RAYMARCH_TILE_ORDER", "linear"), "full_table_lds_limit=0": ("VKV_RAYMARCH_FULL_LIMIT", "1"),
-              # round 5: the march loop with its clamps in every iteration; vkv_render with dword rows instead of buffer FORMAT rows
-              "clamp_always=1": ("VKV_RAYMARCH_CLAMP", "always"), "format_rows=1": ("VKV_RAYMARCH_FORMAT_ROWS", "1")}
+              # round 5: the march loop with its clamps in every iteration
+              "clamp_always=1": ("VKV_RAYMARCH_CLAMP", "always")}
     name, value = env_of[switch]
     env = dict(os.environ, **{name: value})
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -134,7 +133,7 @@ def test_tuning_block_switches_render_the_same_bits():
         assert int(ref[0][1].sum().item()) > 0
         for fields in (dict(address_tables=0), dict(address_tables=1), dict(full_table_lds_limit=0), dict(screen_cull=0), dict(tile_order_linear=1),
                        dict(batch_sequential=1), dict(batch_mode=1), dict(scheduler=1), dict(feedback=0), dict(tile_mix_heavy=0.3, tile_mix_spread=0.6),
-                       dict(clamp_always=1), dict(format_rows=1), dict(clamp_always=1, format_rows=1)):
+                       dict(clamp_always=1), dict(occupancy_kernel=1)):
             c.set_tuning(**fields)
             got = frames()
             reset = {k: getattr(t0, k) for k in fields}

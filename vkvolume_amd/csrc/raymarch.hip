@@ -113,7 +113,7 @@ LeanChoice choose_lean(const RayMarchArgs &a, const VkvTuning &T)
 	// the full tables hold offsets in units of two bytes in 32 bits: a packed image of up to 8 GiB
 	const bool        fits_u32 = packed_bytes(packed_dims(a.W, a.H, a.D)) <= (1ull << 33);
 	if (!no_full && fits_u32 && full_end <= (size_t) T.full_table_lds_limit)
-		return {2, lean_lds_bytes(2, a.lut_words, a.W, a.H, a.D), packed_bytes(packed_dims(a.W, a.H, a.D)) + 256 <= (1ull << 32)};
+		return {2, lean_lds_bytes(2, a.lut_words, a.W, a.H, a.D)};
 	return {1, lean_lds_bytes(1, a.lut_words, a.W, a.H, a.D)};
 }
 

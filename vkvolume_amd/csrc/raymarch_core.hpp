@@ -990,10 +990,6 @@ constexpr uint32_t kLeanSafe     = 16u;       // with kLeanFull: waves whose ray
                                               // without the nine clamps of an iteration (lean_march: "clamp-free march loop")
 constexpr uint32_t kLeanAsync    = 32u;       // separable transfer function + empty-space skipping: the loop's global loads are issued through inline asm and waited
                                               // for with hand-set counts, so that the probe outcome runs while the footprint gathers are still in flight
-constexpr uint32_t kLeanFmt      = 64u;       // with kLeanFull, packed image below 4 GiB: footprint rows through buffer FORMAT loads (8_8_8_8 USCALED, d16): the
-                                              // four bytes of a row arrive as f16 (exact), the filter's x stage widens them inside v_fma_mix_f32 - no byte
-                                              // conversions.  For single-frame launches (vkv_render): it shortens an iteration's dependent chain, which is what a
-                                              // frame alone is bound by; with frames in flight it measured the same as the dword rows (profiles/HISTORY.md r3, r4)
 constexpr uint32_t kLeanStamp    = 8u;        // (diagnostic, instantiated by tools/lab only, with the trace buffer) s_memtime at the top of every iteration,
                                               // summed per wave by the iteration's kind: only probing lanes / only sampling lanes / both
 constexpr size_t   kMaxLutBytes  = 8 * 1024;  // LDS budget of the two-level address tables (1.2 KB at 1024 voxels per axis, 1.9 KB at 2048)
@@ -1030,59 +1026,6 @@ __device__ __forceinline__ void packed_filter_cvt(uint32_t q00, uint32_t q10, ui
 		out_g = __builtin_fmaf(wz, c1 - c0, c0) * kScale;
 	}
 }
-// ---- kLeanFmt: rows as f16 quadruples (v0, g0, v1, g1) from a buffer FORMAT load ---------------------------------------------------
-typedef _Float16 half4v __attribute__((ext_vector_type(4)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef int      int4v __attribute__((ext_vector_type(4)));
-__device__ half4v vkv_buffer_load_format_h4(int4v rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f16");
-
-// buffer resource of the packed image: raw (stride 0), 4 GiB window, dst_sel RGBA, USCALED 8_8_8_8 (gfx9 V# word 3)
-__device__ __forceinline__ int4v packed_rows_rsrc(const uint8_t *base)
-{
-	const uint64_t a = reinterpret_cast<uint64_t>(base);
-	int4v          r;
-	r.x = __builtin_amdgcn_readfirstlane((int) (uint32_t) a);
-	r.y = __builtin_amdgcn_readfirstlane((int) (uint32_t) ((a >> 32) & 0xffffu));
-	r.z = -1;
-	r.w = (int) (0xFACu | (2u << 12) | (10u << 15));
-	return r;
-}
-
-// One channel pair of the x stage: d = (v1 - v0, g1 - g0) in f16 (integers below 256: exact), then c = fma(wx, d, b) with the f16
-// operands widened inside the instruction - the same real numbers the fp32 path multiplies and adds, rounded once: bit-identical.
-__device__ __forceinline__ float fma_mix_lo(float w, half2v d, half2v b)
-{        // fma(w, float(d.x), float(b.x)); the compiler forms it from the plain expression for the low halves only
-	float r;
-	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(d), "v"(b));
-	return r;
-}
-__device__ __forceinline__ float fma_mix_hi(float w, half2v d, half2v b)
-{        // fma(w, float(d.y), float(b.y))
-	float r;
-	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(d), "v"(b));
-	return r;
-}
-
-// packed_filter_cvt<., true> on f16 rows: results as value * 1024 (byte offsets into the 257-entry float tables)
-template <bool WANT_G>
-__device__ __forceinline__ void packed_filter_fmt(half4v h00, half4v h10, half4v h01, half4v h11, float wx, float wy, float wz, float &out_v, float &out_g)
-{
-	constexpr float kScale = kInv255 * 1024.0f;
-	const half2v    b00 = {h00.x, h00.y}, b10 = {h10.x, h10.y}, b01 = {h01.x, h01.y}, b11 = {h11.x, h11.y};
-	const half2v    d00 = half2v{h00.z, h00.w} - b00, d10 = half2v{h10.z, h10.w} - b10, d01 = half2v{h01.z, h01.w} - b01, d11 = half2v{h11.z, h11.w} - b11;
-	{
-		const float c00 = fma_mix_lo(wx, d00, b00), c10 = fma_mix_lo(wx, d10, b10), c01 = fma_mix_lo(wx, d01, b01), c11 = fma_mix_lo(wx, d11, b11);
-		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
-		out_v = __builtin_fmaf(wz, c1 - c0, c0) * kScale;
-	}
-	if (WANT_G)
-	{
-		const float c00 = fma_mix_hi(wx, d00, b00), c10 = fma_mix_hi(wx, d10, b10), c01 = fma_mix_hi(wx, d01, b01), c11 = fma_mix_hi(wx, d11, b11);
-		const float c0 = __builtin_fmaf(wy, c10 - c00, c00), c1 = __builtin_fmaf(wy, c11 - c01, c01);
-		out_g = __builtin_fmaf(wz, c1 - c0, c0) * kScale;
-	}
-}
-
 // The LDS of the lean kernels is ONE dynamic segment whose layout the launcher sizes (lean_lds_bytes): RmLds at its start, behind it
 // either the two-level address tables (kLeanLut) or, starting inside RmLds behind the separable transfer-function tables, the
 // per-voxel-index tables (kLeanFull).  The kernels have NO static LDS object, so the segment starts at LDS address 0 - RmLds sits at
@@ -1189,20 +1132,18 @@ __host__ __forceinline__ size_t lean_lds_bytes(int kind, uint32_t lut_words, int
 
 __device__ __forceinline__ uint32_t *full_lut_base(const RmLds &L) { return const_cast<uint32_t *>(reinterpret_cast<const uint32_t *>(&L)) + kFullLutWord; }
 
-template <bool BYTES = false>        // BYTES (kLeanFmt: packed image below 4 GiB): offsets in bytes instead of units of two bytes
 __device__ __forceinline__ void stage_full_lut(const RayMarchArgs &A, RmLds &L)
 {
-	constexpr int kShift = BYTES ? 0 : 1;
 	static_assert(sizeof(((RmLds *) nullptr)->s) == kFullLutWord * 4, "full tables start behind the separable TF tables");
 	const uint32_t  nx = (uint32_t) A.W + 2u, ny = (uint32_t) A.H + 2u, nz = (uint32_t) A.D + 2u;
 	uint32_t *      fx = full_lut_base(L), *fy = fx + nx, *fz = fy + ny;
 	const uint32_t *g  = A.addr_lut;
 	for (uint32_t b = threadIdx.x; b < nx; b += blockDim.x)
-		fx[b] = (g[b & 31u] + g[kLutXm + (b >> 5)]) >> kShift;
+		fx[b] = (g[b & 31u] + g[kLutXm + (b >> 5)]) >> 1;
 	for (uint32_t b = threadIdx.x; b < ny; b += blockDim.x)
-		fy[b] = (g[32u + (b & 31u)] + g[A.lut_y + (b >> 5)]) >> kShift;
+		fy[b] = (g[32u + (b & 31u)] + g[A.lut_y + (b >> 5)]) >> 1;
 	for (uint32_t b = threadIdx.x; b < nz; b += blockDim.x)
-		fz[b] = (uint32_t) ((((((uint64_t) g[A.lut_z + 2u * (b >> 5) + 1u]) << 32) | g[A.lut_z + 2u * (b >> 5)]) + g[64u + (b & 31u)]) >> kShift);
+		fz[b] = (uint32_t) ((((((uint64_t) g[A.lut_z + 2u * (b >> 5) + 1u]) << 32) | g[A.lut_z + 2u * (b >> 5)]) + g[64u + (b & 31u)]) >> 1);
 }
 
 // Loop-invariant operands of packed_footprint_full, worked out once per ray.  They pass through an empty asm so that the compiler keeps
@@ -1243,21 +1184,6 @@ __device__ __forceinline__ const uint8_t *packed_footprint_full(const FullLutCon
 	const uint32_t xo = *reinterpret_cast<const uint32_t *>(lut + tx), yo = *reinterpret_cast<const uint32_t *>(lut + ty);
 	const uint32_t zo = *reinterpret_cast<const uint32_t *>(lut + tz);
 	return C.base + ((uint64_t) ((xo + yo) + zo) << 1);        // the terms are in units of two bytes
-}
-// the same footprint as a 32-bit BYTE offset into the packed image (kLeanFmt: tables staged in bytes, images below 4 GiB)
-template <bool FREE = false>
-__device__ __forceinline__ uint32_t packed_footprint_full_offset(const FullLutConsts &C, const RmLds &L, float px, float py, float pz, float &wx, float &wy, float &wz)
-{
-	const float cx = __builtin_fmaf(px, C.w, -0.5f), cy = __builtin_fmaf(py, C.h, -0.5f), cz = __builtin_fmaf(pz, C.d, -0.5f);
-	const float fx = __builtin_floorf(cx), fy = __builtin_floorf(cy), fz = __builtin_floorf(cz);
-	wx = cx - fx, wy = cy - fy, wz = cz - fz;
-	const int   tx = (int) __builtin_fmaf(FREE ? fx : __builtin_amdgcn_fmed3f(fx, -1.0f, C.w), 4.0f, 4.0f);
-	const int   ty = (int) __builtin_fmaf(FREE ? fy : __builtin_amdgcn_fmed3f(fy, -1.0f, C.h), 4.0f, C.oy);
-	const int   tz = (int) __builtin_fmaf(FREE ? fz : __builtin_amdgcn_fmed3f(fz, -1.0f, C.d), 4.0f, C.oz);
-	const char *   lut = reinterpret_cast<const char *>(full_lut_base(L));
-	const uint32_t xo = *reinterpret_cast<const uint32_t *>(lut + tx), yo = *reinterpret_cast<const uint32_t *>(lut + ty);
-	const uint32_t zo = *reinterpret_cast<const uint32_t *>(lut + tz);
-	return (xo + yo) + zo;
 }
 // A footprint address that comes out of the LDS address tables is an integer: tell the compiler it points to global memory, or it emits
 // flat_load (which also counts on lgkmcnt, so every wait for an LDS read would wait for the footprint as well).
@@ -1303,17 +1229,6 @@ __device__ __forceinline__ void load_rows_async(uint32_t &q00, uint32_t &q10, ui
 	asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %4, off offset:10\n\tglobal_load_dword %2, %4, off offset:50\n\tglobal_load_dword %3, %4, off offset:60"
 	             : "=&v"(q00), "=&v"(q10), "=&v"(q01), "=&v"(q11)
 	             : "v"(p));
-}
-__device__ __forceinline__ void load_rows_fmt_async(half4v &h00, half4v &h10, half4v &h01, half4v &h11, uint32_t offset, int4v rsrc)
-{
-	asm volatile("buffer_load_format_d16_xyzw %0, %4, %5, 0 offen\n\tbuffer_load_format_d16_xyzw %1, %4, %5, 0 offen offset:10\n\t"
-	             "buffer_load_format_d16_xyzw %2, %4, %5, 0 offen offset:50\n\tbuffer_load_format_d16_xyzw %3, %4, %5, 0 offen offset:60"
-	             : "=&v"(h00), "=&v"(h10), "=&v"(h01), "=&v"(h11)
-	             : "v"(offset), "s"(rsrc));
-}
-__device__ __forceinline__ void wait_rows_fmt(half4v &h00, half4v &h10, half4v &h01, half4v &h11)
-{
-	asm volatile("s_waitcnt vmcnt(0)" : "+v"(h00), "+v"(h10), "+v"(h01), "+v"(h11));
 }
 // Wait for the oldest load in flight, inside the EXEC-masked probe side: four younger loads are behind it when some live lane of the
 // iteration does NOT probe (EXEC here = the probing lanes, `live` = EXEC at the top of the iteration), none otherwise.  One asm statement
@@ -1384,7 +1299,6 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	constexpr bool kHoist = PACKED && GRAD != 2;
 	constexpr bool kLut = (LF & kLeanLut) != 0, kFull = (LF & kLeanFull) != 0 && SEP, kTf = SEP && kHoist;
 	constexpr bool kAsync = (LF & kLeanAsync) != 0 && kTf && SKIP != VKV_SKIP_NONE;        // (not the texture path: its texel fetch is a load the compiler issues)
-	constexpr bool kFmt   = (LF & kLeanFmt) != 0 && kFull && kTf;
 	uint32_t       stamp_prev = 0, stamp_kind = 3;
 	const int      W = A.W, H = A.H, D = A.D;
 	const float    kx = SKIP != VKV_SKIP_NONE ? (float) W / A.block_size[0] : 0.0f, ky = SKIP != VKV_SKIP_NONE ? (float) H / A.block_size[1] : 0.0f,
@@ -1401,10 +1315,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	const float ofx = R.six > 0.0f ? 0.0f : 1.0f, ofy = R.siy > 0.0f ? 0.0f : 1.0f, ofz = R.siz > 0.0f ? 0.0f : 1.0f;
 	FullLutConsts fullc = {};
 	if (kFull)
-		fullc = full_lut_consts<FREE>(A);
-	int4v rows_rsrc = {};
-	if (kFmt)
-		rows_rsrc = packed_rows_rsrc(A.packed);        // (the clamp-free loop keeps them in scalar registers: room for the per-ray map pointer of the anisotropic kernels)
+		fullc = full_lut_consts<FREE>(A);        // (the clamp-free loop keeps them in scalar registers: room for the per-ray map pointer of the anisotropic kernels)
 	// loop position, its bounds and the first hit as floats (exact: n_steps <= 2^24)
 	float       li = (float) R.i, li_min = (float) R.i_min, lfirst = (float) R.first_hit;
 	const float ln = (float) R.n_steps, lback = (float) A.back;
@@ -1471,9 +1382,6 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		uint32_t dist = undefined_value<uint32_t>(), q00 = undefined_value<uint32_t>(), q10 = undefined_value<uint32_t>(), q01 = undefined_value<uint32_t>(),
 		         q11 = undefined_value<uint32_t>();
 		float    wx = undefined_value<float>(), wy = undefined_value<float>(), wz = undefined_value<float>();
-		half4v   h00 = {}, h10 = {}, h01 = {}, h11 = {};
-		if (kFmt)
-			h00 = undefined_value<half4v>(), h10 = undefined_value<half4v>(), h01 = undefined_value<half4v>(), h11 = undefined_value<half4v>();
 		unsigned long long live = 0ull;
 		if (kAsync)
 			live = __builtin_amdgcn_read_exec();        // the lanes whose rays are alive in this iteration
@@ -1486,20 +1394,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			else
 				dist = load_u8_global(dmap, cell);
 		}
-		if (kFmt && !probe)
-		{
-			const uint32_t bo = packed_footprint_full_offset<FREE>(fullc, L, posx, posy, posz, wx, wy, wz);
-			if (kAsync)
-				load_rows_fmt_async(h00, h10, h01, h11, bo, rows_rsrc);
-			else
-			{
-				h00 = vkv_buffer_load_format_h4(rows_rsrc, (int) bo, 0, 0);
-				h10 = vkv_buffer_load_format_h4(rows_rsrc, (int) bo + 10, 0, 0);
-				h01 = vkv_buffer_load_format_h4(rows_rsrc, (int) bo + 50, 0, 0);
-				h11 = vkv_buffer_load_format_h4(rows_rsrc, (int) bo + 60, 0, 0);
-			}
-		}
-		if (kHoist && !kFmt && !probe)
+		if (kHoist && !probe)
 		{
 			const uint8_t *ba = kFull  ? packed_footprint_full<FREE>(fullc, L, posx, posy, posz, wx, wy, wz)
 			                    : kLut ? packed_footprint_lut(A, posx, posy, posz, wx, wy, wz)
@@ -1557,11 +1452,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 				 // filter of bytes / 255; the tables have a 257th entry), alpha byte without a clamp (ai, ag <= 1 by construction of the tables)
 				const char *ai_tab = reinterpret_cast<const char *>(L.s.ai), *ag_tab = reinterpret_cast<const char *>(L.s.ag);
 				float       g_unused;
-				if (kFmt && GRAD == 1)
-					packed_filter_fmt<true>(h00, h10, h01, h11, wx, wy, wz, intensity, gradient);
-				else if (kFmt)
-					packed_filter_fmt<false>(h00, h10, h01, h11, wx, wy, wz, intensity, g_unused);
-				else if (GRAD == 1)
+				if (GRAD == 1)
 					packed_filter_cvt<true, true>(q00, q10, q01, q11, wx, wy, wz, intensity, gradient);
 				else
 					packed_filter_cvt<false, true>(q00, q10, q01, q11, wx, wy, wz, intensity, g_unused);
@@ -1672,9 +1563,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			asm volatile("");        // they stay two regions in this order instead of an if / else whose sides the compiler may swap
 		if (!probe)
 		{
-			if (kAsync && kFmt)
-				wait_rows_fmt(h00, h10, h01, h11);
-			else if (kAsync)
+			if (kAsync)
 				wait_rows(q00, q10, q01, q11);
 			sample_outcome();
 			if (kCounts)
@@ -1776,7 +1665,7 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 		if ((LF & kLeanLut) != 0 && PACKED && GRAD != 2)
 		{        // before the barrier of stage_tables_er
 			if ((LF & kLeanFull) != 0 && tf_is_separable(A))
-				stage_full_lut<(LF & kLeanFmt) != 0>(A, L);
+				stage_full_lut(A, L);
 			else
 				stage_addr_lut(A);
 		}

@@ -24,15 +24,12 @@ constexpr uint32_t kLfFull   = kLeanLut | kLeanFull | kLeanSafe;
 constexpr uint32_t kLfFull   = kLeanLut | kLeanFull | kLeanSafe | kLeanAsync; // + one entry per voxel index with the separable transfer function, clamp-free loop, hand-set load waits
 #endif
 constexpr uint32_t kLfFullNc = kLfFull | kLeanNoCounts;          // the same without the per-pixel counters (what a renderer launches)
-constexpr uint32_t kLfFmt    = kLfFull | kLeanFmt;               // single-frame launches, packed image below 4 GiB: footprint rows through buffer FORMAT loads
-constexpr uint32_t kLfFmtNc  = kLfFmt | kLeanNoCounts;
 constexpr uint32_t kLfLutNc  = kLfLut | kLeanNoCounts;
 
 struct LeanChoice
 {
 	int    kind;        // 0 plain, 1 two-level tables, 2 full tables
 	size_t lds;         // dynamic LDS bytes (lean_lds_bytes: the kernels' whole LDS layout lives in the dynamic segment)
-	bool   fmt = false;        // kind 2 and the packed image lies inside one 4 GiB buffer window: vkv_render may take the FORMAT-row kernels
 };
 
 LeanChoice choose_lean(const RayMarchArgs &a, const VkvTuning &T);        // raymarch.hip
@@ -92,26 +89,7 @@ static int launch_one(vkv_ctx *ctx, int sched, const VkvTuning &T, RayMarchArgs 
 			bool no_counts = false;
 			if constexpr (SKIP != VKV_SKIP_NONE && ERT && GRAD == 1)
 				no_counts = c.kind != 0 && !wants_counts(a);        // the common configuration only: every further instantiation costs build time
-			// one frame per launch is bound by the dependent chain of its longest waves: the FORMAT-row loop is 12 instructions shorter per sample
-			bool fmt = false;
-			if constexpr (SKIP != VKV_SKIP_NONE && GRAD == 1)
-				fmt = c.kind == 2 && c.fmt && T.format_rows != 1;
-			if (fmt)
-			{
-				if constexpr (SKIP != VKV_SKIP_NONE && GRAD == 1)
-				{
-					if constexpr (ERT)
-					{
-						if (no_counts)
-							hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfFmtNc>), dim3(grid), dim3(256), c.lds, s, a);
-						else
-							hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfFmt>), dim3(grid), dim3(256), c.lds, s, a);
-					}
-					else
-						hipLaunchKernelGGL((k_raymarch_lean<SKIP, ERT, GRAD, PACKED, kLfFmt>), dim3(grid), dim3(256), c.lds, s, a);
-				}
-			}
-			else if (no_counts)
+			if (no_counts)
 			{
 				if constexpr (SKIP != VKV_SKIP_NONE && ERT && GRAD == 1)
 				{
