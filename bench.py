@@ -133,7 +133,7 @@ if ROOT not in sys.path:
 
 from vkvolume_amd import abi, camera, lib, multigpu, volume as V  # noqa: E402
 
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r4_traffic.json")  # PMC-measured HBM bytes per launch (own rocprofv3 passes)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r5_traffic.json")  # PMC-measured HBM bytes per launch (own rocprofv3 passes)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 WORKLOADS = {

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --workload $wl --steps 64 --warmup 16 --no-cpu-baseline --no-depth-block --min-seconds 0.5"
+B="python3 $R/bench.py --workload $wl --steps 64 --warmup 16 --no-cpu-baseline --no-depth-block --extras off --min-seconds 0.5"
 run_stats() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$name -- $B "$@" > $O/bench_$name.json 2> $O/bench_$name.err; }
 run_pmc() { name=$1; ctr=$2; shift; shift; timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_${name}_$ctr -- $B --steps 16 --warmup 2 --min-seconds 0.1 "$@" > /dev/null 2> $O/pmc_${name}_$ctr.err; }
 run_stats default

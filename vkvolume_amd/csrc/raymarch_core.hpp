@@ -1,6 +1,6 @@
 // raymarch_core.hpp — device code of the ray-march integrator with block / Chebyshev / anisotropic-Chebyshev empty-space
 // skipping and early ray termination, for gfx950.  Included by the product's translation units (raymarch.hip: argument set-up and
-// dispatch; raymarch_inst.hpp + raymarch_skip*.hip: the kernel instantiations, one file per skipping type) and by
+// dispatch; raymarch_inst.hpp + raymarch_s<skip>e<ert>.hip: the kernel instantiations, one file per (skipping type, early ray termination) pair) and by
 // tools/lab/raymarch_lab.hpp (experimental and retired variants: they live there, not here).
 //
 // Replaces VolumeRenderSubpass::draw (src/volume_render_subpass.cpp:159-294) and the shaders it binds:
