@@ -70,7 +70,13 @@ def march_loop(listing, name_filter):
             # a kernel holds one copy of the march loop per transfer-function path; the bench's TF is the reference's separable product, whose
             # copy reads no RGBA texel (the generic copy's dependent texel fetch is the loop's only flat_load)
             sep = [(a, b) for a, b in cand if not any(x.startswith("flat_load") for x in ins[a:b + 1])]
-            a, b = max(sep or cand, key=lambda ab: ab[1] - ab[0])
+            # round 5: a kernel of the separable path holds the clamp-free loop (the one waves of free rays run: it computes r with v_fract_f32)
+            # next to the loop with the clamps; the bench's frames run the former
+            free = [(a, b) for a, b in (sep or cand) if any(x.startswith("v_fract_f32") for x in ins[a:b + 1])]
+            if free:        # (its rare clamp block sits behind the loop and branches back into it: the shortest region is the loop proper)
+                a, b = min(free, key=lambda ab: ab[1] - ab[0])
+            else:
+                a, b = max(sep or cand, key=lambda ab: ab[1] - ab[0])
             return name, ins[a:b + 1]
     raise SystemExit("no march loop found for %r" % name_filter)
 
