@@ -216,6 +216,8 @@ typedef struct VkvTuning
 	float    tile_mix_spread;
 	uint32_t gradient_segment;         /* vkv_gradient_map: tiles a workgroup marches in z; 0 = automatic                 VKV_GRADIENT_SEGMENT */
 	int32_t  pack_tile;                /* vkv_pack_volume: 0 automatic, 2 / 4 = bricks per workgroup edge                 VKV_PACK_TILE */
+	int32_t  wave_shape;               /* width in pixels of a wave's 64-pixel patch: 0 automatic (4, 8 or 16 from the view: the shape that is most compact
+	                                      in voxels), or 4 / 8 / 16 (A/B switch, same bits)                                 VKV_RAYMARCH_WAVE_SHAPE */
 	int32_t  occupancy_kernel;         /* vkv_occupancy_map: 0 automatic (a wave per span of whole cells for every block width but 4), 1 = the workgroup-per-cell-row
 	                                      kernels of rounds 1-4 (A/B switch, same map)                                     VKV_OCCUPANCY_KERNEL=rows */
 	uint32_t arena_bytes;              /* read-only: size of the device arena vkv_create allocated                        VKV_ARENA_BYTES */

@@ -133,7 +133,7 @@ def test_tuning_block_switches_render_the_same_bits():
         assert int(ref[0][1].sum().item()) > 0
         for fields in (dict(address_tables=0), dict(address_tables=1), dict(full_table_lds_limit=0), dict(screen_cull=0), dict(tile_order_linear=1),
                        dict(batch_sequential=1), dict(batch_mode=1), dict(scheduler=1), dict(feedback=0), dict(tile_mix_heavy=0.3, tile_mix_spread=0.6),
-                       dict(clamp_always=1), dict(occupancy_kernel=1)):
+                       dict(clamp_always=1), dict(occupancy_kernel=1), dict(wave_shape=4), dict(wave_shape=8), dict(wave_shape=16)):
             c.set_tuning(**fields)
             got = frames()
             reset = {k: getattr(t0, k) for k in fields}

@@ -107,7 +107,7 @@ class Tuning(C.Structure):
                 ("tile_order_linear", C.c_int32), ("address_tables", C.c_int32), ("full_table_lds_limit", C.c_uint32),
                 ("screen_cull", C.c_int32), ("feedback", C.c_int32), ("feedback_period", C.c_uint32), ("clamp_always", C.c_int32),
                 ("tile_mix_heavy", C.c_float), ("tile_mix_spread", C.c_float), ("gradient_segment", C.c_uint32),
-                ("pack_tile", C.c_int32), ("occupancy_kernel", C.c_int32), ("arena_bytes", C.c_uint32)]
+                ("pack_tile", C.c_int32), ("wave_shape", C.c_int32), ("occupancy_kernel", C.c_int32), ("arena_bytes", C.c_uint32)]
 
 
 class VolumeHeader(C.Structure):

@@ -307,7 +307,7 @@ static const char *tuning_problem(const VkvTuning &t)
 {
 	if (t.scheduler < 0 || t.scheduler > 1 || t.batch_mode < 0 || t.batch_mode > 1 || t.address_tables < 0 || t.address_tables > 2 || t.feedback_period == 0 ||
 	    t.gradient_segment > 255u || (t.pack_tile != 0 && t.pack_tile != 2 && t.pack_tile != 4) || t.clamp_always < 0 || t.clamp_always > 1 ||
-	    t.occupancy_kernel < 0 || t.occupancy_kernel > 1)
+	    t.occupancy_kernel < 0 || t.occupancy_kernel > 1 || (t.wave_shape != 0 && t.wave_shape != 4 && t.wave_shape != 8 && t.wave_shape != 16))
 		return "field out of range";
 	// a tile mix that is not a number never compares equal to a cached schedule's: every launch would build a new table
 	if (!std::isfinite(t.tile_mix_heavy) || !std::isfinite(t.tile_mix_spread) || t.tile_mix_heavy < 0.0f || t.tile_mix_heavy > 1.0f || t.tile_mix_spread < 0.0f ||
@@ -364,6 +364,11 @@ static void default_tuning(VkvTuning &t)
 		t.arena_bytes = (uint32_t) std::min(std::max(std::atol(e), 1l << 20), 1l << 30);
 	if (const char *e = env("VKV_RAYMARCH_CLAMP"))
 		t.clamp_always = e[0] == 'a';
+	if (const char *e = env("VKV_RAYMARCH_WAVE_SHAPE"))
+	{
+		const int v = std::atoi(e);
+		t.wave_shape = (v == 4 || v == 8 || v == 16) ? v : 0;
+	}
 	if (const char *e = env("VKV_OCCUPANCY_KERNEL"))
 		t.occupancy_kernel = e[0] == 'r';
 	// the environment gets the checks vkv_set_tuning applies: an out-of-range value falls back to the built-in default of its group

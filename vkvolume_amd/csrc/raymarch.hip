@@ -274,6 +274,14 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 	a.trace       = reinterpret_cast<unsigned long long *>(ctx->d_trace);
 	a.back        = (int) std::ceil(P->transfer_function.sampling_factor);
 	a.clamp_always = T.clamp_always != 0 ? 1u : 0u;
+	{        // shape of a wave's pixel patch: voxels per pixel step in x against y (texture-space ray increments x the extent)
+		double vx = 0.0, vy = 0.0;
+		const double dim[3] = {(double) a.W, (double) a.H, (double) a.D};
+		for (int k = 0; k < 3; ++k)
+			vx += (double) a.ddx[k] * dim[k] * (double) a.ddx[k] * dim[k], vy += (double) a.ddy[k] * dim[k] * (double) a.ddy[k] * dim[k];
+		const double r = (vx > 0.0 && vy > 0.0) ? std::sqrt(vx / vy) : 1.0;
+		a.wave_pw_log2 = T.wave_shape == 4 ? 2u : (T.wave_shape == 8 ? 3u : (T.wave_shape == 16 ? 4u : (r >= 1.6 ? 2u : (r <= 1.0 / 1.6 ? 4u : 3u))));
+	}
 	{
 		const float m[3] = {(float) a.mw, (float) a.mh, (float) a.md};
 		for (int k = 0; k < 3; ++k)
