@@ -952,6 +952,13 @@ __device__ __forceinline__ T undefined_value()
 	return x;
 }
 
+// a wave-uniform 64-bit value moved into scalar registers
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t x)
+{
+	const uint32_t lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) x), hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (x >> 32));
+	return ((uint64_t) hi << 32) | lo;
+}
+
 // A wave-uniform float the march loop reads in every iteration, kept in a SCALAR register: v_readfirstlane moves it there and the empty asm
 // stops the compiler from re-deriving it in the loop (in the batch kernel the arguments sit in memory: it would re-load and re-convert
 // them).  A VALU instruction reads one scalar operand for free, and the ten or so uniform operands of the loop then stop counting
@@ -983,6 +990,7 @@ __device__ __forceinline__ int clamp0_i32(int x, int hi)
 __device__ __forceinline__ float clamp0_f32_cold(float x, float hi)
 {        // clamp(x, 0, hi), hi wave-uniform (a scalar operand)
 	float r;
+	hi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hi)));
 	asm volatile("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
 	return r;
 }
@@ -1322,7 +1330,9 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	const int   mw1 = A.mw - 1, mh1 = A.mh - 1, md1 = A.md - 1;
 	// (the multipliers of the cell index, pinned in scalar registers: the batch kernel's arguments sit in memory and the compiler would
 	// otherwise be free to load them again in every iteration)
-	uint32_t amw = (uint32_t) A.mw, amh = (uint32_t) A.mh;
+	// (readfirstlane: an "s" operand must BE in a scalar register - the compiler reports "illegal VGPR to SGPR copy" when its own copy of a
+	// uniform value happens to live in a vector register, which depends on optimisation flags)
+	uint32_t amw = (uint32_t) __builtin_amdgcn_readfirstlane(A.mw), amh = (uint32_t) __builtin_amdgcn_readfirstlane(A.mh);
 	asm volatile("" : "+s"(amw), "+s"(amh));
 	float       grey = 0.0f;
 	uint32_t    ul   = 0;
@@ -1336,7 +1346,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	float       li = (float) R.i, li_min = (float) R.i_min, lfirst = (float) R.first_hit;
 	const float ln = (float) R.n_steps, lback = (float) A.back;
 	// the distance map of a launch without the anisotropic maps is the same for every ray: a scalar base for the probe's load
-	const uint8_t *const dmap = SKIP == VKV_SKIP_ANISOTROPIC_DISTANCE ? R.dmap : A.maps[0];
+	const uint8_t *const dmap = SKIP == VKV_SKIP_ANISOTROPIC_DISTANCE ? R.dmap : reinterpret_cast<const uint8_t *>(uniform_u64(reinterpret_cast<uintptr_t>(A.maps[0])));
 	// FREE: the clamp-free form of the loop, for waves of free rays (lean_free_wave above)
 	float lhi_now = -1.0f;        // the last safe position of this lane's ray: -1 until the first iteration (i = 0) is done, then lhi
 	static_assert(!FREE || ((LF & kLeanSafe) != 0 && kFull && kHoist && SKIP != VKV_SKIP_NONE && !kStamp), "the clamp-free loop exists for kLeanSafe kernels only");
@@ -1744,6 +1754,19 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 
 // (the single-frame kernel is not held to 64 VGPRs like the batch kernel below: one frame at a time is bound by the longest wave's
 // dependent chain, not by the number of resident waves, and at 64 the march loop of some instantiations spills)
+// No packed fp32 instructions in the lean kernels (round 5).  Under plain -O3 the SLP vectoriser pairs the loop's isomorphic fp32 operations
+// into v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32.  On gfx950 a packed fp32 instruction issues at half the rate of a plain one (nothing gained),
+// needs its operands in aligned register pairs (v_mov) and a wait state when it follows its producer (s_nop): the bench kernel's march loop is
+// 124 plain VALU + 36 SALU instructions without them, 109 + 44 with them - and 1.7 % faster without (profiles/r5_ab_no_packed_fp32.txt;
+// MI355X_MICROARCH.md lists packed fp32 as an anti-lever for the same reason).  The target attribute switches the feature off for these
+// kernels only; same IEEE operations, same bits.  (The batch kernel only: the single-frame kernel built this way keeps its 1.8 KB by-value
+// argument block in scratch - its packed and its plain build measure the same for one frame alone.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VKV_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
+#else        // (the host pass of the translation unit does not know the feature)
+#define VKV_NO_PACKED_FP32
+#endif
+
 template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF>
 __global__ void __launch_bounds__(256) k_raymarch_lean(const RayMarchArgs A)
 {
@@ -1764,7 +1787,7 @@ __global__ void __launch_bounds__(256) k_raymarch_lean(const RayMarchArgs A)
 // back in smaller pieces: three single-frame launches in flight gain 5 % in the lab (0.1181 against 0.1242 ms per frame, variants 112 / 21),
 // this kernel loses 6 % (0.1167 against 0.1099; the two-level tables alone 0.1116): twice the workgroups to set up and to stage tables for.)
 template <int SKIP, bool ERT, int GRAD, uint32_t LF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((GRAD == 2 || SKIP == VKV_SKIP_NONE) ? 1 : 8))) k_raymarch_lean_batch(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t groups_per_frame)
+__global__ void __launch_bounds__(256) VKV_NO_PACKED_FP32 __attribute__((amdgpu_waves_per_eu((GRAD == 2 || SKIP == VKV_SKIP_NONE) ? 1 : 8))) k_raymarch_lean_batch(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t groups_per_frame)
 {
 	lean_lds_check();
 	RmLds &        L = lean_lds();
