@@ -1350,6 +1350,8 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	// FREE: the clamp-free form of the loop, for waves of free rays (lean_free_wave above)
 	float lhi_now = -1.0f;        // the last safe position of this lane's ray: -1 until the first iteration (i = 0) is done, then lhi
 	static_assert(!FREE || ((LF & kLeanSafe) != 0 && kFull && kHoist && SKIP != VKV_SKIP_NONE && !kStamp), "the clamp-free loop exists for kLeanSafe kernels only");
+	if (kAsync)        // nothing of the set-up is in flight when the loop starts: the compiler then carries no vmcnt waits for it round the loop
+		__builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) (expcnt, lgkmcnt untouched)
 	while (!done)
 	{
 		const float i    = li;
