@@ -34,6 +34,9 @@ start, end, it = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, t[:, 2]
 print("waves traced", len(t), "launch span %.1f us = %.1f us per frame" % (end.max(), end.max() / n))
 m = it > 0
 print("marching waves", int(m.sum()), "wave iterations", int(it.sum()), "= %.0f per frame" % (it.sum() / n))
+cl = t[:, 9]
+print("clamp-free loop: %d of those iterations took the rare clamp branch (%.2f %%), %.2f per marching wave; waves that never left the loop with the clamps count 0 here" % (
+    int(cl.sum()), 100.0 * cl.sum() / max(it.sum(), 1), cl.sum() / max(m.sum(), 1)))
 ts = np.arange(0, end.max(), 25.0)
 occ = [int(((start <= x) & (end > x)).sum()) for x in ts]
 occ_m = [int(((start <= x) & (end > x) & m).sum()) for x in ts]

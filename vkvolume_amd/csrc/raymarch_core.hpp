@@ -1270,6 +1270,7 @@ __device__ __forceinline__ void wait_rows(uint32_t &q00, uint32_t &q10, uint32_t
 struct LeanStamp
 {
 	uint32_t sum[3], cnt[3];        // shader-clock cycles and iterations of this wave by kind: 0 probe lanes only, 1 sample lanes only, 2 both
+	uint32_t clamped;               // clamp-free loop: iterations that took the rare branch (some lane outside its safe range)
 };
 
 // ---- clamp-free march loop (kLeanSafe) -------------------------------------------------------------------------------------------
@@ -1367,6 +1368,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 				if (__builtin_expect(__builtin_amdgcn_ballot_w64(i > lhi_now) != 0ull, 0))
 				{        // the first iteration of every wave, and the iterations in which a ray with lhi = n - 2 stands at its last position
 					ux = clamp0_f32_cold(ux, A.mapb[0]), uy = clamp0_f32_cold(uy, A.mapb[1]), uz = clamp0_f32_cold(uz, A.mapb[2]);        // to [0, largest float below the extent]
+					++stamp.clamped;        // (diagnostic, read by the trace record only)
 					// lhi, worked out here, where it is rarely needed, instead of being kept in a register across the loop (the empty asm keeps the
 					// compiler from re-using - and spilling - what lean_free_wave computed from the same operands)
 					float last = ln;
@@ -1734,6 +1736,9 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 		for (int o2 = 32; o2 > 0; o2 >>= 1)
 			it = max(it, (uint32_t) __shfl_xor((int) it, o2));
 		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+		uint32_t clamped_max = stamp.clamped;        // a lane counts the rare-branch iterations it was alive in
+		for (int o2 = 32; o2 > 0; o2 >>= 1)
+			clamped_max = max(clamped_max, (uint32_t) __shfl_xor((int) clamped_max, o2));
 		if ((LF & kLeanStamp) != 0 && iter == it && lane == (uint32_t) __builtin_ctzll(__ballot(iter == it)))
 		{        // the stamps of the lane whose ray lived through every iteration of the wave (the others stop counting when their ray ends)
 			unsigned long long *rec = A.trace + ((size_t) blockIdx.x * WPB + wave) * kTraceWords;
@@ -1749,7 +1754,7 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 		{
 			unsigned long long *rec = A.trace + ((size_t) blockIdx.x * WPB + wave) * kTraceWords;        // per launch (a batch: all its frames)
 			rec[0] = t_start, rec[1] = t_end, rec[2] = it, rec[3] = ((unsigned long long) __builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | (k * A.blocks_per_tile + sb);
-			rec[6] = c_start, rec[7] = __builtin_amdgcn_s_memtime(), rec[9] = 0;
+			rec[6] = c_start, rec[7] = __builtin_amdgcn_s_memtime(), rec[9] = clamped_max;
 		}
 	}
 }
