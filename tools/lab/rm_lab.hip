@@ -117,6 +117,8 @@ int dispatch(const RayMarchArgs &a, int variant, hipStream_t s)
 		// the product's lean_march (raymarch_core.hpp), instantiated here: 30 = kLeanLut | kLeanFull as shipped, 31 = + per-iteration stamps
 		case 30: return launch_product_lean<SKIP, ERT, GRAD, kLeanLut | kLeanFull>(a, s);
 		case 31: return launch_product_lean<SKIP, ERT, GRAD, kLeanLut | kLeanFull | kLeanStamp>(a, s);
+		case 32: return launch_product_lean<SKIP, ERT, GRAD, kLeanLut | kLeanFull | kLeanSafe>(a, s);                     // round 5: + the clamp-free march loop
+		case 33: return launch_product_lean<SKIP, ERT, GRAD, kLeanLut | kLeanFull | kLeanSafe | kLeanAsync>(a, s);        // + hand-set load waits = the product's kLfFull
 		case 6: return launch_lean<SKIP, ERT, GRAD, true, kLabUniform | kLabLut | kLabBranch | kLabCvt>(a, s);
 #ifdef LAB_ALL
 		case 1: return launch_lean<SKIP, ERT, GRAD, true, 0>(a, s);
