@@ -1,11 +1,15 @@
 """The march loop of each ray-march kernel in a `hipcc -S --cuda-device-only` listing: the SMALLEST backward-branch region that holds the
-probe byte load and the four footprint loads.  Prints instruction counts by class; with --dump the loop's instructions.
-usage: isa_march_loop.py file.s [name-filter] [--dump]"""
+probe byte load and the four footprint loads.  Prints instruction counts by class; with --dump the loop's instructions; with --order
+which outcome block comes first in the loops with hand-set load waits (the probe side must: its byte is the oldest load, lean_march) -
+exit code 1 if a loop starts with the sample side.
+usage: isa_march_loop.py file.s [name-filter] [--dump] [--order]"""
 import re
 import sys
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 dump = "--dump" in sys.argv
+order = "--order" in sys.argv
+bad_order = 0
 s = open(args[0]).read()
 flt = args[1] if len(args) > 1 else ""
 for f in re.split(r'\n(?=_Z\w+:)', s):
@@ -42,5 +46,13 @@ for f in re.split(r'\n(?=_Z\w+:)', s):
         print("%-72s march loop %4d instr: valu %3d salu %3d vmem-load %2d lds %2d waitcnt %2d branch %2d" % (
             name[:72], len(seg), c('v_'), c('s_') - c('s_waitcnt') - c('s_cbranch') - c('s_branch'), c(('global_load', 'buffer_load', 'flat_load')), c('ds_'),
             c('s_waitcnt'), c(('s_cbranch', 's_branch'))))
+        if order:
+            first = lambda p: next((k for k, x in enumerate(seg) if x.startswith(p)), None)
+            w4, cv = first('s_cmp_lg_u64 exec'), first('v_cvt_f32_ubyte')        # (the hand-set wait of the probe byte starts with this comparison)
+            if w4 is not None and cv is not None:
+                print("    %s side first" % ("probe" if w4 < cv else "SAMPLE"))
+                bad_order += w4 > cv
         if dump:
             print("\n".join("    " + x for x in seg))
+if order and bad_order:
+    sys.exit(1)

@@ -1368,7 +1368,9 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 				if (__builtin_expect(__builtin_amdgcn_ballot_w64(i > lhi_now) != 0ull, 0))
 				{        // the first iteration of every wave, and the iterations in which a ray with lhi = n - 2 stands at its last position
 					ux = clamp0_f32_cold(ux, A.mapb[0]), uy = clamp0_f32_cold(uy, A.mapb[1]), uz = clamp0_f32_cold(uz, A.mapb[2]);        // to [0, largest float below the extent]
-					++stamp.clamped;        // (diagnostic, read by the trace record only)
+#ifdef VKV_TRACE_CLAMPED        // diagnostic build (tools/wave_trace_batch.py prints the share of such iterations: 2.8 % on C3); in the product the
+					++stamp.clamped;        // count would cost every iteration a per-lane copy of it (a value that leaves a loop whose lanes exit at different times)
+#endif
 					// lhi, worked out here, where it is rarely needed, instead of being kept in a register across the loop (the empty asm keeps the
 					// compiler from re-using - and spilling - what lean_free_wave computed from the same operands)
 					float last = ln;
@@ -1569,7 +1571,11 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		// ---- the frag's state update (frag:224-310) under EXEC: plain moves and adds instead of selects ------------------
 		__builtin_amdgcn_wave_barrier();        // emits nothing; keeps the load blocks above apart from the blocks below (left to itself the
 		                                        // compiler sinks each load into its block: the footprint would be requested after the probe outcome)
-		if (probe)
+		// the probe side FIRST (its byte is the oldest load in flight, and its outcome runs while the footprint gathers are under way): the
+		// compiler lays out the side it is told to expect first (without the hint it starts with the sample side; two separate ifs kept the
+		// order too, at the price of a copy of the loop position and three mask operations per iteration).  tools/isa_march_loop.py --order
+		// checks the order in a listing; the result does not depend on it (wait_rows waits for everything)
+		if (__builtin_expect(probe, 1))
 		{
 			if (kAsync)
 			{        // the byte is the oldest load in flight: behind it the four footprint dwords, or nothing
@@ -1589,9 +1595,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			ul   = hit ? cell : ul;
 			done = li >= ln;
 		}
-		if (kAsync)        // the probe side FIRST (its byte is the oldest load): a statement every lane executes between the two sides, so that
-			asm volatile("");        // they stay two regions in this order instead of an if / else whose sides the compiler may swap
-		if (!probe)
+		else
 		{
 			if (kAsync)
 				wait_rows(q00, q10, q01, q11);
