@@ -1337,7 +1337,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	asm volatile("" : "+s"(amw), "+s"(amh));
 	float       grey = 0.0f;
 	uint32_t    ul   = 0;
-	bool        occ  = true, done = false;
+	bool        occ  = true;
 	const float sgx = R.six > 0.0f ? 1.0f : -1.0f, sgy = R.siy > 0.0f ? 1.0f : -1.0f, sgz = R.siz > 0.0f ? 1.0f : -1.0f;
 	const float ofx = R.six > 0.0f ? 0.0f : 1.0f, ofy = R.siy > 0.0f ? 0.0f : 1.0f, ofz = R.siz > 0.0f ? 0.0f : 1.0f;
 	FullLutConsts fullc = {};
@@ -1353,7 +1353,9 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 	static_assert(!FREE || ((LF & kLeanSafe) != 0 && kFull && kHoist && SKIP != VKV_SKIP_NONE && !kStamp), "the clamp-free loop exists for kLeanSafe kernels only");
 	if (kAsync)        // nothing of the set-up is in flight when the loop starts: the compiler then carries no vmcnt waits for it round the loop
 		__builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0) (expcnt, lgkmcnt untouched)
-	while (!done)
+	// (a ray is over when its loop position reaches n_steps - early ray termination puts it there: no "done" flag of its own, whose
+	// per-lane state the compiler keeps as wave masks at six scalar operations and a second comparison per iteration)
+	while (li < ln)
 	{
 		const float i    = li;
 		const float posx = __builtin_fmaf(i, R.sx, R.ex), posy = __builtin_fmaf(i, R.sy, R.ey), posz = __builtin_fmaf(i, R.sz, R.ez);
@@ -1593,7 +1595,6 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 				li = i + skip;
 			occ  = hit ? true : occ;
 			ul   = hit ? cell : ul;
-			done = li >= ln;
 		}
 		else
 		{
@@ -1627,12 +1628,10 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			}
 			else if (kCounts)
 				++R.n_empty;
-			if (!ended)
-			{
-				li     = i + 1.0f;
-				li_min = li;
-			}
-			done = ended || li >= ln;
+			// frag:308-309 ++i, i_min = i; a terminated ray leaves the loop through its position (the position a ray ends with is not an
+			// output, nor is i_min)
+			li_min = i + 1.0f;
+			li     = ended ? ln : li_min;
 		}
 		// the frame time is the critical path of the wave with the longest ray: once a wave has run 48 iterations it is one of
 		// those, so let it win instruction arbitration against the younger waves on its SIMD
