@@ -1469,11 +1469,12 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 				ay = (by + __builtin_amdgcn_fmed3f((float) uiy - uy, -1.0f, 0.0f)) * R.siy;
 				az = (bz + __builtin_amdgcn_fmed3f((float) uiz - uz, -1.0f, 0.0f)) * R.siz;
 			}
-			// a NaN component (0 * inf on an axis-parallel ray) counts as +inf: minNum ignores it; all three cannot be NaN, and if
-			// they were the comparison caps the result exactly as the select chain of the oracle does
-			float m = __builtin_fminf(__builtin_fminf(ax, ay), az);
-			m       = (m < 1073741824.0f) ? m : 1073741824.0f;
-			skip    = __builtin_fmaxf(1.0f, __builtin_ceilf(m));        // a NaN m gives 1 as max(1, (int) NaN = 0) does
+			// a NaN component (0 * inf on an axis-parallel ray) counts as +inf: minNum ignores it; all three cannot be NaN (a direction has a
+			// non-zero component)
+			// (no cap on m: the oracle's int(ceil(m)) saturates for a huge m, here the position becomes huge or +inf - either way past the end of
+			// the ray, and the position a ray ends with is not an output)
+			const float m = __builtin_fminf(__builtin_fminf(ax, ay), az);
+			skip          = __builtin_fmaxf(1.0f, __builtin_ceilf(m));        // a NaN m gives 1 as max(1, (int) NaN = 0) does
 		};
 
 		// ---- sample outcome (frag:272-284) ---------------------------------------------------------------------------
@@ -1620,11 +1621,8 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 				R.a = __builtin_fmaf(om, a, R.a);
 				if (a > 0.0f)
 					lfirst = i;
-				if (ERT)
-				{        // frag:293-299, as selects (the block form costs a save / restore of EXEC around two moves)
+				if (ERT)        // frag:293-299; the frag's "alpha = 1" of a terminated ray happens behind the loop (alpha only passes 0.99 here, and then the ray ends)
 					ended = R.a > 0.99f;
-					R.a   = ended ? 1.0f : R.a;
-				}
 			}
 			else if (kCounts)
 				++R.n_empty;
@@ -1649,6 +1647,8 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			stamp.sum[2] += dt, ++stamp.cnt[2];
 	}
 	R.i = (int) li, R.i_min = (int) li_min, R.first_hit = (int) lfirst;
+	if (ERT)
+		R.a = R.a > 0.99f ? 1.0f : R.a;
 	if (SEP)
 		R.r = grey, R.g = grey, R.b = grey;
 }
