@@ -882,7 +882,7 @@ __device__ __forceinline__ bool stage_tables_er(const RayMarchArgs &A, RmLds &L)
 			L.s.ag[i]   = __uint_as_float(A.tf_bits[kTfAgWord + i]);
 			if (i == 255)
 				L.s.ai[256] = L.s.ai[255], L.s.ag[256] = L.s.ag[255];
-			L.s.pair[i] = make_float2(a, unorm8(i) * a);
+			L.s.pair[i] = i == 0 ? make_float2(0.0f, 0.0f) : make_float2(a, unorm8(i) * a);        // (alpha byte 0 blends nothing: lean_march relies on it)
 		}
 		else
 			L.g.unorm[i] = unorm8(i);
@@ -1428,7 +1428,7 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 			else
 				dist = load_u8_global(dmap, cell);
 		}
-		if (kHoist && !probe)
+		else if (kHoist)
 		{
 			const uint8_t *ba = kFull  ? packed_footprint_full<FREE>(fullc, L, posx, posy, posz, wx, wy, wz)
 			                    : kLut ? packed_footprint_lut(A, posx, posy, posz, wx, wy, wz)
@@ -1606,10 +1606,14 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 				++R.n_vol;
 			occ        = ab > 0u;        // frag:276
 			bool ended = false;
-			if (occ)
+			// kTf: ONE wave-uniform branch around the blend instead of an EXEC-masked block (two EXEC writes less per sample iteration).  For a
+			// lane whose sample is empty the blend is a no-op by its arithmetic: alpha byte 0 reads pair[0] = {0, 0} (stage_tables_er), and
+			// fma(om, 0, x) = x exactly; a > 0 and alpha > 0.99 are false for it (alpha only passes 0.99 when the ray ends there)
+			const bool blend = kTf ? __builtin_amdgcn_ballot_w64(occ) != 0ull : occ;
+			if (blend)
 			{
 				if (SKIP != VKV_SKIP_NONE)
-					ul = cell;
+					ul = (kTf && !occ) ? ul : cell;
 				const float om = 1.0f - R.a;        // frag:287
 				if (SEP)
 					grey = __builtin_fmaf(om, c, grey);
@@ -1621,10 +1625,12 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 				R.a = __builtin_fmaf(om, a, R.a);
 				if (a > 0.0f)
 					lfirst = i;
-				if (ERT)        // frag:293-299; the frag's "alpha = 1" of a terminated ray happens behind the loop (alpha only passes 0.99 here, and then the ray ends)
+				if (ERT && !kTf)        // frag:293-299; the frag's "alpha = 1" of a terminated ray happens behind the loop (alpha only passes 0.99 here, and then the ray ends)
 					ended = R.a > 0.99f;
 			}
-			else if (kCounts)
+			if (ERT && kTf)        // (behind the uniform branch: no value to merge at its end, so no jump around the rare side)
+				ended = R.a > 0.99f;
+			if (kCounts && !occ)
 				++R.n_empty;
 			// frag:308-309 ++i, i_min = i; a terminated ray leaves the loop through its position (the position a ray ends with is not an
 			// output, nor is i_min)
