@@ -1777,7 +1777,7 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 // MI355X_MICROARCH.md lists packed fp32 as an anti-lever for the same reason).  The target attribute switches the feature off for these
 // kernels only; same IEEE operations, same bits.  (The batch kernel only: the single-frame kernel built this way keeps its 1.8 KB by-value
 // argument block in scratch - its packed and its plain build measure the same for one frame alone.)
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VKV_LAB_PACKED_FP32)        // (-DVKV_LAB_PACKED_FP32: the A/B build of profiles/r5_ab_no_packed_fp32.txt)
 #define VKV_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
 #else        // (the host pass of the translation unit does not know the feature)
 #define VKV_NO_PACKED_FP32
