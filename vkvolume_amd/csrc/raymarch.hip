@@ -500,12 +500,7 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	const hipError_t e = hipMemcpyAsync(d_heads, upload_src, upload.size(), hipMemcpyHostToDevice, s);
 	if (e != hipSuccess)
 		return set_error(ctx, (int) e, "render_batch: argument upload: %s", hipGetErrorString(e));
-#ifdef VKV_LAB_SCOUT
-	const uint64_t seq  = (uint64_t) ((host[0].tile_count + 7u) / 8u) * host[0].blocks_per_tile;        // entries per XCD and frame
-	const uint64_t grid = ((seq + 15u) / 16u) * 17u * 8u * n;
-#else
 	const uint64_t grid = (uint64_t) ((host[0].tile_count + 7u) / 8u) * 8u * host[0].blocks_per_tile * n;
-#endif
 	if (grid > 0x7fffffffull)
 		return set_error(ctx, VKV_E_UNSUPPORTED, "render_batch: too many workgroups for one launch");
 	const bool ert  = P[0].options.early_ray_termination != 0;

@@ -1660,10 +1660,8 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 }
 
 // the body of one workgroup: 16x16 pixels of the frame described by A; `bid` is the workgroup's id inside that frame's grid
-// scout (lab, -DVKV_LAB_SCOUT): the workgroup does not render - its 256 lanes walk one ray per 4x4 pixels of the NEXT 16 blocks of its XCD's
-// sequence (bid = the first of them) with four times the step, only to touch the lines those blocks are about to need; it writes nothing.
 template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF, int WPB = 4>
-__device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, RmLds &L, bool scout = false)
+__device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, RmLds &L)
 {
 	// Hardware deals workgroup ids round-robin over the 8 XCDs (own L2 each).  XCD x = id & 7 marches the schedule's tiles
 	// k = x, x + 8, x + 16, ... one after the other: neighbouring workgroups of an XCD share a tile (L2 locality) while the tiles
@@ -1672,38 +1670,20 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 	constexpr uint32_t kParts = 4 / WPB;
 	const uint32_t x = bid & 7u, idx = (bid >> 3) / kParts, part = (bid >> 3) % kParts;
 	const uint32_t rank = (idx / A.blocks_per_tile) * 8u + x, sb = idx % A.blocks_per_tile;
-	if (!scout && rank >= A.tile_count)
+	if (rank >= A.tile_count)
 		return;
 	// Tiles are STARTED centre of the image first (tile_order, built by the launcher): the volume sits there, so the tiles with the
 	// long rays — the critical path of the launch — start at once and the cheap border tiles fill the tail.  Any order gives the same
 	// frame; on C3 this one shortens a single frame's launch from 0.324 to 0.306 ms and the tail of an 8-frame launch from 0.18 to
 	// 0.03 ms (bench.py).  Several single-frame launches in flight on their own streams prefer the plain order
 	// (VKV_RAYMARCH_TILE_ORDER=linear: 0.157 vs 0.167 ms per frame with three in flight) - their heavy centres then do not coincide.
-	const uint32_t k = (!scout && A.tile_order) ? A.tile_order[rank] : rank;
-	if (!scout && k >= A.tile_count)
+	const uint32_t k = A.tile_order ? A.tile_order[rank] : rank;
+	if (k >= A.tile_count)
 		return;        // never with a well-formed order; keeps a damaged one (a target shared by two streams without an event) from becoming a wild address
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	uint32_t       px = 0, py = 0, o = 0;
+	uint32_t       px, py, o;
 	const uint32_t rb = (part * WPB + wave) * 64u + lane;        // ray of the block this lane marches: the lane's own pixel of its 8x8 quadrant
-	bool           inside = false;
-	if (!scout)
-		inside = block_pixel<1>(A, k * A.blocks_per_tile + sb, rb, px, py, o);
-	else
-	{        // lane -> (one of the 16 entries behind this one in the XCD's sequence, one of 4x4 scout rays of that block)
-		const uint32_t e = idx + (threadIdx.x >> 4), r = threadIdx.x & 15u;
-		const uint32_t srank = (e / A.blocks_per_tile) * 8u + x, ssb = e % A.blocks_per_tile;
-		if (srank < A.tile_count)
-		{
-			const uint32_t sk = A.tile_order ? A.tile_order[srank] : srank;
-			if (sk < A.tile_count)
-			{
-				const uint32_t t = A.tile_first + sk * A.tile_stride;
-				px     = (t % A.tiles_x) * A.tile_w + (ssb % A.blocks_per_tile_x) * 16u + 4u * (r & 3u) + 2u;
-				py     = (t / A.tiles_x) * A.tile_h + (ssb / A.blocks_per_tile_x) * 16u + 4u * (r >> 2) + 2u;
-				inside = px < A.img_w && py < A.img_h;
-			}
-		}
-	}
+	const bool     inside = block_pixel<1>(A, k * A.blocks_per_tile + sb, rb, px, py, o);
 	Ray R;
 	R.o = o;
 	const unsigned long long t_start = A.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -1715,12 +1695,6 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 			marched = ray_setup<SKIP>(A, px, py, R);
 		else
 			ray_clear(R);
-	}
-	if (scout)
-	{        // four times the step (exact: powers of two), a quarter of the positions
-		R.sx *= 4.0f, R.sy *= 4.0f, R.sz *= 4.0f, R.six *= 0.25f, R.siy *= 0.25f, R.siz *= 0.25f;
-		R.n_steps = (R.n_steps + 3) >> 2;
-		marched   = marched && R.n_steps > 0;
 	}
 	uint32_t  iter  = 0;
 	LeanStamp stamp = {};
@@ -1754,8 +1728,6 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 				lean_march<SKIP, ERT, GRAD, PACKED, false, LF>(A, R, L, iter, stamp);
 		}
 	}
-	if (scout)
-		return;
 	if (A.tile_cost)
 	{        // the tile costs as much as its longest wave; a lane's `iter` stops counting when its ray ends
 		uint32_t it = iter;
@@ -1840,14 +1812,7 @@ __global__ void __launch_bounds__(256) VKV_NO_PACKED_FP32 __attribute__((amdgpu_
 	const uint32_t f = groups_per_frame == 0 ? g % n : g / groups_per_frame, gi = groups_per_frame == 0 ? g / n : g % groups_per_frame;
 	// (the anisotropic kernels that keep the per-pixel counters have no room under the 64-VGPR cap for the second march loop: they would spill)
 	constexpr uint32_t kLfBatch = (SKIP == VKV_SKIP_ANISOTROPIC_DISTANCE && (LF & kLeanNoCounts) == 0) ? (LF & ~kLeanSafe) : LF;
-#ifdef VKV_LAB_SCOUT
-	// the sequence of an XCD in groups of 17: one scout workgroup in front of every 16 blocks
-	const uint32_t grp = gi / 17u, within = gi % 17u;
-	const bool     scout = within == 0u;
-	lean_block<SKIP, ERT, GRAD, true, kLfBatch>(frames[f], ((grp * 16u + (scout ? 0u : within - 1u)) << 3) | (blockIdx.x & 7u), L, scout);
-#else
 	lean_block<SKIP, ERT, GRAD, true, kLfBatch>(frames[f], (gi << 3) | (blockIdx.x & 7u), L);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
