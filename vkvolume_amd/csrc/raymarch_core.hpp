@@ -1798,12 +1798,13 @@ __global__ void __launch_bounds__(256) k_raymarch_lean(const RayMarchArgs A)
 // held to 64 VGPRs = 8 waves per SIMD (the fast ray set-up first came out at 66: seven waves, 10 % slower with frames in flight: 0.1246
 // against 0.1101 ms per C3 frame).  Not the on-the-fly gradient variant (five trilinear taps per sample, ~100 VGPRs: it would spill) and
 // not the kernels without empty-space skipping (45 VGPRs anyway, but the occupancy target changes their schedule: dense sampling with 8
-// frames per launch 2.63 against 2.14 ms per frame)
+// frames per launch 2.63 against 2.14 ms per frame), and not the kernels without the LDS address tables (volumes without a packed image: at 64
+// registers their loop spills a few dwords, and a kernel with scratch makes its first launch allocate)
 // (Round 3, measured and dropped: workgroups of TWO waves - half a 16x16 block - with the two-level tables, so that wave slots are handed
 // back in smaller pieces: three single-frame launches in flight gain 5 % in the lab (0.1181 against 0.1242 ms per frame, variants 112 / 21),
 // this kernel loses 6 % (0.1167 against 0.1099; the two-level tables alone 0.1116): twice the workgroups to set up and to stage tables for.)
 template <int SKIP, bool ERT, int GRAD, uint32_t LF>
-__global__ void __launch_bounds__(256) VKV_NO_PACKED_FP32 __attribute__((amdgpu_waves_per_eu((GRAD == 2 || SKIP == VKV_SKIP_NONE) ? 1 : 8))) k_raymarch_lean_batch(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t groups_per_frame)
+__global__ void __launch_bounds__(256) VKV_NO_PACKED_FP32 __attribute__((amdgpu_waves_per_eu((GRAD == 2 || SKIP == VKV_SKIP_NONE || (LF & kLeanLut) == 0) ? 1 : 8))) k_raymarch_lean_batch(const RayMarchArgs *__restrict__ frames, uint32_t n, uint32_t groups_per_frame)
 {
 	lean_lds_check();
 	RmLds &        L = lean_lds();
