@@ -929,8 +929,9 @@ __device__ __forceinline__ bool block_pixel(const RayMarchArgs &A, uint32_t b, u
 //     tables indexed straight from the filtered values, and one colour channel is blended: no dependent global texel fetch;
 //   * the probe byte (probing lanes) and the four footprint dwords (sampling lanes) are issued under EXEC AHEAD of both outcome blocks
 //     (a wave barrier keeps the compiler from sinking them); lanes that cannot need a load sit it out;
-//   * probe outcome + state update and sample outcome + state update are two EXEC-masked blocks: plain moves and adds, no selects,
-//     no ballots, no merge values (63 VGPRs = 8 waves per SIMD);
+//   * loads (probe byte | footprint) and outcomes (probe | sample) are ONE if / else each, probe side first; the loop ends on its position
+//     (early termination moves it to the end: no done flag), the blend of a sample sits behind one wave-uniform branch (round 5: what costs
+//     in this loop is the number of instructions, EXEC writes and mask bookkeeping above all; 61 VGPRs = 8 waves per SIMD);
 //   * the footprint address is a sum of per-axis terms read from tables in LDS (kLeanLut / kLeanFull) instead of ~20 half-rate
 //     shift / mask / multiply instructions; clamp bounds come from scalar registers, the cell index from 24-bit multiply-adds;
 //   * the loop position, its bounds and the first hit are floats (exact: n_steps <= 2^24): no conversion at the head of an iteration;
