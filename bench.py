@@ -193,7 +193,7 @@ def build_scene(ctx, name, tf_preset="app", empty=False):
 
 
 def split_frames(n_steps, frames_per_launch):
-    """Frames of a block of n_steps spread evenly over ceil(n_steps / frames_per_launch) launches (20 steps, 8 per launch: 7 + 7 + 6)."""
+    """Frames of a block of n_steps spread evenly over ceil(n_steps / frames_per_launch) launches (20 steps, 6 per launch: 5 + 5 + 5 + 5; 8 per launch: 7 + 7 + 6)."""
     n_launches = -(-n_steps // frames_per_launch)
     out, k = [], 0
     for launch in range(n_launches):
@@ -237,9 +237,10 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: grow the frame with N (weak) or keep it (strong); default per workload")
     ap.add_argument("--submit", default=None, choices=["batch", "streams"], help="N = 1: vkv_render_batch launches (default) or single-frame launches "
                     "on --frames-in-flight streams; N > 1 always uses streams")
-    ap.add_argument("--batch-streams", type=int, default=3, help="batch submission: consecutive vkv_render_batch launches alternate over this many HIP streams "
+    ap.add_argument("--batch-streams", type=int, default=4, help="batch submission: consecutive vkv_render_batch launches alternate over this many HIP streams "
                     "(the tail of one launch overlaps the head of the next)")
-    ap.add_argument("--frames-per-launch", type=int, default=8, help="batch submission: frames per vkv_render_batch launch (1 = one frame per launch)")
+    ap.add_argument("--frames-per-launch", type=int, default=6, help="batch submission: frames per vkv_render_batch launch (1 = one frame per launch; 6 on 4 streams "
+                    "measures 1 - 4 % better than 8 on 3 on every workload: profiles/r5_submission_sweep.txt)")
     ap.add_argument("--frames-in-flight", type=int, default=3, help="stream submission: consecutive frames render on this many HIP streams")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the timed block of K steps until this much time has been measured")
     ap.add_argument("--frame-owner", default="rotate", choices=["rotate", "rank0"], help="N > 1: rank that assembles frame k: k mod N "
@@ -553,7 +554,7 @@ def job(args, env):
     def run_batch(n_steps, timed):
         k, launch = 0, 0
         bp = batch_params_depth if with_depth[0] else batch_params
-        for n in split_frames(n_steps, fpl):  # 20 steps with 8 per launch: 7 + 7 + 6, not 8 + 8 + 4
+        for n in split_frames(n_steps, fpl):  # 20 steps with 6 per launch: 5 + 5 + 5 + 5 (8 per launch: 7 + 7 + 6, not 8 + 8 + 4)
             st = streams[launch % nbs]  # stream of this launch
             slot = (launch % nsets) if gather else (launch % nbs)  # its set of output buffers
             owner = (launch % world) if rotate else 0  # gather path: the rank that assembles this launch's frames

@@ -12,20 +12,20 @@ B="python3 $R/bench.py --workload $wl --steps 64 --warmup 16 --no-cpu-baseline -
 run_stats() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$name -- $B "$@" > $O/bench_$name.json 2> $O/bench_$name.err; }
 run_pmc() { name=$1; ctr=$2; shift; shift; timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_${name}_$ctr -- $B --steps 16 --warmup 2 --min-seconds 0.1 "$@" > /dev/null 2> $O/pmc_${name}_$ctr.err; }
 run_stats default
-run_stats batch8 --batch-streams 1
+run_stats batch8 --frames-per-launch 8 --batch-streams 1
 run_stats single --frames-per-launch 1 --batch-streams 1
 run_stats streams3 --submit streams
 run_stats dense_single --skip none --no-ert --frames-per-launch 1 --batch-streams 1 --steps 16 --warmup 4
-run_pmc batch8 FETCH_SIZE --batch-streams 1
-run_pmc batch8 WRITE_SIZE --batch-streams 1
+run_pmc batch8 FETCH_SIZE --frames-per-launch 8 --batch-streams 1
+run_pmc batch8 WRITE_SIZE --frames-per-launch 8 --batch-streams 1
 run_pmc single FETCH_SIZE --frames-per-launch 1
 run_pmc single WRITE_SIZE --frames-per-launch 1
 # instruction mix of the ray-march kernels (SQ block, one pass): VALU / SALU / LDS / VMEM instructions, wave cycles and their wait shares
-run_pmc batch8 SQ_WAVES,SQ_WAVE_CYCLES,SQ_BUSY_CU_CYCLES,SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_ANY,SQ_INSTS_VALU,SQ_INSTS_SALU --batch-streams 1
-run_pmc batch8 SQ_INSTS_VMEM_RD,SQ_INSTS_LDS,SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_THREAD_CYCLES_VALU,SQ_INSTS_VALU_CVT,SQ_INSTS_VALU_FMA_F32,SQ_INSTS_VALU_INT32 --batch-streams 1
+run_pmc batch8 SQ_WAVES,SQ_WAVE_CYCLES,SQ_BUSY_CU_CYCLES,SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_ANY,SQ_INSTS_VALU,SQ_INSTS_SALU --frames-per-launch 8 --batch-streams 1
+run_pmc batch8 SQ_INSTS_VMEM_RD,SQ_INSTS_LDS,SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_THREAD_CYCLES_VALU,SQ_INSTS_VALU_CVT,SQ_INSTS_VALU_FMA_F32,SQ_INSTS_VALU_INT32 --frames-per-launch 8 --batch-streams 1
 # VALU busy of the ray-march kernel (the binding limit next to the HBM fraction): SQ_ACTIVE_INST_VALU * 4 / (SIMDs * GRBM_GUI_ACTIVE)
-run_pmc batch8 SQ_ACTIVE_INST_VALU,SQ_BUSY_CYCLES,GRBM_GUI_ACTIVE --batch-streams 1
-run_stats dense_batch8 --skip none --no-ert --steps 16 --warmup 8 --batch-streams 1
+run_pmc batch8 SQ_ACTIVE_INST_VALU,SQ_BUSY_CYCLES,GRBM_GUI_ACTIVE --frames-per-launch 8 --batch-streams 1
+run_stats dense_batch8 --skip none --no-ert --steps 16 --warmup 8 --frames-per-launch 8 --batch-streams 1
 for w in c2 c3cube c4 c5; do timeout 300 python3 $R/bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null; done
 timeout 600 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_driver_like.json 2> $O/bench_driver_like.err
 timeout 300 python3 $R/tools/time_precompute.py c3 > $O/precompute_times_c3.txt 2>&1

@@ -1,6 +1,6 @@
 """PREDICTED strong-scaling curve of BASELINE.json configs[4] (c5: 2048^3, anisotropic maps, the fixed 7680x4320 frame dealt over the ranks in
 16x16 tiles) from ONE GPU: for N = 2, 4, 8 the tile share of every rank r is rendered alone (`bench.py --workload c5 --virtual-rank r/N`,
-the bench's own submission: 8 frames per launch, 3 streams, no exchange), and
+the bench's own submission: 6 frames per launch, 4 streams, no exchange), and
 
     predicted_speedup(N) = t(N = 1) / (max_r t(r/N) + exchange),     exchange = bytes one rank sends per frame / 153 GB/s (one xGMI link)
 
