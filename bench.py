@@ -786,7 +786,7 @@ def job(args, env):
                    "output": "RGBA8",
                    "submission": ("vkv_render_batch, up to %d frames per launch, consecutive launches on %d HIP stream(s); tile start order from the "
                                   "tile costs measured on earlier frames into the same target (each target shows the same orbit view every block: the best "
-                                  "case for that feedback; VKV_RAYMARCH_FEEDBACK=0 measured 0.119 instead of 0.114 ms per frame on c3)" % (fpl, nbs)) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams (measured start order per target as well; each of the %d targets shows one orbit view)" % (fif, fif, nbuf)),
+                                  "case for that feedback; VKV_RAYMARCH_FEEDBACK=0 measured 0.1027 instead of 0.0986 ms per frame on c3)" % (fpl, nbs)) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams (measured start order per target as well; each of the %d targets shows one orbit view)" % (fif, fif, nbuf)),
                    "occupied_voxel_percent": round(occupied_voxel_percent(ctx, v, tf), 4)},
         "covered_Mray_per_s": round(cov_total / elapsed / 1e6, 3), "covered_fraction": round(cov_total / (rays_per_frame_all * args.steps), 4),
         "volume_samples_per_s": round(vs_total / elapsed, 1), "distance_probes_per_s": round(ds_total / elapsed, 1),
