@@ -322,8 +322,8 @@ def main():
     def side_block(key, holder, **over):
         """A short extra measurement with some options replaced, reported as holder[key].  It can never cost the headline: an exception becomes
         {"error": ...} (on every rank: the ranks agree on the outcome through one all-reduce), and a block that hangs - a collective one rank never
-        enters - is given up after --native-timeout seconds by a watchdog that prints the line as it stands and ends the process (fresh
-        processes were started by the launcher; nothing is re-executed)."""
+        enters - is given up after --native-timeout seconds by a watchdog that prints the line as it stands and ends the process with status 124
+        (fresh processes were started by the launcher; nothing is re-executed)."""
         a2 = copy.copy(args)
         for k, val in over.items():
             setattr(a2, k, val)
@@ -332,8 +332,8 @@ def main():
         def give_up():
             if rank == 0 and holder is not None:
                 holder[key] = {"error": "gave up after %.0f s (--native-timeout): the block did not finish" % args.native_timeout}
-            emit()
-            os._exit(0)
+            emit()  # the headline first, so the measurement is not lost
+            os._exit(124)  # non-zero like the --launch-timeout watchdog: a run whose collective hung is not a success
 
         dog = threading.Timer(args.native_timeout, give_up) if (world > 1 or use_gather) and args.native_timeout > 0 else None
         if dog:

@@ -218,8 +218,8 @@ typedef struct VkvTuning
 	int32_t  pack_tile;                /* vkv_pack_volume: 0 automatic, 2 / 4 = bricks per workgroup edge                 VKV_PACK_TILE */
 	int32_t  wave_shape;               /* width in pixels of a wave's 64-pixel patch: 0 automatic (4, 8 or 16 from the view: the shape that is most compact
 	                                      in voxels), or 4 / 8 / 16 (A/B switch, same bits)                                 VKV_RAYMARCH_WAVE_SHAPE */
-	int32_t  occupancy_kernel;         /* vkv_occupancy_map: 0 automatic (a wave per span of whole cells for every block width but 4), 1 = the workgroup-per-cell-row
-	                                      kernels of rounds 1-4 (A/B switch, same map)                                     VKV_OCCUPANCY_KERNEL=rows */
+	int32_t  occupancy_kernel;         /* vkv_occupancy_map: 0 automatic (k_occupancy_map_waves: a wave per span of 64 dwords, every block width), 1 = the
+	                                      workgroup-per-cell-row kernels of rounds 1-4 (A/B switch, same map)                                     VKV_OCCUPANCY_KERNEL=rows */
 	uint32_t arena_bytes;              /* read-only: size of the device arena vkv_create allocated                        VKV_ARENA_BYTES */
 } VkvTuning;
 int vkv_get_tuning(const vkv_ctx *ctx, VkvTuning *out);

@@ -117,9 +117,10 @@ def gradient_map(vol, tf):
     return grad
 
 
-def occupancy_map(vol, grad, tf_tex, tf, block):
+def occupancy_map(vol, grad, tf_tex, tf, block, map_extent_override=None):
+    """map_extent_override: a map extent that is not ceil(extent / block) (the block size then follows from it, src/compute_distance_map.cpp:110-113)"""
     vol = np.ascontiguousarray(vol, np.uint8)
-    me = map_extent(_extent_of(vol), block)
+    me = map_extent_override if map_extent_override is not None else map_extent(_extent_of(vol), block)
     out = np.empty((me.depth, me.height, me.width), np.uint8)
     lib().vkvo_occupancy_map(_ptr(vol), _ptr(grad), _ptr(tf_tex), C.byref(tf), _extent_of(vol), _ptr(out), me)
     return out

@@ -186,6 +186,43 @@ def test_gradient_and_occupancy_fuzz(ctx, seed):
     assert int(d_count.item()) == O.occupied_voxel_count(scene.vol, scene.grad, scene.tf), "occupied voxel count, " + what
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "16"))))
+def test_occupancy_map_extents_beyond_the_volume(ctx, seed):
+    """the ABI accepts any map extent <= the volume's; block = ceil(extent / map extent) can then leave whole cell rows / slices
+    outside the volume (16^3 voxels under a 7^3 map: block 3, cells 6 of y and z hold no voxel).  Such cells stay EMPTY (the reference's loop
+    over a cell's voxels is clipped at the volume edge, occupancy_map.comp:52-53) - in the wave kernel, the workgroup-per-cell-row kernels
+    (VkvTuning.occupancy_kernel = 1) and the oracle alike, and nothing is read past the volume."""
+    rng = np.random.default_rng(4200 + seed)
+    if seed == 0:
+        shape, me = (16, 16, 16), abi.Extent3D(7, 7, 7)
+    elif seed == 1:
+        shape, me = (256, 33, 21), abi.Extent3D(100, 12, 8)
+    else:
+        shape = (int(rng.choice([16, 64, 68, 132, 256, 260])), int(rng.integers(5, 70)), int(rng.integers(5, 50)))
+        me = abi.Extent3D(*(int(rng.integers(max(1, -(-n // int(rng.integers(2, 7)))), n + 1)) for n in shape))
+    vol = T.random_volume(shape, seed=seed, sparsity=0.9)
+    variant = ("precomputed", "no_gradient")[seed % 2]
+    opt = abi.VolumeOptions(intensity_min=0.1, gradient_min=0.0, gradient_max=0.0) if variant == "no_gradient" else abi.VolumeOptions(**T.APP_TF)
+    scene = T.OracleScene(vol, opt, 4)
+    expect = O.occupancy_map(scene.vol, scene.grad, scene.tex, scene.tf, 0, map_extent_override=me)
+    v, tf = make_gpu_volume(ctx, scene)
+    st = torch.cuda.current_stream().cuda_stream
+    t0 = ctx.get_tuning()
+    got = {}
+    try:
+        for kernel in (0, 1):
+            ctx.set_tuning(occupancy_kernel=kernel)
+            d_map = torch.full(expect.shape, 77, dtype=torch.uint8, device="cuda")
+            ctx.occupancy_map(v.volume.data_ptr(), v.gradient.data_ptr() if variant == "precomputed" else None, v.transfer_function.data_ptr(), tf,
+                              v.extent, d_map.data_ptr(), me, st)
+            got[kernel] = d_map.cpu().numpy()
+    finally:
+        ctx.set_tuning(occupancy_kernel=t0.occupancy_kernel)
+    what = "shape %s map %s %s" % (shape, me.as_tuple(), variant)
+    assert np.array_equal(got[0], expect), "wave kernel, " + what
+    assert np.array_equal(got[1], expect), "row kernels, " + what
+
+
 def sparse_occupancy(shape_dhw, seed, p):
     rng = np.random.default_rng(seed)
     return np.where(rng.random(shape_dhw) < p, 0, 255).astype(np.uint8)

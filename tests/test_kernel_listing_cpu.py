@@ -1,7 +1,8 @@
 """Properties of the compiled ray-march kernels that no run can show but the measurements depend on, read from the compiler's listing of
 the bench's translation unit (hipcc cross-compiles gfx950 without a GPU; ~30 s):
   * the march loops with hand-set load waits start with the PROBE side (its byte is the oldest load in flight and its outcome runs while the
-    footprint gathers are under way: lean_march; the result does not depend on the order, the frame time does);
+    footprint gathers are under way: lean_march; the result does not depend on that order, the frame time does), and the loads in front
+    of the hand-set wait are the probe byte FOLLOWED by the four footprint dwords (the result does depend on this one: vmcnt(4) releases the oldest load);
   * the batch kernels of the packed-image path fit their 64-register budget without scratch (a kernel with scratch makes its first launch
     allocate device memory, which vkv_render / vkv_render_batch promise not to do)."""
 import os
@@ -40,6 +41,9 @@ def test_march_loops_with_hand_set_waits_start_with_the_probe_side(listing):
     assert r.returncode == 0, r.stdout[-2000:]
     assert r.stdout.count("probe side first") >= 8, r.stdout[-2000:]        # the clamp-free loop and the loop with the clamps of every such kernel
     assert "SAMPLE side first" not in r.stdout
+    # the hand-set vmcnt(4) releases the probe byte only when it was issued BEFORE the four footprint dwords
+    assert "LOAD ORDER" not in r.stdout, r.stdout[-2000:]
+    assert r.stdout.count("loads in front of the wait: probe byte, then four footprint dwords") == r.stdout.count("probe side first")
 
 
 def test_batch_kernels_have_no_scratch_and_the_bench_kernel_keeps_eight_waves(listing):

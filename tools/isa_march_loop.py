@@ -1,7 +1,8 @@
 """The march loop of each ray-march kernel in a `hipcc -S --cuda-device-only` listing: the SMALLEST backward-branch region that holds the
 probe byte load and the four footprint loads.  Prints instruction counts by class; with --dump the loop's instructions; with --order
 which outcome block comes first in the loops with hand-set load waits (the probe side must: its byte is the oldest load, lean_march) -
-exit code 1 if a loop starts with the sample side.
+exit code 1 if a loop starts with the sample side or if the loads in front of the hand-set wait are not
+"probe byte, then the four footprint dwords" (vmcnt counts loads in issue order: the wait releases the oldest).
 usage: isa_march_loop.py file.s [name-filter] [--dump] [--order]"""
 import re
 import sys
@@ -52,6 +53,15 @@ for f in re.split(r'\n(?=_Z\w+:)', s):
             if w4 is not None and cv is not None:
                 print("    %s side first" % ("probe" if w4 < cv else "SAMPLE"))
                 bad_order += w4 > cv
+                # the hand-set vmcnt(4) in front of the probe outcome releases the probe BYTE only if that byte is the oldest of the iteration's
+                # loads: the vector-memory loads in front of the wait must be exactly one global_load_ubyte followed by the four footprint dwords
+                # (nothing else pins the order of the two sides of the load if / else)
+                vm = [x.split()[0] for x in seg[:w4] if x.startswith(('global_load', 'buffer_load', 'flat_load', 'global_store', 'buffer_store', 'flat_store'))]
+                if vm == ['global_load_ubyte'] + ['global_load_dword'] * 4:
+                    print("    loads in front of the wait: probe byte, then four footprint dwords")
+                else:
+                    print("    LOAD ORDER in front of the wait: %s" % " ".join(vm))
+                    bad_order += 1
         if dump:
             print("\n".join("    " + x for x in seg))
 if order and bad_order:

@@ -414,7 +414,11 @@ __global__ void __launch_bounds__(256) k_occupancy_map_waves(const uint8_t *__re
 				in = 0, step |= 1u << i;
 	}
 	const int    z_end = min((cz + 1) * bz, D), nz = z_end - cz * bz;
-	const int    cy_end = min(cy0 + cy_per_wave, mh);
+	// a map may have more cell rows / slices than the volume fills (map extent > ceil(extent / block), e.g. 16^3 voxels under a 7^3 map:
+	// block 3, cells 6 of y and z lie outside): those cells hold no voxel and stay EMPTY, like in the workgroup-per-cell-row kernels
+	const int    cy_end = min(min(cy0 + cy_per_wave, mh), (H + by - 1) / by);
+	if (nz <= 0 || cy0 >= cy_end)
+		return;
 	const size_t zs = (size_t) H * (size_t) W;
 	for (int cy = cy0; cy < cy_end; cy += CRB)
 	{

@@ -452,6 +452,21 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	std::vector<uint8_t> upload(kPullHeadsBytes + n * sizeof(RayMarchArgs), 0);
 	std::memcpy(upload.data() + kPullHeadsBytes, host.data(), n * sizeof(RayMarchArgs));
 	const void *upload_src = upload.data();
+	// a capture slot taken below returns to the context on every error path: only a launch that was recorded keeps it
+	struct SlotGuard
+	{
+		vkv_ctx *ctx;
+		size_t   index;
+		bool     armed;
+		~SlotGuard()
+		{
+			if (!armed)
+				return;
+			std::lock_guard<std::mutex> lock(ctx->mutex);
+			if (index < ctx->capture_slots.size())
+				ctx->capture_slots[index].in_use = false, ctx->capture_slots[index].owner = nullptr;
+		}
+	} slot_guard{ctx, 0, false};
 	{        // A stream that is being captured into a hipGraph records the copy's SOURCE POINTER and reads it at every replay: the block then has to
 		 // outlive the call - a pinned slot the context keeps until vkv_trim / vkv_destroy
 		hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
@@ -479,18 +494,18 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 				(void) hipThreadExchangeStreamCaptureMode(&mode);
 				const hipError_t ea = hipHostMalloc(&hp, kCaptureSlotBytes, hipHostMallocDefault);
 				const hipError_t eb = ea == hipSuccess ? hipMalloc(&dp, kCaptureSlotBytes) : ea;
+				const bool failed = ea != hipSuccess || eb != hipSuccess || !hp || !dp;
+				if (failed && hp)
+					(void) hipHostFree(hp);        // still inside the relaxed window: a free under the capture's own mode could invalidate it
 				(void) hipThreadExchangeStreamCaptureMode(&mode);
-				if (ea != hipSuccess || eb != hipSuccess || !hp || !dp)
-				{
-					if (hp)
-						(void) hipHostFree(hp);
+				if (failed)
 					return set_error(ctx, VKV_E_UNSUPPORTED, "render_batch: no argument block for a captured launch: %s", hipGetErrorString(ea != hipSuccess ? ea : eb));
-				}
 				c.pinned = static_cast<uint8_t *>(hp), c.device = static_cast<uint8_t *>(dp);
 				ctx->capture_slots.push_back(c);
 				slot = &ctx->capture_slots.back();
 			}
 			slot->in_use = true, slot->owner = s;
+			slot_guard.index = (size_t) (slot - ctx->capture_slots.data()), slot_guard.armed = true;
 			std::memcpy(slot->pinned, upload.data(), upload.size());
 			upload_src = slot->pinned;
 			d_heads    = reinterpret_cast<uint32_t *>(slot->device);
@@ -538,7 +553,9 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: bad skipping_type %d", P[0].options.skipping_type);
 		if (any_sort)
 			hipLaunchKernelGGL(k_tile_orders_from_cost, dim3(n), dim3(256), 0, s, d_frames);
-		return check_launch(ctx, "render_batch");
+		const int rc_pull = check_launch(ctx, "render_batch");
+		slot_guard.armed = slot_guard.armed && rc_pull != VKV_OK;
+		return rc_pull;
 	}
 	if (!launch_batch(P[0].options.skipping_type, ert, grad, d_frames, n, (uint32_t) grid, gpf, choice, no_counts, s))
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: bad skipping_type %d", P[0].options.skipping_type);
@@ -546,7 +563,9 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	// sort is not in front of anybody's render this way; in front it cost 70 us per 20-frame block of three launches)
 	if (any_sort)
 		hipLaunchKernelGGL(k_tile_orders_from_cost, dim3(n), dim3(256), 0, s, d_frames);
-	return check_launch(ctx, "render_batch");
+	const int rc_launch = check_launch(ctx, "render_batch");
+	slot_guard.armed = slot_guard.armed && rc_launch != VKV_OK;
+	return rc_launch;
 }
 
 }        // namespace vkv
