@@ -21,9 +21,11 @@ the others; streams that happen to share a hardware queue simply serialise, whic
 `--submit streams` keeps `--frames-in-flight` single-frame launches in flight on as many HIP streams (the round 1 scheme).
 The one-frame-at-a-time launch duration is always measured too (`single_frame`, outside the timed region).
 
-N > 1: the frame is cut into 16x16 tiles dealt round-robin to the ranks (volume replicated); each rank renders its tiles into a
-compact RGBA8 buffer, the buffers are gathered over RCCL to the frame's owner (rank k mod N for frame k, so that consecutive
-frames use disjoint xGMI links; --frame-owner rank0 pins it) and de-interleaved there.  `--scaling weak` (default for c2/c3/c4):
+N > 1: the tiles of the frame's screen rectangle (the 16x16 tiles the clipped box projects into: vkv_screen_tile_rect, derived by every
+rank from the uniforms; --tile-rect off = every tile of the frame) are dealt round-robin to the ranks (volume replicated); each rank renders
+its tiles into a compact RGBA8 buffer, the buffers are gathered over RCCL to the owner of the launch (rank l mod N for launch l, so that
+consecutive launches use disjoint xGMI links; --frame-owner spread: frame j of launch l to rank (l + j) mod N; rank0 pins it) and
+de-interleaved there (the rest of the image is cleared).  `--scaling weak` (default for c2/c3/c4):
 the frame grows to (W*sx)x(H*sy), sx*sy = N, sampling the SAME frustum; `--scaling strong` (default for c5, BASELINE.json
 configs[4]): the frame stays 7680x4320 whatever N is.  value = rays of all ranks / max-over-ranks wall time.
 
@@ -243,8 +245,12 @@ def main():
                     "measures 1 - 4 % better than 8 on 3 on every workload: profiles/r5_submission_sweep.txt)")
     ap.add_argument("--frames-in-flight", type=int, default=3, help="stream submission: consecutive frames render on this many HIP streams")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the timed block of K steps until this much time has been measured")
-    ap.add_argument("--frame-owner", default="rotate", choices=["rotate", "rank0"], help="N > 1: rank that assembles frame k: k mod N "
-                    "(default; the inbound xGMI links and the de-interleave of consecutive frames are then disjoint) or always rank 0")
+    ap.add_argument("--frame-owner", default="rotate", choices=["rotate", "spread", "rank0"], help="N > 1: rank that assembles a launch's frames: launch l on rank l mod N "
+                    "(rotate, default: the inbound xGMI links and the de-interleave of consecutive launches are disjoint), frame j of launch l on rank (l + j) mod N "
+                    "(spread: every GPU receives at once; batch submission), or always rank 0")
+    ap.add_argument("--tile-rect", default="on", choices=["on", "off"], help="N > 1 / --virtual-rank / --force-gather: schedule and exchange only the tiles of each "
+                    "frame's screen rectangle (vkv_screen_tile_rect: the clipped box's projection, derived by every rank from the uniforms; default) or every "
+                    "tile of the frame (off: rounds 1-5)")
     ap.add_argument("--exchange", default="torch", choices=["native", "torch"], help="N > 1: the tile gather through torch.distributed.gather (default: "
                     "0.170 ms per step in the one-rank pipeline test) or through the C ABI (vkv_gather_tiles / vkv_scatter_tiles: ncclGather on a "
                     "communicator of our own, no torch.distributed on the data path; 0.190 ms per step in the same test)")
@@ -361,7 +367,7 @@ def main():
 
     def brief(o, extra=()):
         d = {k: o[k] for k in ("ms_per_step", "value", "unit", "steps", "warmup", "repeats", "scaling", "covered_Mray_per_s", "phases", "rccl_ranks",
-                                "rccl_ranks_source", "volume_samples_per_s", "distance_probes_per_s") + tuple(extra) if k in o}
+                                "rccl_ranks_source", "volume_samples_per_s", "distance_probes_per_s", "exchange_bytes_per_frame") + tuple(extra) if k in o}
         d.update(frac=o["roofline"]["frac"], achieved=o["roofline"]["achieved"], workload=o["config"]["workload"], parallelism=o["config"]["parallelism"])
         return d
 
@@ -370,11 +376,15 @@ def main():
         run on real links carries the product's gather next to torch.distributed's"""
         if not (use_gather and args.exchange == "torch" and submit == "batch" and (args.native_block == "on" or (args.native_block == "auto" and args.backend == "nccl"))):
             return
-        tmp = {}
-        side_block("n", tmp if rank == 0 else None, exchange="native", steps=min(args.steps, 16), warmup=min(args.warmup, 8), min_seconds=min(args.min_seconds, 0.5), **over)
-        if rank == 0 and o is not None:
-            r = tmp.get("n")
-            o["native_exchange"] = r if (r is None or "error" in r) else brief(r)
+        # twice: the launch's owner rotating (launch l -> rank l mod N, ONE ncclGather per launch) and the owners spread inside a launch (frame j of
+        # launch l -> rank (l + j) mod N, one RCCL group of gathers per launch: every GPU receives at once)
+        for key, owner in (("native_exchange", args.frame_owner if args.frame_owner != "spread" else "rotate"), ("native_exchange_spread", "spread")):
+            tmp = {}
+            side_block("n", tmp if rank == 0 else None, exchange="native", frame_owner=owner, steps=min(args.steps, 16), warmup=min(args.warmup, 8),
+                       min_seconds=min(args.min_seconds, 0.5), **over)
+            if rank == 0 and o is not None:
+                r = tmp.get("n")
+                o[key] = r if (r is None or "error" in r) else brief(r)
 
     out = job(args, env)
     state["out"] = out
@@ -445,14 +455,29 @@ def job(args, env):
         if len(virtual) != 2 or not (0 <= virtual[0] < virtual[1]):
             raise SystemExit("--virtual-rank R/N needs 0 <= R < N")
     compact = use_gather or virtual is not None
-    tiles = abi.full_frame_tiles(fw, fh, TILE, TILE, virtual[0] if virtual else rank, virtual[1] if virtual else world, compact=compact)
-    params = [sp.make_params(view, proj, tiles) for view, proj in views]
-    my_pixels = tiles.tile_count * TILE * TILE if compact else fw * fh
-    # every pixel of the frame is a ray (covered or not), summed over ranks; a virtual rank counts its own share only
-    rays_per_frame_all = my_pixels if virtual else fw * fh
+    my_rank, n_ranks = (virtual if virtual else (rank, world))
+    # Sharded frames (N > 1, the one-rank proxies): only the tiles of each view's screen rectangle are scheduled and exchanged - the tile rectangle
+    # the clipped box projects into, derived by every rank from the uniforms alone (vkv_screen_tile_rect); the de-interleave clears the rest.
+    use_rect = compact and getattr(args, "tile_rect", "on") != "off"
+    whole_rect = abi.whole_image_rect(fw, fh, TILE, TILE)
+    params, rects, tiles_v = [], [], []
+    for view, proj in views:
+        p = sp.make_params(view, proj, abi.full_frame_tiles(fw, fh, TILE, TILE))
+        r = lib.screen_tile_rect(p.ray_cast, p.ray_gen, (fw, fh), (TILE, TILE)) if use_rect else whole_rect
+        t = abi.full_frame_tiles(fw, fh, TILE, TILE, my_rank, n_ranks, compact=compact, rect=r if use_rect else None)
+        p.tiles = t
+        params.append(p)
+        rects.append(r)
+        tiles_v.append(t)
+    tiles = tiles_v[0]  # (N = 1 without a proxy: the one schedule of every view - all tiles of the frame)
+    pixels_v = [t.tile_count * TILE * TILE if compact else fw * fh for t in tiles_v]  # output slots of this rank per view
+    my_pixels = max(pixels_v)
+    # every pixel of the frame is a ray (covered or not), summed over ranks - the assembled frame is complete, whatever was exchanged; a virtual
+    # rank counts the share of the WHOLE frame's pixels it stands for (1 / N of them: its value stays comparable with the frame's)
+    rays_per_frame_all = (fw * fh / n_ranks) if virtual else fw * fh
 
     # ---- pre-pass (untimed): frag counters per view -> algorithmic bytes per frame ---------------------------------
-    counts = torch.zeros((my_pixels, 3), dtype=torch.int32, device="cuda")
+    counts = torch.zeros((max(my_pixels, 1), 3), dtype=torch.int32, device="cuda")
     n_vs, n_ds, n_cov = [], [], []
     for p in params:
         counts.zero_()
@@ -467,11 +492,15 @@ def job(args, env):
     # ---- outputs -------------------------------------------------------------------------------------------------
     fif = max(1, args.frames_in_flight)
     fpl = max(1, min(args.frames_per_launch, abi.MAX_BATCH, args.steps))
-    gather, images, rotate = None, [], False
+    gather, images, rotate, spread = None, [], False, False
     nbs = max(1, args.batch_streams) if submit == "batch" else 1
     nsets = nbs + 1  # gather path: one more buffer set than render streams, so a launch does not wait for the exchange nbs launches back
-    if use_gather and submit == "batch":
-        rotate = args.frame_owner == "rotate" and world > 1
+    batch_gather = use_gather and submit == "batch"
+    if batch_gather:
+        rotate = args.frame_owner in ("rotate", "spread") and world > 1
+        # spread: frame j of launch l is assembled on rank (l + j) mod N (one gather per frame; natively all of a launch's in ONE RCCL group), so
+        # every GPU receives at the same time over its own inbound links; the one-rank proxy takes the same code path with every owner 0
+        spread = args.frame_owner == "spread"
         if args.exchange == "native":
             gather = multigpu.NativeBatchExchange(ctx, dist, rank, world, (fw, fh), TILE, 4, frames=fpl, n_sets=nsets, any_root=rotate)
             images = gather.images or []
@@ -481,10 +510,10 @@ def job(args, env):
             if rank == 0 or rotate:
                 images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nsets * fpl)]
         nbuf = nsets * fpl
-        bufs, my_rays = gather.buffers, gather.my_ray_count()
+        bufs = None  # the frames of a launch lie back to back in the launch's buffer set (gather.frame_pointer)
     elif use_gather:
         nbuf = fif + 1  # one more buffer than render streams: a render does not wait for the gather of the frame fif steps back
-        rotate = args.frame_owner == "rotate" and world > 1
+        rotate = args.frame_owner in ("rotate", "spread") and world > 1
         if args.exchange == "native":
             gather = multigpu.NativeExchange(ctx, dist, rank, world, (fw, fh), TILE, 4, n_buffers=nbuf, any_root=rotate)
             images = gather.images or []
@@ -494,73 +523,105 @@ def job(args, env):
             gather = multigpu.TileGather(dist, rank, world, (fw, fh), TILE, 4, device="cuda", n_buffers=nbuf, any_root=rotate)
             if rank == 0 or rotate:
                 images = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
-        bufs, my_rays = gather.buffers, gather.my_ray_count()
+        bufs = gather.buffers
     else:
         # per-frame submission: as many targets as keep every target on ONE of the orbit views (like the slots of the batch path)
         nbuf = fpl * nbs if submit == "batch" else -(-fif // N_VIEWS) * N_VIEWS
         if virtual:
-            bufs, my_rays = [torch.zeros((my_pixels, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)], my_pixels
+            bufs = [torch.zeros((max(my_pixels, 1), 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
         else:
-            bufs, my_rays = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)], fw * fh
-    # set-up: the per-target state of the start-order feedback (vkv_render itself never allocates)
-    for t in bufs:
-        ctx.register_target(t.data_ptr(), (fw, fh), tiles)
-    torch.cuda.synchronize()
+            bufs = [torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+    # in-image pixels this rank renders of every view (the 4 B per ray of the algorithmic bytes; edge tiles of the frame are partial)
+    if compact:
+        rays_v = [multigpu.rect_ray_count(r, my_rank, n_ranks, (fw, fh), TILE) for r in rects]
+    else:
+        rays_v = [fw * fh] * N_VIEWS
+    # what the exchange moves: ceil(tiles of the view's rectangle / N) tiles of RGBA8 from every rank to the frame's owner
+    exchange_bytes_v = [multigpu.tiles_per_rank(r, n_ranks) * TILE * TILE * B_OUT for r in rects]
+    exchange_bytes_whole = multigpu.tiles_per_rank(whole_rect, n_ranks) * TILE * TILE * B_OUT
+    # set-up: the per-target state of the start-order feedback (vkv_render itself never allocates); a target is registered once, for the
+    # schedule of the first view it shows (frames of another schedule into it start centre-first)
+    registered = set()
+
+    def register(ptr, view_i):
+        if ptr not in registered:
+            registered.add(ptr)
+            ctx.register_target(ptr, (fw, fh), tiles_v[view_i])
+
     # algorithmic bytes of one frame (this rank's part): 8 B per trilinear footprint of the volume, 8 more for the gradient map's when the
     # transfer function has a gradient term, 1 B per distance probe
     b_sample = 16 if tf.use_gradient else 8
-    frame_bytes = [n_vs[i] * b_sample + n_ds[i] * 1 + my_rays * B_OUT for i in range(N_VIEWS)]
+    frame_bytes = [n_vs[i] * b_sample + n_ds[i] * 1 + rays_v[i] * B_OUT for i in range(N_VIEWS)]
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(max(fif, nbs) - 1)]
     # the exchange streams get the higher priority: their small kernels (RCCL's gather, the de-interleave) must not queue behind the render
     # workgroups of the next frames (native exchange with a one-rank group: 0.25 -> 0.19 ms per step)
     side = torch.cuda.Stream(priority=-1) if gather else None
     xchg = torch.cuda.Stream(priority=-1) if gather else None  # native exchange: RCCL's gather here, the de-interleave on `side`
-    freed = [None] * (nsets if (use_gather and submit == "batch") else nbuf)
+    freed = [None] * (nsets if batch_gather else nbuf)
     launches = []  # (start event, stop event, algorithmic bytes) of the timed launches of the last block
     phases = []  # gather path, launches this rank owns: (render start, render end, gathered or None, de-interleaved) events
     phase_ms = {"render_ms": [], "gather_ms": [], "scatter_ms": [], "exchange_ms": []}
 
-    # per-launch parameter blocks of the batch path: slot j of a launch renders into bufs[j]
-    batch_params = None
-    if submit == "batch":
-        batch_params = []
-        for view_i in range(N_VIEWS):
-            row = []
-            for j in range(nbuf):
-                q = abi.RenderParams.from_buffer_copy(params[view_i])
-                q.d_out_rgba8, q.d_out_color, q.d_out_counts, q.d_out_depth = bufs[j].data_ptr(), None, None, None
-                q.d_in_depth, q.blend_over_target = None, 0
-                row.append(q)
-            batch_params.append(row)
+    def plan(n_steps):
+        """the launches of a block of n_steps: (first step, frames, stream index, buffer set, owner of the launch, owners of its frames or None)"""
+        k, out_ = 0, []
+        for launch, n in enumerate(split_frames(n_steps, fpl)):  # 20 steps with 6 per launch: 5 + 5 + 5 + 5 (8 per launch: 7 + 7 + 6, not 8 + 8 + 4)
+            owner = (launch % world) if rotate else 0  # gather path: the rank that assembles this launch's frames
+            roots = [((launch + j) % world) if rotate else 0 for j in range(n)] if spread else None
+            out_.append((k, n, launch % nbs, (launch % nsets) if gather else (launch % nbs), owner, roots))
+            k += n
+        return out_
 
-    # the same parameter blocks with gl_FragDepth written as well (frag:315-321; the reference's subpass always writes depth): timed in a
-    # block of its own after the headline blocks, reported as ms_per_step_with_depth
-    depth_bufs, batch_params_depth = None, None
-    if submit == "batch" and not use_gather and not args.no_depth_block and not virtual:
+    # per-launch parameter blocks of the batch path.  N = 1: slot j of a launch renders into bufs[j].  Gather path: the frames of a launch lie
+    # back to back in the launch's buffer set - frame j at the tile offset its predecessors' rectangles leave (multigpu.launch_layout) - so the
+    # blocks depend on which views a launch holds: built once per (first view, frames, set) before the warm-up
+    depth_bufs = None
+    want_depth = submit == "batch" and not use_gather and not args.no_depth_block and not virtual
+    if want_depth:
         depth_bufs = [torch.zeros((fh, fw), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
-        batch_params_depth = []
-        for view_i in range(N_VIEWS):
-            row = []
-            for j in range(nbuf):
-                q = abi.RenderParams.from_buffer_copy(batch_params[view_i][j])
-                q.d_out_depth = depth_bufs[j].data_ptr()
-                row.append(q)
-            batch_params_depth.append(row)
+    launch_cache = {}
+
+    def launch_params(k, n, slot, depth):
+        key = (k % N_VIEWS, n, slot, depth)
+        hit = launch_cache.get(key)
+        if hit is not None:
+            return hit
+        idx = [(k + j) % N_VIEWS for j in range(n)]
+        rl = [rects[i] for i in idx]
+        off = multigpu.launch_layout(rl, world)[1] if batch_gather else None
+        plist = []
+        for j, i in enumerate(idx):
+            q = abi.RenderParams.from_buffer_copy(params[i])
+            target = gather.frame_pointer(slot, off[j]) if batch_gather else bufs[slot * fpl + j].data_ptr()
+            q.d_out_rgba8, q.d_out_color, q.d_out_counts = target, None, None
+            q.d_out_depth = depth_bufs[slot * fpl + j].data_ptr() if depth else None  # gl_FragDepth as well (frag:315-321): ms_per_step_with_depth
+            q.d_in_depth, q.blend_over_target = None, 0
+            register(target, i)
+            plist.append(q)
+        launch_cache[key] = (plist, rl)
+        return launch_cache[key]
+
+    if submit == "batch":
+        for n_steps in (args.warmup, args.steps):
+            for k, n, _, slot, _, _ in plan(n_steps):
+                launch_params(k, n, slot, False)
+                if want_depth:
+                    launch_params(k, n, slot, True)
+    else:
+        for j, t in enumerate(bufs):
+            register(t.data_ptr(), j % N_VIEWS)
+    torch.cuda.synchronize()
 
     last_slot, last_owner = [0], [0]
     with_depth = [False]
     native = gather is not None and args.exchange == "native"
 
     def run_batch(n_steps, timed):
-        k, launch = 0, 0
-        bp = batch_params_depth if with_depth[0] else batch_params
-        for n in split_frames(n_steps, fpl):  # 20 steps with 6 per launch: 5 + 5 + 5 + 5 (8 per launch: 7 + 7 + 6, not 8 + 8 + 4)
-            st = streams[launch % nbs]  # stream of this launch
-            slot = (launch % nsets) if gather else (launch % nbs)  # its set of output buffers
-            owner = (launch % world) if rotate else 0  # gather path: the rank that assembles this launch's frames
-            launch += 1
-            plist = [bp[(k + j) % N_VIEWS][slot * fpl + j] for j in range(n)]
+        for k, n, si, slot, owner, roots in plan(n_steps):
+            st = streams[si]  # stream of this launch
+            plist, rl = launch_params(k, n, slot, with_depth[0])
             last_slot[0] = slot * fpl + n - 1  # output buffer of the block's last step (--verify)
+            mine = (rank in roots) if roots else (rank == owner)  # this rank assembles a frame of the launch
             with torch.cuda.stream(st):
                 if gather and freed[slot] is not None:
                     st.wait_event(freed[slot])  # the exchange that last used this buffer set has read it
@@ -578,38 +639,35 @@ def job(args, env):
                     rendered = torch.cuda.Event()
                     rendered.record(st)
                 elif gather:
-                    gather.start(slot, owner, n)  # ONE collective for the launch's n frames, ordered after the render
+                    gather.start(slot, owner, rl, roots)  # ONE collective for the launch's n frames (or one per frame), ordered after the render
             if gather and native:
-                # vkv_assemble_frames on the exchange stream, behind the launch: one ncclGather + one de-interleave kernel, nothing waits on the host
+                # vkv_assemble_frames on the exchange stream, behind the launch: one ncclGather (or one group) + one de-interleave kernel, nothing waits on the host
                 xchg.wait_event(rendered)
-                gather.assemble(slot, owner, n, xchg)
-                if timed and rank == owner:  # phases of a launch on its owner: render, then gather + de-interleave (one call here)
+                gather.assemble(slot, owner, n, xchg, rects=rl if use_rect else None, roots=roots)
+                if timed and mine:  # phases of a launch on a rank that assembles part of it: render, then gather + de-interleave (one call here)
                     x1 = torch.cuda.Event(enable_timing=True)
                     x1.record(xchg)
                     phases.append((e0, e1, None, x1))
                 freed[slot] = torch.cuda.Event()
                 freed[slot].record(xchg)
-                last_owner[0] = owner
+                last_owner[0] = roots[-1] if roots else owner
             elif gather:
                 with torch.cuda.stream(side):
                     got = gather.finish(slot)
-                    if got is not None:
+                    if got:
                         g1 = None
                         if timed:
                             g1 = torch.cuda.Event(enable_timing=True)
-                            g1.record(side)  # the launch's block has arrived from every rank
-                        flat, nf = got
-                        for j in range(nf):
-                            src, stride = gather.frame_source(flat, j)
-                            ctx.scatter_tiles(src, images[slot * fpl + j].data_ptr(), (fw, fh), (TILE, TILE), world, stride, 4, side.cuda_stream)
+                            g1.record(side)  # the launch's frames this rank assembles have arrived from every rank
+                        for f, src, stride, r in got:
+                            ctx.scatter_tiles(src, images[slot * fpl + f].data_ptr(), (fw, fh), (TILE, TILE), world, stride, 4, side.cuda_stream, rect=r)
                         if timed:
                             s1 = torch.cuda.Event(enable_timing=True)
                             s1.record(side)
                             phases.append((e0, e1, g1, s1))
                     freed[slot] = torch.cuda.Event()
                     freed[slot].record(side)
-                last_owner[0] = owner
-            k += n
+                last_owner[0] = roots[-1] if roots else owner
 
     # HIP events bracket every launch at N = 1; on the gather path every 7th (a timing event per launch costs ~25 us per step
     # there, more than 10 % of the step, once seven queues are busy)
@@ -634,11 +692,11 @@ def job(args, env):
                     rendered.record(st)
                 elif gather:
                     # RCCL gather of frame k (ordered after the render) overlaps the renders of the next frames
-                    gather.start(b, k % world if rotate else 0)
+                    gather.start(b, k % world if rotate else 0, rects[k % N_VIEWS])
             if gather and native:
                 # gather + de-interleave of frame k on the assembly stream, behind its render: nothing waits on the host
                 xchg.wait_event(rendered)
-                last = gather.assemble(b, k % world if rotate else 0, xchg, side)
+                last = gather.assemble(b, k % world if rotate else 0, xchg, side, rect=rects[k % N_VIEWS])
                 freed[b] = torch.cuda.Event()
                 freed[b].record(last)
             elif gather:
@@ -646,7 +704,7 @@ def job(args, env):
                     flat = gather.finish(b)
                     if flat is not None:
                         ctx.scatter_tiles(flat.data_ptr(), images[b].data_ptr(), (fw, fh), (TILE, TILE), world, gather.tiles_per_rank, 4,
-                                          side.cuda_stream)
+                                          side.cuda_stream, rect=rects[k % N_VIEWS])
                     freed[b] = torch.cuda.Event()
                     freed[b].record(side)
 
@@ -705,7 +763,7 @@ def job(args, env):
 
     # ---- the same block with gl_FragDepth written too (not the headline: BASELINE's metric is the colour frame) ------
     depth_ms = None
-    if batch_params_depth is not None:
+    if want_depth:
         with_depth[0] = True
         run(args.warmup, False)
         dblocks, dtotal = [], 0.0
@@ -779,8 +837,10 @@ def job(args, env):
                                                   {0: "no ESS", 1: "block ESS", 2: "Chebyshev distance-map ESS", 3: "anisotropic Chebyshev distance-map ESS"}[skip]
                                                   + (" + ERT" if not args.no_ert else ", no ERT"),
                                                   "imin 0.1 imax 1 gmin 0 gmax 0.2" if args.tf == "app" else "imin 0.1 imax 1 gmin 0 gmax 0 (intensity only)"),
-                   "parallelism": "screen tiles 16x16 round-robin over %d GPU(s), RCCL gather to %s" % (
-                       world, ("rank l mod N for launch l (one gather per launch)" if submit == "batch" else "rank k mod N for frame k") if rotate else "rank 0")
+                   "parallelism": "16x16 screen tiles %s round-robin over %d GPU(s), RCCL gather to %s" % (
+                       "of each frame's screen rectangle (vkv_screen_tile_rect)" if use_rect else "of the whole frame", world,
+                       ("rank (l + j) mod N for frame j of launch l (one gather per frame, one RCCL group per launch)" if spread else
+                        ("rank l mod N for launch l (one gather per launch)" if submit == "batch" else "rank k mod N for frame k")) if rotate else "rank 0")
                    + ((" (vkv_assemble_frames: one ncclGather + one de-interleave per launch)" if submit == "batch" else " (vkv_assemble_frame: ncclGather + de-interleave)") if native else (" (torch.distributed.gather)" if args.backend == "nccl" else " (torch.distributed.gather over GLOO through host memory: a functional run, not a measurement)"))
                    if world > 1 else "1 GPU",
                    "output": "RGBA8",
@@ -806,6 +866,14 @@ def job(args, env):
                              "gaps between launches. single_frame is the same kernel with nothing else running. HIP events bracket every launch at "
                              "N = 1 and every 7th launch on the gather path (where launches of consecutive frames overlap)"},
     }
+    if compact:
+        # what the exchange moves per frame: every rank sends ceil(tiles of the view's screen rectangle / N) tiles of RGBA8 to the frame's owner;
+        # `whole_frame` = the same with every tile of the frame (rounds 1-5, --tile-rect off)
+        per_rank = float(np.mean([exchange_bytes_v[k % N_VIEWS] for k in range(args.steps)]))
+        out["exchange_bytes_per_frame"] = {"per_rank": int(per_rank), "all_ranks": int(per_rank * n_ranks), "whole_frame_all_ranks": int(exchange_bytes_whole * n_ranks),
+                                           "ratio": round(per_rank / exchange_bytes_whole, 4), "tile_rect": "on" if use_rect else "off",
+                                           "frame_owner": ("spread: frame j of launch l on rank (l + j) mod N" if spread else ("rotate: launch l on rank l mod N" if rotate else "rank 0")) if use_gather else None,
+                                           "tiles_of_rect_per_view": [int(r.w * r.h) for r in rects], "tiles_of_frame": int(whole_rect.w * whole_rect.h)}
     if any(phase_ms.values()):
         # HIP-event times of the launches rank 0 owned, from the render's end: gather_ms includes waiting for the slowest rank's render (torch
         # exchange: until the block has arrived; then scatter_ms = the de-interleave kernels), exchange_ms = both (native: one call)
@@ -842,7 +910,7 @@ def job(args, env):
         pass
 
     if virtual:
-        out["virtual_rank"] = {"rank": virtual[0], "of": virtual[1], "tiles": int(tiles.tile_count), "rays_per_frame": my_pixels,
+        out["virtual_rank"] = {"rank": virtual[0], "of": virtual[1], "tiles_per_view": [int(t.tile_count) for t in tiles_v], "rays_per_frame": rays_per_frame_all,
                                "note": "one GPU rendering the tile share of rank %d of %d (compact schedule, no exchange): value and ms_per_step are this share's" % virtual}
     if world == 1 and not args.no_cpu_baseline and not virtual:
         out["cpu_baseline"] = cpu_baseline(ctx, sp, v, params, (fw, fh), args.cpu_seconds, not args.no_verify_cpu, out)

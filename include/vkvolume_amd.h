@@ -139,18 +139,31 @@ typedef struct VkvRenderOptions
 	int32_t test;                  /* VKV_TEST_NONE */
 } VkvRenderOptions;
 
+/* A rectangle of screen tiles: x0, y0 = its first tile column / row, w x h tiles.  vkv_screen_tile_rect() derives the rectangle a frame's
+ * fragments can lie in from the uniforms alone, so every rank of a multi-GPU frame arrives at the same one without talking. */
+typedef struct VkvTileRect
+{
+	uint32_t x0, y0, w, h;
+} VkvTileRect;
+
 /* Screen tiling of one launch (single GPU: all tiles; multi GPU: every tile_stride-th tile).
- * The W×H image is cut into tiles of tile_width × tile_height pixels, numbered row-major.
- * The launch renders tiles tile_first + k*tile_stride, k = 0 .. tile_count-1.
+ * The W×H image is cut into tiles of tile_width × tile_height pixels.  The SCHEDULED tiles are those of `rect` (rect.w == 0 or rect.h == 0:
+ * every tile of the image), numbered row-major INSIDE the rectangle: tile t is column rect.x0 + t % rect.w, row rect.y0 + t / rect.w.
+ * The launch renders tiles tile_first + k*tile_stride, k = 0 .. tile_count-1.  Pixels outside the rectangle are not touched by the launch
+ * (vkv_scatter_tiles / vkv_assemble_frames clear them when they assemble a frame).
  * compact == 0: outputs are indexed by image pixel  (y*image_width + x);
  * compact != 0: outputs are indexed by (k*tile_height + ly)*tile_width + lx  (the per-rank
  *               buffer that is gathered over RCCL and de-interleaved by vkv_scatter_tiles); the
- *               slots of a partial tile's pixels beyond the image edge are never written. */
+ *               slots of a partial tile's pixels beyond the image edge are never written.
+ * The reference's rasteriser only shades fragments of the clipped box's faces (src/volume_render_subpass.cpp:262-293,
+ * shaders/volume_render_clipped.vert:50-65): the rectangle is this build's counterpart - tiles no fragment can lie in are neither
+ * scheduled nor exchanged. */
 typedef struct VkvTileSchedule
 {
-	uint32_t tile_width, tile_height; /* multiples of 16 (one 256-thread workgroup marches 16x16 pixels) */
-	uint32_t tile_first, tile_stride, tile_count;
-	uint32_t compact;
+	uint32_t    tile_width, tile_height; /* multiples of 16 (one 256-thread workgroup marches 16x16 pixels) */
+	uint32_t    tile_first, tile_stride, tile_count;
+	uint32_t    compact;
+	VkvTileRect rect;                    /* all zero: the whole image */
 } VkvTileSchedule;
 
 /* Everything VolumeRenderSubpass::draw binds for one volume
@@ -377,26 +390,40 @@ int vkv_release_stream(vkv_ctx *ctx, void *stream);
 int vkv_render(vkv_ctx *ctx, const VkvRenderParams *params, void *stream);
 
 /* Several frames in ONE launch: `count` (1 .. VKV_MAX_BATCH) parameter blocks that share the kernel variant (skipping type, ERT,
- * gradient mode, test mode), have a packed sampling image and the same tile-schedule size; cameras, volumes and output buffers
- * may differ (stereo pairs, orbit sweeps, the per-rank tile sets of a multi-GPU frame, the reference's frames in flight).  The
+ * gradient mode, test mode), have a packed sampling image and the same tile SIZE (the tile counts and rectangles of the schedules may
+ * differ: the frames of a multi-GPU launch each have their own screen rectangle); cameras, volumes and output buffers may differ (stereo pairs, orbit sweeps, the per-rank tile sets of a multi-GPU frame, the reference's frames in flight).  The
  * frames advance side by side inside one grid, so the long tail of each is covered by the bulk of the others without relying on
  * several hardware queues.  Output buffers of different frames must not overlap.  Results are bit-identical to `count` vkv_render calls. */
 #define VKV_MAX_BATCH 32
 int vkv_render_batch(vkv_ctx *ctx, const VkvRenderParams *params, uint32_t count, void *stream);
 
-/* Root-rank de-interleave of gathered compact tile buffers into the W×H image (multi-GPU):
- * d_gathered holds n_ranks buffers of tiles_per_rank tiles each, bytes_per_pixel per pixel.  tiles_per_rank is only the distance
- * (in tiles) between the buffers of consecutive ranks: when the frames of a whole vkv_render_batch launch were gathered in one
- * collective as [rank][frame][tiles], frame f is read with d_gathered + f * (one rank's bytes of a frame) and
- * tiles_per_rank = frames * (tiles of a rank per frame). */
+/* The tile rectangle the fragments of a frame can lie in (pure CPU, double precision from the float uniforms: the same inputs give the
+ * same rectangle on every rank).  The volume's box [0,1]^3 (texture space) is cut by the clipping plane (plane_tex: the kept side is
+ * dot(plane_tex.xyz, p) + plane_tex.w >= 0, the side the integrator starts its rays on, frag:117 / volume_render_clipped.vert:56), the
+ * vertices of the clipped box are solved through the ray generator (p - camera_pos_tex = g (dir00 + fx ddx + fy ddy)), and the pixel
+ * bound of the (fx, fy), widened by two pixels, is rounded outwards to whole tiles and then to multiples of `align_tiles` tiles
+ * (0 or 1: no alignment; a renderer whose camera moves aligns to e.g. 4 tiles so that the rectangle - and with it the cached start
+ * order and the feedback state of a target - changes less often).  A pixel outside the rectangle cannot have a fragment, whatever
+ * the depth test does afterwards.  The rectangle is never empty: a box that is off screen gives the 1 x 1 rectangle of tile (0, 0)
+ * (a fixed, minimal exchange); a vertex at or behind the camera plane, or a degenerate generator, gives the whole image. */
+int vkv_screen_tile_rect(const VkvRayCastUniform *ray_cast, const VkvRayGen *ray_gen, uint32_t image_width, uint32_t image_height,
+                         uint32_t tile_width, uint32_t tile_height, uint32_t align_tiles, VkvTileRect *out_rect);
+
+/* Root-rank de-interleave of gathered compact tile buffers into the W×H image (multi-GPU): the tiles of `rect` (NULL or w == 0: every
+ * tile of the image; numbered row-major inside it as in VkvTileSchedule) were dealt round-robin to n_ranks ranks, tile t to rank
+ * t % n_ranks as its (t / n_ranks)-th.  d_gathered holds the n_ranks compact buffers, `rank_stride_tiles` tiles apart (>= the
+ * ceil(tiles / n_ranks) tiles a rank holds: when the frames of a launch travel as one block per rank the stride is the block's tile
+ * count and the caller offsets d_gathered to the frame), bytes_per_pixel per pixel.  Pixels outside the rectangle are CLEARED to zero:
+ * the image is complete after the call. */
 int vkv_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, uint32_t image_width,
-                      uint32_t image_height, uint32_t tile_width, uint32_t tile_height,
-                      uint32_t n_ranks, uint32_t tiles_per_rank, uint32_t bytes_per_pixel, void *stream);
+                      uint32_t image_height, uint32_t tile_width, uint32_t tile_height, const VkvTileRect *rect,
+                      uint32_t n_ranks, uint32_t rank_stride_tiles, uint32_t bytes_per_pixel, void *stream);
 
 /* ---- multi-GPU exchange step --------------------------------------------------------------------------------
  * Rays are independent: a frame is cut into screen tiles dealt round-robin to the ranks (VkvTileSchedule: tile_first = rank,
- * tile_stride = n_ranks, compact = 1), the volume is replicated, and the ONLY exchange is the gather of every rank's compact tile
- * buffer to the frame's owner, followed by vkv_scatter_tiles there.  One process (or host thread) per GPU, one ncclComm_t each.
+ * tile_stride = n_ranks, compact = 1, rect = vkv_screen_tile_rect of the frame's uniforms), the volume is replicated, and the ONLY
+ * exchange is the gather of every rank's compact tile buffer to the frame's owner, followed by vkv_scatter_tiles there.  One process (or
+ * host thread) per GPU, one ncclComm_t each.
  *
  * vkv_gather_tiles enqueues that gather on `stream` with RCCL's ncclGather (rccl.h:745; 7 concurrent point-to-point transfers into
  * the root over xGMI): every rank sends bytes_per_rank bytes from d_tiles, the root receives n_ranks * bytes_per_rank bytes into
@@ -405,21 +432,29 @@ int vkv_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, uint3
  * VKV_RCCL_LIBRARY=<path> overrides.  Returns VKV_E_UNSUPPORTED when no RCCL can be loaded, 1000 + ncclResult_t on RCCL errors. */
 int vkv_gather_tiles(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, size_t bytes_per_rank, int32_t root, void *nccl_comm, void *stream);
 
-/* The whole exchange of one frame on `stream`: vkv_gather_tiles to `root`, then (on the root only) vkv_scatter_tiles of the gathered
- * buffers into d_image.  d_gathered is scratch of n_ranks * tiles_per_rank * tile_width * tile_height * bytes_per_pixel bytes on the
- * root; d_image / d_gathered may be NULL on the other ranks. */
+/* The whole exchange of one frame on `stream`: vkv_gather_tiles of this rank's ceil(tiles of rect / n_ranks) compact tiles to `root`, then
+ * (on the root only) vkv_scatter_tiles of the gathered buffers into d_image.  d_gathered is scratch of n_ranks * ceil(tiles / n_ranks) *
+ * tile_width * tile_height * bytes_per_pixel bytes on the root; d_image / d_gathered may be NULL on the other ranks. */
 int vkv_assemble_frame(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, void *d_image, uint32_t image_width, uint32_t image_height,
-                       uint32_t tile_width, uint32_t tile_height, uint32_t n_ranks, uint32_t rank, uint32_t tiles_per_rank,
+                       uint32_t tile_width, uint32_t tile_height, const VkvTileRect *rect, uint32_t n_ranks, uint32_t rank,
                        uint32_t bytes_per_pixel, int32_t root, void *nccl_comm, void *stream);
 
-/* The exchange of a whole vkv_render_batch launch in ONE collective (what a C or C++ renderer binds for frames in flight; the Python
- * bench does the same through torch.distributed): d_tiles holds this rank's compact tile buffers of `frames` frames back to back,
- * [frame][tiles_per_rank tiles]; one ncclGather brings them to `root` as [rank][frame][tiles] in d_gathered (scratch of
- * n_ranks * frames * tiles_per_rank tiles on the root), and ONE de-interleave kernel there writes frame f into d_images[f] (host array
- * of `frames` device pointers, 1 .. VKV_MAX_BATCH; copied at call time).  d_gathered / d_images may be NULL on the other ranks. */
+/* The exchange of a whole vkv_render_batch launch (what a C or C++ renderer binds for frames in flight).  Frame f has its own tile
+ * rectangle rects[f] (NULL: every frame the whole image) and its own owner roots[f] (NULL: every frame `root`): with the owners of a
+ * launch's frames spread over the ranks every GPU receives at once, over all of its inbound xGMI links, instead of one GPU receiving
+ * everything.  tpr(f) = ceil(tiles of rects[f] / n_ranks) is what a rank renders of frame f (its VkvTileSchedule.tile_count, except on
+ * the last ranks of a ragged deal, whose missing tile's slot travels unused).
+ *   d_tiles     this rank's compact tiles of the launch, frames back to back: [frame f][tpr(f) tiles];
+ *   d_gathered  scratch of n_ranks * sum_f tpr(f) tiles on every rank that owns a frame (its layout is the call's own business: [rank][frame]
+ *               [tiles] after the one gather, [frame][rank][tiles] after the group);
+ *   d_images    host array of `frames` device pointers (copied at call time); entry f is only read on the owner of frame f.
+ * roots == NULL: ONE ncclGather of the launch's whole block to `root`.  roots != NULL: one ncclGather per frame, all inside ONE group
+ * (ncclGroupStart / ncclGroupEnd: RCCL fuses the group's point-to-point transfers into one kernel).  Then, on every rank that owns a frame,
+ * ONE de-interleave kernel for the frames it owns (pixels outside a frame's rectangle are cleared).
+ * Every rank must pass the same frames, rects, roots. */
 int vkv_assemble_frames(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, void *const *d_images, uint32_t frames, uint32_t image_width,
-                        uint32_t image_height, uint32_t tile_width, uint32_t tile_height, uint32_t n_ranks, uint32_t rank, uint32_t tiles_per_rank,
-                        uint32_t bytes_per_pixel, int32_t root, void *nccl_comm, void *stream);
+                        uint32_t image_height, uint32_t tile_width, uint32_t tile_height, const VkvTileRect *rects, uint32_t n_ranks, uint32_t rank,
+                        uint32_t bytes_per_pixel, int32_t root, const int32_t *roots, void *nccl_comm, void *stream);
 
 /* Deterministic synthetic uint8 volume, generated on the device. kind 0 = soft
  * sphere (config C1), kind 1 = ellipsoid shells + hash noise (configs C2..C5). */

@@ -808,7 +808,10 @@ static void render_items(RenderJob *job)
 {
 	const VkvRenderParams *P   = job->P;
 	const uint32_t         tw = P->tiles.tile_width, th = P->tiles.tile_height;
-	const uint32_t         tiles_x = (P->image_width + tw - 1) / tw;
+	/* the schedule's tile rectangle (VkvTileSchedule.rect; all zero = the whole image): tiles are numbered row-major inside it */
+	const int              whole   = P->tiles.rect.w == 0 || P->tiles.rect.h == 0;
+	const uint32_t         tiles_x = whole ? (P->image_width + tw - 1) / tw : P->tiles.rect.w;
+	const uint32_t         org_x = whole ? 0u : P->tiles.rect.x0 * tw, org_y = whole ? 0u : P->tiles.rect.y0 * th;
 	const uint32_t         chunks  = (th + CHUNK_ROWS - 1) / CHUNK_ROWS;
 	const uint32_t         stride  = job->stride;
 	const float *          lut     = job->lut;
@@ -829,7 +832,7 @@ static void render_items(RenderJob *job)
 		}
 		const uint32_t k  = (uint32_t) (item / chunks), row0 = (uint32_t) (item % chunks) * CHUNK_ROWS;
 		const uint32_t t  = P->tiles.tile_first + k * P->tiles.tile_stride;
-		const uint32_t x0 = (t % tiles_x) * tw, y0 = (t / tiles_x) * th;
+		const uint32_t x0 = org_x + (t % tiles_x) * tw, y0 = org_y + (t / tiles_x) * th;
 		for (uint32_t ly = row0; ly < th && ly < row0 + CHUNK_ROWS; ++ly)
 		{
 			const uint32_t y = y0 + ly;

@@ -31,9 +31,9 @@ def test_bench_two_ranks_share_one_device_over_gloo():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
-    for steps, fpl in ((12, 8), (7, 3)):
+    for steps, fpl, more in ((12, 8, []), (7, 3, []), (11, 4, ["--frame-owner", "spread"]), (6, 6, ["--tile-rect", "off"])):
         cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device", "--workload", "small", "--steps", str(steps),
-               "--warmup", "3", "--frames-per-launch", str(fpl), "--min-seconds", "0.2", "--verify", "--c5-block", "off", "--no-cpu-baseline", "--launch-timeout", "600"]
+               "--warmup", "3", "--frames-per-launch", str(fpl), "--min-seconds", "0.2", "--verify", "--c5-block", "off", "--no-cpu-baseline", "--launch-timeout", "600"] + more
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -45,6 +45,13 @@ def test_bench_two_ranks_share_one_device_over_gloo():
         assert d["value"] > 0 and d["roofline"]["frac"] > 0
         assert "verify ok" in r.stderr, r.stderr[-2000:]
         assert "native_exchange" not in d  # --native-block auto: only with the nccl backend
+        # round 6: only the tiles of each frame's screen rectangle travel (the small workload's box fills about half of the frame)
+        x = d["exchange_bytes_per_frame"]
+        if "--tile-rect" in more:
+            assert x["ratio"] == 1.0 and x["tile_rect"] == "off"
+        else:
+            assert 0.2 < x["ratio"] < 0.9 and x["tile_rect"] == "on" and max(x["tiles_of_rect_per_view"]) < x["tiles_of_frame"], x
+        assert ("spread" in x["frame_owner"]) == ("spread" in more)
     # the C ABI's exchange asked for where RCCL cannot provide it (two ranks on one device): the block degrades to an "error" string in its
     # sub-object, the headline line is still printed, once, and the job ends with status 0
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device", "--workload", "small", "--steps", "8",
@@ -78,3 +85,8 @@ def test_bench_one_rank_group_carries_both_exchanges():
     assert "error" not in ne, ne
     assert ne["ms_per_step"] > 0 and ne["rccl_ranks"] == 1 and "ncclCommCount" in ne["rccl_ranks_source"] and "exchange_ms" in ne["phases"] and ne["phases"]["render_ms"] > 0
     assert "gather_ms" in d["phases"] and d["rccl_ranks"] == 1
+    # the same launches with the owners spread inside a launch (one RCCL group of per-frame gathers: with one rank every owner is rank 0)
+    ns = d["native_exchange_spread"]
+    assert "error" not in ns, ns
+    assert ns["ms_per_step"] > 0 and "exchange_ms" in ns["phases"] and "spread" in ns["exchange_bytes_per_frame"]["frame_owner"]
+    assert d["exchange_bytes_per_frame"]["ratio"] < 0.9 and ne["exchange_bytes_per_frame"]["per_rank"] == d["exchange_bytes_per_frame"]["per_rank"]

@@ -40,7 +40,7 @@ def test_c5_frame_as_eight_virtual_ranks(ctx):
     8 ranks, RCCL gather.  One GPU plays the eight ranks in turn (rays are independent: what rank r renders does not depend on who else
     renders): rank r renders VkvTileSchedule{16, 16, tile_first = r, tile_stride = 8, compact = 1} of two views with one vkv_render_batch
     launch into its compact buffers; the eight buffers are laid out [rank][tiles] as ncclGather delivers them - and are also sent through
-    ncclGather itself (a one-rank communicator, 531 MB) - and de-interleaved by vkv_scatter_tiles(n_ranks = 8).
+    ncclGather itself (a one-rank communicator, the whole block of a view) - and de-interleaved by vkv_scatter_tiles(n_ranks = 8).
       (a) the assembled RGBA8 frame == a direct full-frame render, byte for byte (both views);
       (b) every 32nd pixel in x and y == the CPU oracle: three counters + RGBA8, bit-exact;
       (c) the eight ranks' event totals (volume samples + distance probes) are within +-15 % of each other (the load-balance claim
@@ -63,27 +63,33 @@ def test_c5_frame_as_eight_virtual_ranks(ctx):
     views = [orbit(v, az, size) for az in (45.0, 200.0)]
     total_tiles = (fw // tile) * (fh // tile)
     assert total_tiles == 129600 and total_tiles % world == 0
-    per_rank = total_tiles // world
-    n = per_rank * tile * tile
-    gathered = [torch.zeros((world, n, 4), dtype=torch.uint8, device="cuda") for _ in views]        # [rank][tiles] per view
-    counts_r = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+    # round 6: only the tiles of each view's screen rectangle (vkv_screen_tile_rect: derived from the uniforms alone, the same on every rank)
+    # are scheduled and exchanged; the two views of a rank's launch have different tile counts
+    full = [sp.make_params(view, proj) for view, proj in views]
+    rects = [lib.screen_tile_rect(p.ray_cast, p.ray_gen, size, (tile, tile)) for p in full]
+    per_rank = [multigpu.tiles_per_rank(r, world) for r in rects]
+    for r_, n_ in zip(rects, per_rank):
+        assert n_ * world <= 0.70 * total_tiles, "rectangle %s: the exchange moves %d of %d tiles" % (r_.as_tuple(), n_ * world, total_tiles)
+    n = [t * tile * tile for t in per_rank]
+    gathered = [torch.zeros((world, n[k], 4), dtype=torch.uint8, device="cuda") for k in range(len(views))]        # [rank][tiles] per view
+    counts_r = torch.zeros((max(n), 3), dtype=torch.int32, device="cuda")
     events = np.zeros((len(views), world), np.int64)
     for r in range(world):
-        sched = abi.full_frame_tiles(fw, fh, tile, tile, r, world, compact=True)
-        assert sched.tile_count == per_rank
+        scheds = [abi.full_frame_tiles(fw, fh, tile, tile, r, world, compact=True, rect=rect) for rect in rects]
         plist = []
         for k, (view, proj) in enumerate(views):
-            p = sp.make_params(view, proj, sched)
+            assert per_rank[k] - 1 <= scheds[k].tile_count <= per_rank[k]
+            p = sp.make_params(view, proj, scheds[k])
             p.d_out_rgba8, p.d_out_color, p.d_out_counts, p.d_out_depth = gathered[k][r].data_ptr(), None, None, None
             plist.append(p)
         ctx.render_batch(plist, st)        # ONE launch per rank: its tiles of both views
         for k, (view, proj) in enumerate(views):        # the rank's counters (a second, single-frame launch of the same tiles)
-            p = sp.make_params(view, proj, sched)
-            check = torch.zeros((n, 4), dtype=torch.uint8, device="cuda")
+            p = sp.make_params(view, proj, scheds[k])
+            check = torch.zeros((n[k], 4), dtype=torch.uint8, device="cuda")
             sp.draw(p, rgba8=check, counts=counts_r)
             torch.cuda.synchronize()
             assert torch.equal(check, gathered[k][r]), "rank %d, view %d: vkv_render and vkv_render_batch disagree" % (r, k)
-            events[k, r] = int(counts_r[:, :2].to(torch.int64).sum().item())
+            events[k, r] = int(counts_r[:scheds[k].tile_count * tile * tile, :2].to(torch.int64).sum().item())
     torch.cuda.synchronize()
     # (c) load balance of round-robin 16x16 tiles
     for k in range(len(views)):
@@ -93,13 +99,13 @@ def test_c5_frame_as_eight_virtual_ranks(ctx):
     rccl, comm = one_rank_communicator()
     try:
         for k, (view, proj) in enumerate(views):
-            p_full = sp.make_params(view, proj)
+            p_full = full[k]
             direct = torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda")
             counts = torch.zeros((fh, fw, 3), dtype=torch.int32, device="cuda")
             sp.draw(p_full, rgba8=direct, counts=counts)
             # (a) de-interleave of the [rank][tiles] block
             image = torch.full((fh, fw, 4), 3, dtype=torch.uint8, device="cuda")
-            ctx.scatter_tiles(gathered[k].data_ptr(), image.data_ptr(), size, (tile, tile), world, per_rank, 4, st)
+            ctx.scatter_tiles(gathered[k].data_ptr(), image.data_ptr(), size, (tile, tile), world, per_rank[k], 4, st, rect=rects[k])
             torch.cuda.synchronize()
             assert int(direct.to(torch.int64).sum().item()) > 0
             assert torch.equal(image, direct), "view %d: the frame assembled from 8 ranks' tiles differs from the direct render" % k
@@ -107,7 +113,7 @@ def test_c5_frame_as_eight_virtual_ranks(ctx):
             recv = torch.zeros_like(gathered[k])
             image.fill_(5)
             ctx.gather_tiles(gathered[k].data_ptr(), recv.data_ptr(), gathered[k].numel(), 0, comm.value, st)
-            ctx.scatter_tiles(recv.data_ptr(), image.data_ptr(), size, (tile, tile), world, per_rank, 4, st)
+            ctx.scatter_tiles(recv.data_ptr(), image.data_ptr(), size, (tile, tile), world, per_rank[k], 4, st, rect=rects[k])
             torch.cuda.synchronize()
             assert torch.equal(image, direct), "view %d: ncclGather + vkv_scatter_tiles differs from the direct render" % k
             if k == 0:

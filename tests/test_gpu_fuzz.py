@@ -43,37 +43,45 @@ def test_tile_schedule_fuzz(ctx, seed):
     world, frames = int(rng.integers(1, 10)), int(rng.integers(1, 5))
     ro = abi.RenderOptions(skipping_type=st_mode, clip_distance=1.0, early_ray_termination=bool(rng.integers(0, 2)))
     views = [T.orbit(float(rng.uniform(0, 360)), elevation=float(rng.uniform(-60, 60)), image_size=size) for _ in range(frames)]
-    tiles_x, tiles_y = -(-size[0] // tw), -(-size[1] // th)
-    per_rank = -(-(tiles_x * tiles_y) // world)
-    n = per_rank * tw * th
+    # odd seeds: every frame through the schedule of its own screen rectangle (vkv_screen_tile_rect, aligned to 1, 2 or 4 tiles) - the frames of a
+    # launch then have different tile counts and lie back to back in a rank's block; even seeds: every tile of the image
+    full = [scene.params(view, proj, size, ro, tiles=abi.full_frame_tiles(size[0], size[1], tw, th)) for view, proj in views]
+    if seed % 2:
+        rects = [lib.screen_tile_rect(p.ray_cast, p.ray_gen, size, (tw, th), int(rng.choice([1, 1, 2, 4]))) for p in full]
+    else:
+        rects = [abi.whole_image_rect(size[0], size[1], tw, th)] * frames
+    tpr, off, total = multigpu.launch_layout(rects, world)
+    tp = tw * th
     st = torch.cuda.current_stream().cuda_stream
-    gathered = torch.full((world, frames, n, 4), 0x5A, dtype=torch.uint8, device="cuda")        # as the launch's owner receives it
-    what = "seed %d: frame %s tiles %dx%d world %d frames %d mode %d" % (seed, size, tw, th, world, frames, st_mode)
+    gathered = torch.full((world, total * tp, 4), 0x5A, dtype=torch.uint8, device="cuda")        # as the launch's owner receives it: [rank][frame][tiles]
+    what = "seed %d: frame %s tiles %dx%d world %d frames %d mode %d rects %s" % (seed, size, tw, th, world, frames, st_mode, [r.as_tuple() for r in rects])
     for r in range(world):
-        sched = abi.full_frame_tiles(size[0], size[1], tw, th, r, world, compact=True)
-        if sched.tile_count == 0:
+        scheds = [abi.full_frame_tiles(size[0], size[1], tw, th, r, world, compact=True, rect=rect) for rect in rects]
+        if max(s.tile_count for s in scheds) == 0:
             continue        # more ranks than tiles: this one has nothing to render (bench.py's ranks pass such schedules too)
         plist, counts = [], []
         for f, (view, proj) in enumerate(views):
-            p = T_bind(ctx, v, scene, view, proj, size, ro, sched)
-            c = torch.zeros((sched.tile_count * tw * th, 3), dtype=torch.int32, device="cuda")  # (slots beyond the image edge stay unwritten)
-            p.d_out_rgba8, p.d_out_color, p.d_out_counts, p.d_out_depth = gathered[r, f].data_ptr(), None, c.data_ptr(), None
+            p = T_bind(ctx, v, scene, view, proj, size, ro, scheds[f])
+            c = torch.zeros((max(1, scheds[f].tile_count) * tp, 3), dtype=torch.int32, device="cuda")  # (slots beyond the image edge stay unwritten)
+            p.d_out_rgba8, p.d_out_color, p.d_out_counts, p.d_out_depth = gathered[r].data_ptr() + off[f] * tp * 4, None, c.data_ptr(), None
             plist.append(p)
             counts.append(c)
         if frames == 1:
             ctx.render(plist[0], st)
         else:
-            ctx.render_batch(plist, st)
+            ctx.render_batch(plist, st)        # (frames without a tile for this rank ride along)
         torch.cuda.synchronize()
         for f, (view, proj) in enumerate(views):
-            ref = scene.render(scene.params(view, proj, size, ro, tiles=sched))
+            if scheds[f].tile_count == 0:
+                continue
+            ref = scene.render(scene.params(view, proj, size, ro, tiles=scheds[f]))
             assert np.array_equal(counts[f].cpu().numpy().astype(np.uint32).reshape(ref.counts.shape), ref.counts), what + ", rank %d frame %d counters" % (r, f)
     for f, (view, proj) in enumerate(views):
         image = torch.full((size[1], size[0], 4), 3, dtype=torch.uint8, device="cuda")
-        ctx.scatter_tiles(gathered.data_ptr() + f * n * 4, image.data_ptr(), size, (tw, th), world, frames * per_rank, 4, st)
+        ctx.scatter_tiles(gathered.data_ptr() + off[f] * tp * 4, image.data_ptr(), size, (tw, th), world, total, 4, st, rect=rects[f])
         torch.cuda.synchronize()
-        full = scene.render(scene.params(view, proj, size, ro, tiles=abi.full_frame_tiles(size[0], size[1], tw, th)), want_rgba8=True)
-        assert np.array_equal(image.cpu().numpy(), full.rgba8), what + ", assembled frame %d" % f
+        ref_full = scene.render(full[f], want_rgba8=True)
+        assert np.array_equal(image.cpu().numpy(), ref_full.rgba8), what + ", assembled frame %d" % f
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "24"))))

@@ -500,6 +500,38 @@ def test_render_compact_tiles_and_rgba8(ctx, shell_scene):
     d_g, d_img = dev(gathered), torch.zeros((size[1], size[0], 4), dtype=torch.uint8, device="cuda")
     ctx.scatter_tiles(d_g.data_ptr(), d_img.data_ptr(), size, (32, 16), world, tiles_per_rank, 4, torch.cuda.current_stream().cuda_stream)
     assert np.array_equal(d_img.cpu().numpy(), ref_full.rgba8)
+    # round 6: the same frame through the schedule of its screen rectangle (vkv_screen_tile_rect): fewer tiles per rank, the same image - on the
+    # device (non-compact: pixels outside the rectangle are not touched) and against the oracle's rendering of the same schedule
+    rect = lib.screen_tile_rect(full.ray_cast, full.ray_gen, size, (32, 16))
+    assert 0 < rect.tiles < 5 * 5
+    tpr = -(-rect.tiles // world)
+    gathered = np.zeros((world, tpr * 32 * 16, 4), np.uint8)
+    whole = np.full((size[1], size[0], 4), 7, np.uint8)
+    for rank in range(world):
+        tiles = abi.full_frame_tiles(size[0], size[1], 32, 16, rank, world, compact=True, rect=rect)
+        params = scene.params(view, proj, size, opts, tiles=tiles)
+        ref = scene.render(params, want_rgba8=True)
+        color, counts, depth, rgba8 = gpu_render(ctx, v, params, want_rgba8=True)
+        assert np.array_equal(counts, ref.counts)
+        inside = ref.counts[..., 0] + ref.counts[..., 1] > 0
+        assert np.array_equal(rgba8[inside], ref.rgba8[inside])
+        gathered[rank, :rgba8.shape[0]] = rgba8
+    d_g = dev(gathered)
+    d_img.fill_(9)
+    ctx.scatter_tiles(d_g.data_ptr(), d_img.data_ptr(), size, (32, 16), world, tpr, 4, torch.cuda.current_stream().cuda_stream, rect=rect)
+    assert np.array_equal(d_img.cpu().numpy(), ref_full.rgba8)
+    # one rank, image-indexed outputs: the launch writes the rectangle's pixels only
+    params = scene.params(view, proj, size, opts, tiles=abi.full_frame_tiles(size[0], size[1], 32, 16, rect=rect))
+    d_out = dev(whole)
+    sp = V.VolumeRenderSubpass(ctx, v, opts, size)
+    sp.draw(sp.bind(params), rgba8=d_out)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    ys, xs = slice(rect.y0 * 16, min(size[1], (rect.y0 + rect.h) * 16)), slice(rect.x0 * 32, min(size[0], (rect.x0 + rect.w) * 32))
+    assert np.array_equal(got[ys, xs], ref_full.rgba8[ys, xs])
+    mask = np.ones(size[::-1], bool)
+    mask[ys, xs] = False
+    assert (got[mask] == 7).all() and not ref_full.rgba8[mask].any()
 
 
 def test_render_error_paths(ctx, shell_scene):

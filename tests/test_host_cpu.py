@@ -48,7 +48,7 @@ def test_ctypes_mirror_matches_c_layout(tmp_path):
     out = subprocess.check_output([str(exe)]).decode().split("\n")
     mirror = {"VkvExtent3D": abi.Extent3D, "VkvTransferFunctionUniform": abi.TransferFunctionUniform, "VkvVolumeOptions": abi.VolumeOptions,
               "VkvCameraUniform": abi.CameraUniform, "VkvRayCastUniform": abi.RayCastUniform, "VkvRayGen": abi.RayGen,
-              "VkvRenderOptions": abi.RenderOptions, "VkvTileSchedule": abi.TileSchedule, "VkvRenderParams": abi.RenderParams,
+              "VkvRenderOptions": abi.RenderOptions, "VkvTileRect": abi.TileRect, "VkvTileSchedule": abi.TileSchedule, "VkvRenderParams": abi.RenderParams,
               "VkvTuning": abi.Tuning}
     n = 0
     for line in out:
@@ -146,6 +146,22 @@ def test_tile_schedules_partition_the_frame(frame, tile, world):
         assert g.schedule.tile_count == s.tile_count and s.tile_count <= g.tiles_per_rank
         rays += g.my_ray_count()
     assert (seen == 1).all() and rays == frame[0] * frame[1]
+    # round 6: the same deal inside a tile rectangle (tiles numbered row-major inside it)
+    rect = abi.TileRect(tiles_x // 3, tiles_y // 4, max(1, tiles_x // 2), max(1, tiles_y // 2))
+    seen = np.zeros((tiles_y, tiles_x), int)
+    rays = 0
+    for r in range(world):
+        g = multigpu.TileGather(None, r, world, frame, tile, 4, device="cpu")
+        s = g.rect_schedule(rect)
+        assert s.tile_count <= multigpu.tiles_per_rank(rect, world) <= g.tiles_per_rank and s.rect.as_tuple() == rect.as_tuple()
+        for k in range(s.tile_count):
+            t = s.tile_first + k * s.tile_stride
+            seen[rect.y0 + t // rect.w, rect.x0 + t % rect.w] += 1
+        rays += g.my_ray_count(rect)
+    inside = np.zeros_like(seen, bool)
+    inside[rect.y0:rect.y0 + rect.h, rect.x0:rect.x0 + rect.w] = True
+    assert (seen[inside] == 1).all() and not seen[~inside].any()
+    assert rays == (min(frame[0], (rect.x0 + rect.w) * tile) - rect.x0 * tile) * (min(frame[1], (rect.y0 + rect.h) * tile) - rect.y0 * tile)
 
 
 def test_product_fails_loudly_without_library(monkeypatch):
@@ -248,3 +264,42 @@ def test_bench_spreads_the_frames_of_a_block_evenly_over_its_launches():
         for fpl in (1, 3, 8, 12, 32):
             parts = bench.split_frames(steps, fpl)
             assert sum(parts) == steps and max(parts) <= fpl and max(parts) - min(parts) <= 1 and len(parts) == -(-steps // fpl)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "40"))))
+def test_screen_tile_rect_holds_every_fragment(seed):
+    """vkv_screen_tile_rect (the counterpart of the reference's rasteriser only shading the clipped box's faces, src/volume_render_subpass.cpp:262-293):
+    a frame rendered through the rectangle's schedule into cleared buffers equals the full-frame render - no pixel outside the rectangle has a
+    fragment - for cameras outside, at, inside and beside the box, clip planes in front of, through and behind it, rotated anisotropic volumes;
+    and the rectangle is TIGHT where the box is well in front of the camera (within the 2-pixel margin and the tile rounding of the pixels
+    that do have a fragment)."""
+    rng = np.random.default_rng(7700 + seed)
+    shape = tuple(int(x) for x in rng.integers(8, 30, size=3))
+    vol = O.synth_volume(shape, 1, int(rng.integers(1, 1 << 30)))
+    voxel = tuple(float(x) for x in rng.uniform(0.3, 2.0, size=3))
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    scene = T.OracleScene(vol, abi.VolumeOptions(**T.APP_TF), 4, voxel_size=voxel, axis_angle=(float(axis[0]), float(axis[1]), float(axis[2]), float(rng.uniform(0, 360))))
+    size = (int(rng.integers(3, 12)) * 16 - int(rng.integers(0, 16)), int(rng.integers(2, 8)) * 16 - int(rng.integers(0, 16)))
+    radius = float(rng.choice([30.0, 60.0, 110.0, 150.0, 260.0, 500.0]))  # the node is scaled to 100 units: 30 / 60 put the camera inside or at the box
+    centre = (0.0, 0.0, 0.0) if seed % 3 else tuple(float(x) for x in rng.uniform(-90.0, 90.0, size=3))  # every third seed: the box off-centre / off screen
+    view = camera.orbit_camera(float(rng.uniform(0, 360)), float(rng.uniform(-80, 80)), radius, centre)
+    proj = camera.perspective_vulkan(float(rng.uniform(25, 100)), size[0] / size[1])
+    clip = float(rng.choice([0.1, 1.0, 1.0, 20.0, 70.0, 120.0, 200.0]))
+    opts = abi.RenderOptions(skipping_type=abi.SKIP_NONE, clip_distance=clip, test=abi.TEST_RAY_ENTRY)  # the ray entry of every fragment: no marching needed
+    params = scene.params(view, proj, size, opts)
+    align = int(rng.choice([1, 1, 2, 4]))
+    rect = lib.screen_tile_rect(params.ray_cast, params.ray_gen, size, (16, 16), align)
+    tiles_x, tiles_y = -(-size[0] // 16), -(-size[1] // 16)
+    assert rect.w >= 1 and rect.h >= 1 and rect.x0 + rect.w <= tiles_x and rect.y0 + rect.h <= tiles_y
+    full = scene.render(params)
+    covered = full.color[..., 3] != 0  # TEST_RAY_ENTRY writes alpha 1 for every fragment
+    p2 = scene.params(view, proj, size, opts, tiles=abi.full_frame_tiles(size[0], size[1], rect=rect))
+    part = scene.render(p2)
+    assert np.array_equal(part.color, full.color), "a fragment lies outside the rectangle %s (image %s tiles)" % (rect.as_tuple(), (tiles_x, tiles_y))
+    ys, xs = np.nonzero(covered)
+    if len(xs) and radius >= 150.0 and align == 1 and clip <= 20.0 and seed % 3:  # (an off-centre orbit can put the camera next to the box)
+        # tight: the rectangle's pixel bound is within 2 pixels (the margin) + 1 (sampling at pixel centres) + a tile of the covered pixels' bound
+        assert rect.x0 * 16 >= xs.min() - 19 and rect.y0 * 16 >= ys.min() - 19, (rect.as_tuple(), xs.min(), ys.min())
+        assert (rect.x0 + rect.w) * 16 <= xs.max() + 1 + 19 and (rect.y0 + rect.h) * 16 <= ys.max() + 1 + 19, (rect.as_tuple(), xs.max(), ys.max())
+    print("seed %d: image %dx%d tiles, rect %s, %d covered pixels, radius %g clip %g" % (seed, tiles_x, tiles_y, rect.as_tuple(), len(xs), radius, clip))

@@ -82,10 +82,22 @@ class RenderOptions(C.Structure):
                          1 if depth_attachment else 0, test)
 
 
+class TileRect(C.Structure):
+    """VkvTileRect: x0, y0 = first tile column / row, w x h tiles (all zero: the whole image)"""
+    _fields_ = [("x0", C.c_uint32), ("y0", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32)]
+
+    def as_tuple(self):
+        return (self.x0, self.y0, self.w, self.h)
+
+    @property
+    def tiles(self):
+        return self.w * self.h
+
+
 class TileSchedule(C.Structure):
     """VkvTileSchedule"""
     _fields_ = [("tile_width", C.c_uint32), ("tile_height", C.c_uint32), ("tile_first", C.c_uint32),
-                ("tile_stride", C.c_uint32), ("tile_count", C.c_uint32), ("compact", C.c_uint32)]
+                ("tile_stride", C.c_uint32), ("tile_count", C.c_uint32), ("compact", C.c_uint32), ("rect", TileRect)]
 
 
 class RenderParams(C.Structure):
@@ -116,10 +128,18 @@ class VolumeHeader(C.Structure):
                 ("type", C.c_char * 16), ("endianness", C.c_char * 16), ("image_transform", C.c_float * 16)]
 
 
-def full_frame_tiles(image_width, image_height, tile_width=16, tile_height=16, rank=0, world=1, compact=False):
-    """Tile schedule of one rank: every ``world``-th tile starting at ``rank`` (interleaved screen tiles)."""
-    tiles_x = (image_width + tile_width - 1) // tile_width
-    tiles_y = (image_height + tile_height - 1) // tile_height
-    total = tiles_x * tiles_y
+def full_frame_tiles(image_width, image_height, tile_width=16, tile_height=16, rank=0, world=1, compact=False, rect=None):
+    """Tile schedule of one rank: every ``world``-th tile starting at ``rank`` (interleaved screen tiles) of the whole image or, with
+    ``rect`` (a TileRect, e.g. from lib.screen_tile_rect), of that tile rectangle."""
+    if rect is not None and rect.w and rect.h:
+        total, r = rect.w * rect.h, TileRect(rect.x0, rect.y0, rect.w, rect.h)
+    else:
+        tiles_x = (image_width + tile_width - 1) // tile_width
+        tiles_y = (image_height + tile_height - 1) // tile_height
+        total, r = tiles_x * tiles_y, TileRect(0, 0, 0, 0)
     count = (total - rank + world - 1) // world if total > rank else 0
-    return TileSchedule(tile_width, tile_height, rank, world, count, 1 if compact else 0)
+    return TileSchedule(tile_width, tile_height, rank, world, count, 1 if compact else 0, r)
+
+
+def whole_image_rect(image_width, image_height, tile_width=16, tile_height=16):
+    return TileRect(0, 0, (image_width + tile_width - 1) // tile_width, (image_height + tile_height - 1) // tile_height)

@@ -27,8 +27,9 @@ int launch_occupancy_map(vkv_ctx *, const uint8_t *, const uint8_t *, const uint
 int launch_distance_map(vkv_ctx *, uint8_t *, uint8_t *, VkvExtent3D, hipStream_t);
 int launch_distance_map_anisotropic(vkv_ctx *, uint8_t *const[8], uint8_t *, VkvExtent3D, hipStream_t);
 int launch_synth_volume(vkv_ctx *, uint8_t *, VkvExtent3D, uint32_t, uint32_t, hipStream_t);
-int launch_scatter_tiles(vkv_ctx *, const void *, void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
-int launch_scatter_tiles_frames(vkv_ctx *, const void *, void *const *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t);
+int launch_scatter_tiles_frames(vkv_ctx *, uint32_t, void *const *, const void *const *, const VkvTileRect *, const uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
+                                uint32_t, hipStream_t);
+void screen_tile_rect(const VkvRayCastUniform *, const VkvRayGen *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, VkvTileRect *);
 int prepare_render(vkv_ctx *, const VkvRenderParams *, uint32_t, hipStream_t);
 void load_feedback_code();
 int launch_render(vkv_ctx *, const VkvRenderParams *, const float *, hipStream_t);
@@ -598,8 +599,11 @@ int vkv_register_target(vkv_ctx *ctx, const void *d_target, uint32_t image_width
 		e = hipMemset(cost, 0, bytes);
 	if (e == hipSuccess)
 		e = hipMemcpy(order, identity.data(), bytes, hipMemcpyHostToDevice);
+	const bool     whole   = tiles->rect.w == 0 || tiles->rect.h == 0;
+	const uint32_t org_x = whole ? 0u : tiles->rect.x0 * tiles->tile_width, org_y = whole ? 0u : tiles->rect.y0 * tiles->tile_height;
+	const uint32_t tiles_x = whole ? (image_width + tiles->tile_width - 1) / tiles->tile_width : tiles->rect.w;
 	auto *f = e == hipSuccess ? new (std::nothrow) vkv_ctx::TileFeedback{d_target, image_width, image_height, tiles->tile_width, tiles->tile_height, tiles->tile_first,
-	                                                                      tiles->tile_stride, tiles->tile_count, cost, order, false, 0u, 0u, 8u, 0u}
+	                                                                      tiles->tile_stride, tiles->tile_count, org_x, org_y, tiles_x, cost, order, false, 0u, 0u, 8u, 0u}
 	                          : nullptr;
 	if (!f)
 	{
@@ -1004,8 +1008,12 @@ static int check_render_params(vkv_ctx *ctx, const VkvRenderParams *P)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: tile size must be a positive multiple of 16 and tile_stride > 0");
 	{
 		const uint64_t tiles_x = (P->image_width + t.tile_width - 1) / t.tile_width, tiles_y = (P->image_height + t.tile_height - 1) / t.tile_height;
-		if (t.tile_count && (uint64_t) t.tile_first + (uint64_t) (t.tile_count - 1) * t.tile_stride >= tiles_x * tiles_y)
-			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: tile schedule runs past the image");
+		const bool     whole   = t.rect.w == 0 || t.rect.h == 0;
+		if (!whole && ((uint64_t) t.rect.x0 + t.rect.w > tiles_x || (uint64_t) t.rect.y0 + t.rect.h > tiles_y))
+			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: the schedule's tile rectangle runs past the image");
+		const uint64_t scheduled = whole ? tiles_x * tiles_y : (uint64_t) t.rect.w * t.rect.h;
+		if (t.tile_count && (uint64_t) t.tile_first + (uint64_t) (t.tile_count - 1) * t.tile_stride >= scheduled)
+			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: tile schedule runs past the %s", whole ? "image" : "tile rectangle");
 	}
 	if (P->d_packed_volume && ((uintptr_t) P->d_packed_volume & 255u) != 0)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: d_packed_volume must be 256-byte aligned");
@@ -1062,19 +1070,43 @@ int vkv_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t count, voi
 	return launch_render_batch(ctx, P, count, luts.data(), (hipStream_t) stream);
 }
 
+// the tile rectangle a caller passed (NULL / empty: every tile of the image), checked against the image; false = it runs past the image
+static bool resolve_rect(const VkvTileRect *rect, uint32_t image_width, uint32_t image_height, uint32_t tile_width, uint32_t tile_height, VkvTileRect &out)
+{
+	const uint32_t tiles_x = (image_width + tile_width - 1) / tile_width, tiles_y = (image_height + tile_height - 1) / tile_height;
+	if (!rect || rect->w == 0 || rect->h == 0)
+	{
+		out = VkvTileRect{0u, 0u, tiles_x, tiles_y};
+		return true;
+	}
+	out = *rect;
+	return (uint64_t) rect->x0 + rect->w <= tiles_x && (uint64_t) rect->y0 + rect->h <= tiles_y;
+}
+
+int vkv_screen_tile_rect(const VkvRayCastUniform *ray_cast, const VkvRayGen *ray_gen, uint32_t image_width, uint32_t image_height, uint32_t tile_width,
+                         uint32_t tile_height, uint32_t align_tiles, VkvTileRect *out_rect)
+{
+	if (!ray_cast || !ray_gen || !out_rect || !image_width || !image_height || !tile_width || !tile_height)
+		return VKV_E_INVALID_ARGUMENT;
+	screen_tile_rect(ray_cast, ray_gen, image_width, image_height, tile_width, tile_height, align_tiles, out_rect);
+	return VKV_OK;
+}
+
 int vkv_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, uint32_t image_width, uint32_t image_height, uint32_t tile_width,
-                      uint32_t tile_height, uint32_t n_ranks, uint32_t tiles_per_rank, uint32_t bytes_per_pixel, void *stream)
+                      uint32_t tile_height, const VkvTileRect *rect, uint32_t n_ranks, uint32_t rank_stride_tiles, uint32_t bytes_per_pixel, void *stream)
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
 	DeviceGuard guard(ctx->device);
 	if (!d_gathered || !d_image || !image_width || !image_height || !tile_width || !tile_height || !n_ranks)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "scatter_tiles: null pointer or zero size");
-	const uint64_t tiles = (uint64_t) ((image_width + tile_width - 1) / tile_width) * ((image_height + tile_height - 1) / tile_height);
-	if ((uint64_t) tiles_per_rank * n_ranks < tiles)
-		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "scatter_tiles: gathered buffer holds fewer tiles than the image");
-	return launch_scatter_tiles(ctx, d_gathered, d_image, image_width, image_height, tile_width, tile_height, n_ranks, tiles_per_rank, bytes_per_pixel,
-	                            (hipStream_t) stream);
+	VkvTileRect r;
+	if (!resolve_rect(rect, image_width, image_height, tile_width, tile_height, r))
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "scatter_tiles: the tile rectangle runs past the image");
+	if ((uint64_t) rank_stride_tiles * n_ranks < (uint64_t) r.w * r.h)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "scatter_tiles: gathered buffer holds fewer tiles than the rectangle");
+	return launch_scatter_tiles_frames(ctx, 1u, &d_image, &d_gathered, &r, &rank_stride_tiles, image_width, image_height, tile_width, tile_height, n_ranks,
+	                                   bytes_per_pixel, (hipStream_t) stream);
 }
 
 // ---- RCCL, resolved at run time (the library is not a link-time dependency of the product) ---------------------------------
@@ -1083,11 +1115,13 @@ namespace
 {
 typedef int (*nccl_gather_fn)(const void *, void *, size_t, int /* ncclDataType_t */, int, void * /* ncclComm_t */, hipStream_t);
 typedef const char *(*nccl_error_fn)(int);
+typedef int (*nccl_group_fn)(void);
 struct Rccl
 {
 	void *         handle = nullptr;
 	nccl_gather_fn gather = nullptr;
 	nccl_error_fn  error  = nullptr;
+	nccl_group_fn  group_start = nullptr, group_end = nullptr;
 	bool           tried  = false;
 	std::string    why;        // the loader's message when no library could be opened (dlerror() clears itself: captured once)
 };
@@ -1126,6 +1160,8 @@ const Rccl &rccl()
 		g_rccl.handle = h;
 		g_rccl.gather = reinterpret_cast<nccl_gather_fn>(dlsym(h, "ncclGather"));
 		g_rccl.error  = reinterpret_cast<nccl_error_fn>(dlsym(h, "ncclGetErrorString"));
+		g_rccl.group_start = reinterpret_cast<nccl_group_fn>(dlsym(h, "ncclGroupStart"));
+		g_rccl.group_end   = reinterpret_cast<nccl_group_fn>(dlsym(h, "ncclGroupEnd"));
 	}
 	return g_rccl;
 }
@@ -1151,51 +1187,102 @@ int vkv_gather_tiles(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, size_t
 }
 
 int vkv_assemble_frame(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, void *d_image, uint32_t image_width, uint32_t image_height, uint32_t tile_width,
-                       uint32_t tile_height, uint32_t n_ranks, uint32_t rank, uint32_t tiles_per_rank, uint32_t bytes_per_pixel, int32_t root, void *nccl_comm,
+                       uint32_t tile_height, const VkvTileRect *rect, uint32_t n_ranks, uint32_t rank, uint32_t bytes_per_pixel, int32_t root, void *nccl_comm,
                        void *stream)
 {
-	if (!ctx)
-		return VKV_E_INVALID_ARGUMENT;
-	if (n_ranks == 0 || rank >= n_ranks || root < 0 || (uint32_t) root >= n_ranks)
-		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frame: bad rank / root / n_ranks");
-	const bool is_root = rank == (uint32_t) root;
-	if (is_root && (!d_gathered || !d_image))
-		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frame: the root needs d_gathered and d_image");
-	const size_t bytes_per_rank = (size_t) tiles_per_rank * tile_width * tile_height * bytes_per_pixel;
-	int          rc             = vkv_gather_tiles(ctx, d_tiles, d_gathered, bytes_per_rank, root, nccl_comm, stream);
-	if (rc != VKV_OK || !is_root)
-		return rc;
-	return vkv_scatter_tiles(ctx, d_gathered, d_image, image_width, image_height, tile_width, tile_height, n_ranks, tiles_per_rank, bytes_per_pixel, stream);
+	return vkv_assemble_frames(ctx, d_tiles, d_gathered, &d_image, 1u, image_width, image_height, tile_width, tile_height, rect, n_ranks, rank, bytes_per_pixel, root, nullptr,
+	                           nccl_comm, stream);
 }
 
 int vkv_assemble_frames(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, void *const *d_images, uint32_t frames, uint32_t image_width, uint32_t image_height,
-                        uint32_t tile_width, uint32_t tile_height, uint32_t n_ranks, uint32_t rank, uint32_t tiles_per_rank, uint32_t bytes_per_pixel, int32_t root,
-                        void *nccl_comm, void *stream)
+                        uint32_t tile_width, uint32_t tile_height, const VkvTileRect *rects, uint32_t n_ranks, uint32_t rank, uint32_t bytes_per_pixel, int32_t root,
+                        const int32_t *roots, void *nccl_comm, void *stream)
 {
 	if (!ctx)
 		return VKV_E_INVALID_ARGUMENT;
-	if (n_ranks == 0 || rank >= n_ranks || root < 0 || (uint32_t) root >= n_ranks || frames == 0 || frames > VKV_MAX_BATCH)
-		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: bad rank / root / n_ranks, or frames not in 1 .. %d", VKV_MAX_BATCH);
-	const bool is_root = rank == (uint32_t) root;
-	if (is_root && (!d_gathered || !d_images))
-		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: the root needs d_gathered and d_images");
-	if (is_root)
+	if (n_ranks == 0 || rank >= n_ranks || frames == 0 || frames > VKV_MAX_BATCH)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: bad rank / n_ranks, or frames not in 1 .. %d", VKV_MAX_BATCH);
+	if (!image_width || !image_height || !tile_width || !tile_height || (bytes_per_pixel != 4 && bytes_per_pixel != 16))
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: zero size, or bytes_per_pixel not 4 or 16");
+	// per frame: rectangle, owner, tiles per rank, where the frame starts in a rank's block
+	VkvTileRect rect[VKV_MAX_BATCH];
+	int32_t     owner[VKV_MAX_BATCH];
+	uint32_t    tpr[VKV_MAX_BATCH];
+	uint64_t    off[VKV_MAX_BATCH + 1];
+	const bool  one_owner = roots == nullptr;        // the caller's choice: one gather of the whole block to `root`, or a group of gathers, one per frame
+	bool        mine      = false;
+	off[0] = 0;
+	for (uint32_t f = 0; f < frames; ++f)
+	{
+		if (!resolve_rect(rects ? &rects[f] : nullptr, image_width, image_height, tile_width, tile_height, rect[f]))
+			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: the tile rectangle of frame %u runs past the image", f);
+		owner[f] = roots ? roots[f] : root;
+		if (owner[f] < 0 || (uint32_t) owner[f] >= n_ranks)
+			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: bad root %d of frame %u", owner[f], f);
+		const uint64_t tiles = (uint64_t) rect[f].w * rect[f].h;
+		tpr[f]     = (uint32_t) ((tiles + n_ranks - 1) / n_ranks);
+		off[f + 1] = off[f] + tpr[f];
+		if ((uint32_t) owner[f] == rank)
+		{
+			mine = true;
+			if (!d_images || !d_images[f])
+				return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: d_images[%u] is null on the frame's owner", f);
+		}
+	}
+	if (off[frames] * n_ranks > 0xffffffffull)
+		return set_error(ctx, VKV_E_UNSUPPORTED, "assemble_frames: too many tiles for one exchange");
+	if (mine && !d_gathered)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: a rank that owns a frame needs d_gathered");
+	const size_t   tile_bytes = (size_t) tile_width * tile_height * bytes_per_pixel;
+	const uint8_t *tiles_b    = static_cast<const uint8_t *>(d_tiles);
+	uint8_t *      gath_b     = static_cast<uint8_t *>(d_gathered);
+	const void *   src[VKV_MAX_BATCH];
+	uint32_t       stride[VKV_MAX_BATCH];
+	if (one_owner)
+	{
+		// ONE collective for the whole launch: [frame][tiles] of every rank -> [rank][frame][tiles] on the owner
+		const int rc = vkv_gather_tiles(ctx, d_tiles, d_gathered, (size_t) off[frames] * tile_bytes, owner[0], nccl_comm, stream);
+		if (rc != VKV_OK)
+			return rc;
 		for (uint32_t f = 0; f < frames; ++f)
-			if (!d_images[f])
-				return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: d_images[%u] is null", f);
-	if (!image_width || !image_height || !tile_width || !tile_height)
-		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: zero size");
-	const uint64_t tiles = (uint64_t) ((image_width + tile_width - 1) / tile_width) * ((image_height + tile_height - 1) / tile_height);
-	if ((uint64_t) tiles_per_rank * n_ranks < tiles)
-		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: the ranks' buffers hold fewer tiles than the image");
-	// ONE collective for the whole launch: [frame][tiles] of every rank -> [rank][frame][tiles] on the root
-	const size_t bytes_per_rank = (size_t) frames * tiles_per_rank * tile_width * tile_height * bytes_per_pixel;
-	int          rc             = vkv_gather_tiles(ctx, d_tiles, d_gathered, bytes_per_rank, root, nccl_comm, stream);
-	if (rc != VKV_OK || !is_root)
-		return rc;
+			src[f] = gath_b + (size_t) off[f] * tile_bytes, stride[f] = (uint32_t) off[frames];
+	}
+	else
+	{
+		// owners spread over the ranks: one gather per frame, all of them in ONE group (RCCL fuses the group's point-to-point transfers: every
+		// owner receives at the same time over its own inbound links); frame f arrives as [rank][tpr(f) tiles] at tile n_ranks * off[f]
+		if (!d_tiles || !nccl_comm)
+			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: null buffer / communicator");
+		const Rccl &r = rccl();
+		if (!r.gather)
+			return set_error(ctx, VKV_E_UNSUPPORTED, "assemble_frames: no RCCL library with ncclGather could be loaded (%s)", r.why.empty() ? "librccl.so.1" : r.why.c_str());
+		DeviceGuard guard(ctx->device);
+		const bool  grouped = r.group_start && r.group_end;
+		int         rc      = grouped ? r.group_start() : 0;
+		for (uint32_t f = 0; f < frames && rc == 0; ++f)
+			if (tpr[f])
+				rc = r.gather(tiles_b + (size_t) off[f] * tile_bytes, (uint32_t) owner[f] == rank ? gath_b + (size_t) n_ranks * off[f] * tile_bytes : nullptr,
+				              (size_t) tpr[f] * tile_bytes, 0 /* ncclInt8 / ncclChar */, owner[f], nccl_comm, (hipStream_t) stream);
+		if (grouped)
+		{
+			const int rc2 = r.group_end();        // (always closed: an open group would swallow the caller's next collective)
+			rc = rc ? rc : rc2;
+		}
+		if (rc != 0)
+			return set_error(ctx, 1000 + rc, "assemble_frames: ncclGather group: %s", r.error ? r.error(rc) : "error");
+		for (uint32_t f = 0; f < frames; ++f)
+			src[f] = gath_b + (size_t) n_ranks * off[f] * tile_bytes, stride[f] = tpr[f];
+	}
+	if (!mine)
+		return VKV_OK;
+	// ONE de-interleave kernel for the frames this rank owns
+	void *      img[VKV_MAX_BATCH];
+	uint32_t    n = 0;
+	for (uint32_t f = 0; f < frames; ++f)
+		if ((uint32_t) owner[f] == rank)
+			img[n] = d_images[f], src[n] = src[f], rect[n] = rect[f], stride[n] = stride[f], ++n;
 	DeviceGuard guard(ctx->device);
-	return launch_scatter_tiles_frames(ctx, d_gathered, d_images, frames, image_width, image_height, tile_width, tile_height, n_ranks, tiles_per_rank, bytes_per_pixel,
-	                                   (hipStream_t) stream);
+	return launch_scatter_tiles_frames(ctx, n, img, src, rect, stride, image_width, image_height, tile_width, tile_height, n_ranks, bytes_per_pixel, (hipStream_t) stream);
 }
 
 int vkv_prepare_render(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t count, void *stream)

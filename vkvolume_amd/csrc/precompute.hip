@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(256) k_occupancy_map_dword_any(const uint8_t *
 		const int     xd     = (x0 >> 2) + d;
 		uint32_t      occ    = 0;
 		constexpr int kBatch = 8;        // rows fetched together (see k_occupancy_map_dword)
-		const int     ny = y_end - cy * by, n_rows = ny * (z_end - cz * bz);
+		const int     ny = y_end - cy * by, nz = z_end - cz * bz, n_rows = (ny > 0 && nz > 0) ? ny * nz : 0;        // (a cell row / slice past the volume: no rows)
 		for (int r0 = 0; r0 < n_rows; r0 += kBatch)
 		{
 			uint32_t v4[kBatch], g4[kBatch];
@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(256) k_occupancy_map_dword(const uint8_t *__re
 	// the by x bz rows of the cell are fetched eight at a time (16 loads in flight per lane: the kernel is a pure stream and
 	// bandwidth = bytes in flight / latency)
 	constexpr int kBatch = 8;
-	const int     ny = y_end - cy * by, n_rows = ny * (z_end - cz * bz);
+	const int     ny = y_end - cy * by, nz = z_end - cz * bz, n_rows = (ny > 0 && nz > 0) ? ny * nz : 0;        // (a cell row / slice past the volume: no rows)
 	for (int r0 = 0; r0 < n_rows; r0 += kBatch)
 	{
 		uint32_t v4[kBatch], g4[kBatch];
@@ -1375,43 +1375,41 @@ __global__ void __launch_bounds__(256) k_convert_volume(const T *__restrict__ ra
 }
 
 // ---------------------------------------------------------------------------------------------
-// Multi-GPU: de-interleave gathered compact tile buffers into the final image (one thread per pixel)
+// Multi-GPU: de-interleave gathered compact tile buffers into the final image(s) (one thread per pixel, or per four RGBA8 pixels).
+// blockIdx.z = frame of the launch; each frame has its own image, source ([rank][tiles], `stride` tiles between two ranks' buffers) and
+// tile rectangle (tiles numbered row-major inside it, tile t on rank t % n_ranks as its (t / n_ranks)-th); pixels outside the rectangle
+// are cleared, so the image is complete after the kernel.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256) k_scatter_tiles(const T *__restrict__ gathered, T *__restrict__ image, uint32_t iw, uint32_t ih,
-                                                       uint32_t tw, uint32_t th, uint32_t n_ranks, uint32_t tiles_per_rank)
+struct ScatterFrame
 {
-	const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
-	const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
-	if (x >= iw || y >= ih)
-		return;
-	const uint32_t tiles_x = (iw + tw - 1) / tw;
-	const uint32_t t       = (y / th) * tiles_x + (x / tw);
-	const uint32_t rank = t % n_ranks, k = t / n_ranks;
-	const size_t   src = (((size_t) rank * tiles_per_rank + k) * th + (y % th)) * tw + (x % tw);
-	image[(size_t) y * iw + x] = gathered[src];
-}
-
-// the frames of one gathered vkv_render_batch launch in one grid: blockIdx.z = frame; the source holds [rank][frame][tiles]
-struct ScatterImages
+	void *      image;
+	const void *src;
+	uint32_t    rx0, ry0, rw, rh;        // the tile rectangle
+	uint32_t    stride;                  // tiles between the buffers of two ranks
+	uint32_t    pad;
+};
+struct ScatterFrames
 {
-	void *image[VKV_MAX_BATCH];
+	ScatterFrame f[VKV_MAX_BATCH];
 };
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_scatter_tiles_frames(const T *__restrict__ gathered, const ScatterImages images, uint32_t iw, uint32_t ih, uint32_t tw, uint32_t th,
-                                                              uint32_t n_ranks, uint32_t tiles_per_rank, uint32_t frames)
+__global__ void __launch_bounds__(256) k_scatter_tiles_frames(const ScatterFrames frames, uint32_t iw, uint32_t ih, uint32_t tw, uint32_t th, uint32_t n_ranks)
 {
 	const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
 	const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
-	const uint32_t f = blockIdx.z;
 	if (x >= iw || y >= ih)
 		return;
-	const uint32_t tiles_x = (iw + tw - 1) / tw;
-	const uint32_t t       = (y / th) * tiles_x + (x / tw);
-	const uint32_t rank = t % n_ranks, k = t / n_ranks;
-	const size_t   src = ((((size_t) rank * frames + f) * tiles_per_rank + k) * th + (y % th)) * tw + (x % tw);
-	static_cast<T *>(images.image[f])[(size_t) y * iw + x] = gathered[src];
+	const ScatterFrame &F  = frames.f[blockIdx.z];
+	const uint32_t      tx = x / tw - F.rx0, ty = y / th - F.ry0;        // (wraps to a huge value left of / above the rectangle)
+	T                   v  = {};
+	if (tx < F.rw && ty < F.rh)
+	{
+		const uint32_t t    = ty * F.rw + tx;
+		const uint32_t rank = t % n_ranks, k = t / n_ranks;
+		v = static_cast<const T *>(F.src)[(((size_t) rank * F.stride + k) * th + (y % th)) * tw + (x % tw)];
+	}
+	static_cast<T *>(F.image)[(size_t) y * iw + x] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1470,6 +1468,14 @@ int launch_occupancy_map(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_gr
 	const int W = (int) e.width, H = (int) e.height, D = (int) e.depth, mw = (int) me.width, mh = (int) me.height, md = (int) me.depth;
 	const bool precomputed = tf->use_gradient && d_grad;
 	const VkvTuning T_occ = tuning_of(ctx);
+	// a map extent above ceil(extent / block) leaves cells without a voxel: EMPTY.  The wave kernel fills the whole map first anyway;
+	// the workgroup-per-cell-row kernels only visit cells the volume reaches in x, so such a map is filled for them too
+	if ((uint64_t) (mw - 1) * bx >= (uint64_t) W || (uint64_t) (mh - 1) * by >= (uint64_t) H || (uint64_t) (md - 1) * bz >= (uint64_t) D)
+	{
+		const hipError_t em = hipMemsetAsync(d_map, 255, (size_t) me.width * me.height * me.depth, s);
+		if (em != hipSuccess)
+			return set_error(ctx, (int) em, "occupancy_map: fill: %s", hipGetErrorString(em));
+	}
 	if ((bx == 1 || bx == 2 || bx == 4) && T_occ.occupancy_kernel == 1 && (e.width & 3u) == 0 && (!tf->use_gradient || precomputed) && (((uintptr_t) d_vol | (uintptr_t) d_grad) & 3u) == 0)
 	{
 		const uint32_t dblocks = (e.width / 4 + 255) / 256;
@@ -1954,46 +1960,27 @@ int launch_convert_volume(vkv_ctx *ctx, const void *d_raw, int type, bool big_en
 	return check_launch(ctx, "convert_volume");
 }
 
-int launch_scatter_tiles(vkv_ctx *ctx, const void *d_gathered, void *d_image, uint32_t iw, uint32_t ih, uint32_t tw, uint32_t th, uint32_t n_ranks,
-                         uint32_t tiles_per_rank, uint32_t bpp, hipStream_t s)
+// `n` frames (1 .. VKV_MAX_BATCH) described by images[f], srcs[f], rects[f] (a rectangle of whole tiles inside the image), strides[f]
+int launch_scatter_tiles_frames(vkv_ctx *ctx, uint32_t n, void *const *images, const void *const *srcs, const VkvTileRect *rects, const uint32_t *strides, uint32_t iw,
+                                uint32_t ih, uint32_t tw, uint32_t th, uint32_t n_ranks, uint32_t bpp, hipStream_t s)
 {
-	const dim3 grid((iw + 63) / 64, (ih + 3) / 4);
-	if (bpp == 4 && (iw & 3u) == 0 && (tw & 3u) == 0 && ((((uintptr_t) d_gathered) | ((uintptr_t) d_image)) & 15u) == 0)
-	{        // four RGBA8 pixels per lane: rows of both layouts are whole multiples of 16 bytes, so it is the 16-byte kernel on iw/4 x tw/4
-		const dim3 grid4((iw / 4 + 63) / 64, (ih + 3) / 4);
-		hipLaunchKernelGGL(k_scatter_tiles<uint4>, grid4, dim3(256), 0, s, (const uint4 *) d_gathered, (uint4 *) d_image, iw / 4, ih, tw / 4, th, n_ranks,
-		                   tiles_per_rank);
+	ScatterFrames fr{};
+	bool          aligned = true;
+	for (uint32_t f = 0; f < n; ++f)
+	{
+		fr.f[f] = ScatterFrame{images[f], srcs[f], rects[f].x0, rects[f].y0, rects[f].w, rects[f].h, strides[f], 0u};
+		aligned = aligned && (((uintptr_t) images[f] | (uintptr_t) srcs[f]) & 15u) == 0;
 	}
+	if (bpp == 4 && (iw % 4) == 0 && (tw % 4) == 0 && aligned)
+		// RGBA8: four pixels per thread (a 16-pixel tile row = 64 B = 4 threads)
+		hipLaunchKernelGGL(k_scatter_tiles_frames<uint4>, dim3((iw / 4 + 63) / 64, (ih + 3) / 4, n), dim3(256), 0, s, fr, iw / 4, ih, tw / 4, th, n_ranks);
 	else if (bpp == 4)
-		hipLaunchKernelGGL(k_scatter_tiles<uint32_t>, grid, dim3(256), 0, s, (const uint32_t *) d_gathered, (uint32_t *) d_image, iw, ih, tw, th, n_ranks,
-		                   tiles_per_rank);
+		hipLaunchKernelGGL(k_scatter_tiles_frames<uint32_t>, dim3((iw + 63) / 64, (ih + 3) / 4, n), dim3(256), 0, s, fr, iw, ih, tw, th, n_ranks);
 	else if (bpp == 16)
-		hipLaunchKernelGGL(k_scatter_tiles<uint4>, grid, dim3(256), 0, s, (const uint4 *) d_gathered, (uint4 *) d_image, iw, ih, tw, th, n_ranks,
-		                   tiles_per_rank);
+		hipLaunchKernelGGL(k_scatter_tiles_frames<uint4>, dim3((iw + 63) / 64, (ih + 3) / 4, n), dim3(256), 0, s, fr, iw, ih, tw, th, n_ranks);
 	else
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "scatter_tiles: bytes_per_pixel must be 4 or 16");
 	return check_launch(ctx, "scatter_tiles");
-}
-
-int launch_scatter_tiles_frames(vkv_ctx *ctx, const void *d_gathered, void *const *d_images, uint32_t frames, uint32_t iw, uint32_t ih, uint32_t tw, uint32_t th,
-                                uint32_t n_ranks, uint32_t tiles_per_rank, uint32_t bpp, hipStream_t s)
-{
-	ScatterImages imgs = {};
-	uintptr_t     align = (uintptr_t) d_gathered;
-	for (uint32_t f = 0; f < frames; ++f)
-		imgs.image[f] = d_images[f], align |= (uintptr_t) d_images[f];
-	if (bpp == 4 && (iw & 3u) == 0 && (tw & 3u) == 0 && (align & 15u) == 0)
-		hipLaunchKernelGGL(k_scatter_tiles_frames<uint4>, dim3((iw / 4 + 63) / 64, (ih + 3) / 4, frames), dim3(256), 0, s, (const uint4 *) d_gathered, imgs, iw / 4, ih,
-		                   tw / 4, th, n_ranks, tiles_per_rank, frames);
-	else if (bpp == 4)
-		hipLaunchKernelGGL(k_scatter_tiles_frames<uint32_t>, dim3((iw + 63) / 64, (ih + 3) / 4, frames), dim3(256), 0, s, (const uint32_t *) d_gathered, imgs, iw, ih, tw,
-		                   th, n_ranks, tiles_per_rank, frames);
-	else if (bpp == 16)
-		hipLaunchKernelGGL(k_scatter_tiles_frames<uint4>, dim3((iw + 63) / 64, (ih + 3) / 4, frames), dim3(256), 0, s, (const uint4 *) d_gathered, imgs, iw, ih, tw, th,
-		                   n_ranks, tiles_per_rank, frames);
-	else
-		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "assemble_frames: bytes_per_pixel must be 4 or 16");
-	return check_launch(ctx, "assemble_frames");
 }
 
 }        // namespace vkv

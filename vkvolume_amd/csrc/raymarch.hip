@@ -178,18 +178,27 @@ static bool launch_pull(vkv_ctx *ctx, int skip, bool ert, int grad, const RayMar
 	}
 }
 
-// Conservative pixel bound of the unit box [0,1]^3 (texture space) as seen through the ray generator of the kernel: pixel (px, py) looks
-// along dir00 + (px + 0.5) ddx + (py + 0.5) ddy from cam, so a corner c is seen at the (fx, fy) with c - cam = g (dir00 + fx ddx + fy ddy),
-// g > 0.  The bound is the min / max over the eight corners, widened by two pixels (the device evaluates the direction in fp32: it can
-// disagree with this double-precision solve by a tiny fraction of a pixel); a corner at or behind the camera plane, or a degenerate
-// generator, disables it.  Pixels outside cannot hit the box, whatever the clip plane or the depth test do afterwards.
-static void screen_bound_of_box(RayMarchArgs &a, const VkvTuning &T)
+// Conservative pixel bound of what a frame's fragments can see: the unit box [0,1]^3 (texture space) cut by the clipping plane (kept side:
+// dot(plane_tex.xyz, p) + plane_tex.w >= 0 - ray_setup_impl starts a ray at t0 = max(t_box_near, t_plane) and needs t0 < t_box_far, so every
+// fragment's ray holds a point of that clipped box), as seen through the ray generator of the kernel: pixel (px, py) looks along
+// dir00 + (px + 0.5) ddx + (py + 0.5) ddy from cam, so a point c is seen at the (fx, fy) with c - cam = g (dir00 + fx ddx + fy ddy), g > 0.
+// The clipped box is convex and the map to (fx, fy) keeps convexity in front of the camera: the bound is the min / max over its VERTICES - the
+// box corners on the kept side and the points where the plane cuts an edge (the plane is moved outwards by 1e-4 of its normal's length
+// first: the device evaluates in fp32) -, widened by two pixels (the device evaluates the direction in fp32: it can disagree with this
+// double-precision solve by a tiny fraction of a pixel).  A vertex at or behind the camera plane, or a degenerate generator, disables it
+// (kScreenBoundNone); no vertex at all = nothing can be seen (kScreenBoundEmpty).  With the application's plane (through a point in front of the
+// camera, facing away from it) every vertex lies in front of the camera, also for a camera inside the box: round 6 - the bound of the
+// un-clipped box (rounds 2-5) gave up there.  Pixels outside cannot have a fragment, whatever the depth test does afterwards.
+enum
 {
-	a.cull_x0 = 0u, a.cull_x1 = ~0u, a.cull_y0 = 0u, a.cull_y1 = ~0u;
-	if (!T.screen_cull)        // A/B switch
-		return;
+	kScreenBoundNone  = 0,
+	kScreenBoundEmpty = 1,
+	kScreenBoundRect  = 2
+};
+int screen_bound(const float cam[3], const float dir00[3], const float ddx[3], const float ddy[3], const float plane_tex[4], double out[4])
+{
 	// inverse of M = [ddx ddy dir00] (columns) by the adjugate
-	const double M[3][3] = {{a.ddx[0], a.ddy[0], a.dir00[0]}, {a.ddx[1], a.ddy[1], a.dir00[1]}, {a.ddx[2], a.ddy[2], a.dir00[2]}};
+	const double M[3][3] = {{ddx[0], ddy[0], dir00[0]}, {ddx[1], ddy[1], dir00[1]}, {ddx[2], ddy[2], dir00[2]}};
 	double       inv[3][3], scale = 0.0;
 	for (int i = 0; i < 3; ++i)
 		for (int j = 0; j < 3; ++j)
@@ -200,26 +209,92 @@ static void screen_bound_of_box(RayMarchArgs &a, const VkvTuning &T)
 		}
 	const double det = M[0][0] * inv[0][0] + M[0][1] * inv[1][0] + M[0][2] * inv[2][0];
 	if (!std::isfinite(det) || !(std::fabs(det) > 1e-12 * scale * scale * scale))
-		return;
-	double lo_x = 1e300, hi_x = -1e300, lo_y = 1e300, hi_y = -1e300;
-	for (int c = 0; c < 8; ++c)
+		return kScreenBoundNone;
+	// vertices of the clipped box
+	double    vert[8 + 12][3];
+	int       n_vert = 0;
+	double    sd[8];        // signed plane values of the corners (+ the outward shift)
+	bool      clip = plane_tex != nullptr;
+	if (clip)
 	{
-		const double v[3] = {(double) (c & 1) - a.cam[0], (double) ((c >> 1) & 1) - a.cam[1], (double) ((c >> 2) & 1) - a.cam[2]};
+		const double pn = std::sqrt((double) plane_tex[0] * plane_tex[0] + (double) plane_tex[1] * plane_tex[1] + (double) plane_tex[2] * plane_tex[2]);
+		if (!std::isfinite(pn) || !(pn > 0.0) || !std::isfinite((double) plane_tex[3]))
+			clip = false;        // no usable plane: the whole box
+		for (int c = 0; c < 8 && clip; ++c)
+			sd[c] = (double) plane_tex[0] * (c & 1) + (double) plane_tex[1] * ((c >> 1) & 1) + (double) plane_tex[2] * ((c >> 2) & 1) + (double) plane_tex[3] + 1e-4 * pn;
+	}
+	for (int c = 0; c < 8; ++c)
+		if (!clip || sd[c] >= 0.0)
+			vert[n_vert][0] = (double) (c & 1), vert[n_vert][1] = (double) ((c >> 1) & 1), vert[n_vert][2] = (double) ((c >> 2) & 1), ++n_vert;
+	if (clip)
+		for (int c = 0; c < 8; ++c)
+			for (int axis = 0; axis < 3; ++axis)
+			{
+				const int d = c | (1 << axis);
+				if (d == c || (sd[c] >= 0.0) == (sd[d] >= 0.0))
+					continue;        // (each edge once: from its corner with the axis bit clear) the plane does not cut this edge
+				const double u = sd[c] / (sd[c] - sd[d]);
+				for (int k = 0; k < 3; ++k)
+					vert[n_vert][k] = (double) ((c >> k) & 1) + u * ((double) ((d >> k) & 1) - (double) ((c >> k) & 1));
+				++n_vert;
+			}
+	if (n_vert == 0)
+		return kScreenBoundEmpty;
+	double lo_x = 1e300, hi_x = -1e300, lo_y = 1e300, hi_y = -1e300;
+	for (int i = 0; i < n_vert; ++i)
+	{
+		const double v[3] = {vert[i][0] - cam[0], vert[i][1] - cam[1], vert[i][2] - cam[2]};
 		const double fa = (inv[0][0] * v[0] + inv[0][1] * v[1] + inv[0][2] * v[2]) / det, fb = (inv[1][0] * v[0] + inv[1][1] * v[1] + inv[1][2] * v[2]) / det;
 		const double g  = (inv[2][0] * v[0] + inv[2][1] * v[1] + inv[2][2] * v[2]) / det;
 		if (!(g > 1e-6) || !std::isfinite(fa) || !std::isfinite(fb))
-			return;        // a corner beside or behind the camera: its projection says nothing
+			return kScreenBoundNone;        // a vertex beside or behind the camera: its projection says nothing
 		lo_x = std::min(lo_x, fa / g), hi_x = std::max(hi_x, fa / g), lo_y = std::min(lo_y, fb / g), hi_y = std::max(hi_y, fb / g);
 	}
 	// pixel p is sampled at p + 0.5
-	const double x0 = std::floor(lo_x - 0.5) - 2.0, x1 = std::ceil(hi_x - 0.5) + 2.0, y0 = std::floor(lo_y - 0.5) - 2.0, y1 = std::ceil(hi_y - 0.5) + 2.0;
-	if (x1 < 0.0 || y1 < 0.0 || x0 > 4.0e9 || y0 > 4.0e9)
-	{        // the box is off screen: an empty bound
+	out[0] = std::floor(lo_x - 0.5) - 2.0, out[1] = std::ceil(hi_x - 0.5) + 2.0, out[2] = std::floor(lo_y - 0.5) - 2.0, out[3] = std::ceil(hi_y - 0.5) + 2.0;
+	if (out[1] < 0.0 || out[3] < 0.0 || out[0] > 4.0e9 || out[2] > 4.0e9)
+		return kScreenBoundEmpty;        // off screen
+	return kScreenBoundRect;
+}
+
+static void screen_bound_of_box(RayMarchArgs &a, const VkvTuning &T)
+{
+	a.cull_x0 = 0u, a.cull_x1 = ~0u, a.cull_y0 = 0u, a.cull_y1 = ~0u;
+	if (!T.screen_cull)        // A/B switch
+		return;
+	double    b[4];
+	const int kind = screen_bound(a.cam, a.dir00, a.ddx, a.ddy, a.plane_tex, b);
+	if (kind == kScreenBoundNone)
+		return;
+	if (kind == kScreenBoundEmpty)
+	{        // nothing of the clipped box is on screen: an empty bound
 		a.cull_x0 = 1u, a.cull_x1 = 0u;
 		return;
 	}
-	a.cull_x0 = x0 <= 0.0 ? 0u : (uint32_t) x0, a.cull_y0 = y0 <= 0.0 ? 0u : (uint32_t) y0;
-	a.cull_x1 = x1 >= 4.0e9 ? ~0u : (uint32_t) x1, a.cull_y1 = y1 >= 4.0e9 ? ~0u : (uint32_t) y1;
+	a.cull_x0 = b[0] <= 0.0 ? 0u : (uint32_t) b[0], a.cull_y0 = b[2] <= 0.0 ? 0u : (uint32_t) b[2];
+	a.cull_x1 = b[1] >= 4.0e9 ? ~0u : (uint32_t) b[1], a.cull_y1 = b[3] >= 4.0e9 ? ~0u : (uint32_t) b[3];
+}
+
+// vkv_screen_tile_rect: the same bound in whole tiles
+void screen_tile_rect(const VkvRayCastUniform *rc, const VkvRayGen *rg, uint32_t iw, uint32_t ih, uint32_t tw, uint32_t th, uint32_t align, VkvTileRect *out)
+{
+	const uint32_t tiles_x = (iw + tw - 1) / tw, tiles_y = (ih + th - 1) / th;
+	*out = VkvTileRect{0u, 0u, tiles_x, tiles_y};
+	double    b[4];
+	const int kind = screen_bound(rc->camera_pos_tex, rg->dir00, rg->ddx, rg->ddy, rc->plane_tex, b);
+	if (kind == kScreenBoundNone)
+		return;
+	if (kind == kScreenBoundEmpty || b[0] >= (double) iw || b[2] >= (double) ih)
+	{
+		*out = VkvTileRect{0u, 0u, 1u, 1u};
+		return;
+	}
+	const uint32_t x0 = b[0] <= 0.0 ? 0u : (uint32_t) b[0], y0 = b[2] <= 0.0 ? 0u : (uint32_t) b[2];
+	const uint32_t x1 = b[1] >= (double) (iw - 1) ? iw - 1 : (uint32_t) b[1], y1 = b[3] >= (double) (ih - 1) ? ih - 1 : (uint32_t) b[3];        // inclusive
+	const uint32_t q = align > 1 ? align : 1u;
+	uint32_t       tx0 = (x0 / tw) / q * q, ty0 = (y0 / th) / q * q;
+	uint32_t       tx1 = std::min(tiles_x, (x1 / tw + q) / q * q), ty1 = std::min(tiles_y, (y1 / th + q) / q * q);        // exclusive
+	*out = VkvTileRect{tx0, ty0, tx1 - tx0, ty1 - ty0};
 }
 
 // VkvRenderParams -> kernel arguments.  Returns VKV_OK with a.nblocks == 0 when the schedule is empty.
@@ -254,7 +329,12 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 	a.depth_attachment = P->options.depth_attachment != 0, a.blend = P->blend_over_target != 0;
 	a.img_w = P->image_width, a.img_h = P->image_height;
 	a.tile_w = P->tiles.tile_width, a.tile_h = P->tiles.tile_height;
-	a.tiles_x    = (a.img_w + a.tile_w - 1) / a.tile_w;
+	{        // the schedule's tile rectangle (all zero: the whole image); tiles are numbered row-major inside it
+		const VkvTileRect &r = P->tiles.rect;
+		const bool         whole = r.w == 0 || r.h == 0;
+		a.tiles_x = whole ? (a.img_w + a.tile_w - 1) / a.tile_w : r.w;
+		a.org_x = whole ? 0u : r.x0 * a.tile_w, a.org_y = whole ? 0u : r.y0 * a.tile_h;
+	}
 	a.tile_first = P->tiles.tile_first, a.tile_stride = P->tiles.tile_stride, a.tile_count = P->tiles.tile_count, a.compact = P->tiles.compact;
 	a.blocks_per_tile_x = a.tile_w / 16;
 	a.blocks_per_tile   = a.blocks_per_tile_x * (a.tile_h / 16);
@@ -291,7 +371,15 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 	if (a.packed && T.address_tables != 0)
 		a.addr_lut = packed_addr_lut(ctx, a.W, a.H, a.D, &a.lut_y, &a.lut_z, &a.lut_words, s, setup);
 	screen_bound_of_box(a, T);
-	a.tile_order  = T.tile_order_linear ? nullptr : tile_start_order(ctx, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count, s, setup);
+	{
+		// centre first: of the image, or of the rectangle (the projected box) - the order of a rectangle depends on its size only, not on where
+		// it lies, so a camera that moves the rectangle about keeps its cached table
+		const VkvTileRect &r = P->tiles.rect;
+		const bool         whole = r.w == 0 || r.h == 0;
+		a.tile_order = T.tile_order_linear ? nullptr
+		                                   : tile_start_order(ctx, whole ? a.img_w : r.w * a.tile_w, whole ? a.img_h : r.h * a.tile_h, a.tile_w, a.tile_h, a.tile_first,
+		                                                      a.tile_stride, a.tile_count, s, setup);
+	}
 	for (int i = 0; i < 256; ++i)
 		a.alpha_lut[i] = alpha_lut[i];
 	return VKV_OK;
@@ -317,7 +405,7 @@ static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a, hipStream_t s)
 		return false;
 	for (auto *e : ctx->feedback)
 		if (e->target == target && e->img_w == a.img_w && e->img_h == a.img_h && e->tile_w == a.tile_w && e->tile_h == a.tile_h && e->first == a.tile_first &&
-		    e->stride == a.tile_stride && e->count == a.tile_count)
+		    e->stride == a.tile_stride && e->count == a.tile_count && e->org_x == a.org_x && e->org_y == a.org_y && e->tiles_x == a.tiles_x)
 		{
 			f = e;
 			break;
@@ -431,13 +519,25 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 			return rc;
 		if (!host[i].packed)
 			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: frame %u has no packed sampling image (d_packed_volume)", i);
-		if (host[i].nblocks != host[0].nblocks || host[i].tile_count != host[0].tile_count || host[i].blocks_per_tile != host[0].blocks_per_tile)
-			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: frame %u has a different tile schedule size than frame 0", i);
+		// the frames of a launch share the tile SIZE; their tile counts may differ (every frame of a multi-GPU launch has its own screen
+		// rectangle): the grid is sized for the largest, a frame's surplus workgroups leave at once
+		if (host[i].blocks_per_tile != host[0].blocks_per_tile)
+			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render_batch: frame %u has a different tile size than frame 0", i);
 		if (ctx->d_debug_orders && i < ctx->debug_order_frames && ctx->debug_order_count == host[i].tile_count)
 			host[i].tile_order = ctx->d_debug_orders + (size_t) i * ctx->debug_order_count;        // diagnostic start orders
 	}
-	if (host[0].nblocks == 0)
+	uint32_t max_tiles = 0, ref = 0;        // ref: the first frame with tiles (an empty frame's argument block is only filled up to its tile count)
+	bool     same_count = true;
+	for (uint32_t i = n; i-- > 0;)
+	{
+		max_tiles = std::max(max_tiles, host[i].nblocks ? host[i].tile_count : 0u);
+		if (host[i].nblocks)
+			ref = i;
+	}
+	if (max_tiles == 0)
 		return VKV_OK;
+	for (uint32_t i = 0; i < n; ++i)
+		same_count = same_count && host[i].nblocks != 0 && host[i].tile_count == max_tiles;
 	// measured start order only with early ray termination: without it every covered tile is about equally long, nothing is gained by
 	// starting the longest first, and an order sorted by cost scatters neighbouring tiles (C3 without ERT: 0.394 against 0.373 ms per frame)
 	bool any_sort = false;
@@ -515,7 +615,7 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	const hipError_t e = hipMemcpyAsync(d_heads, upload_src, upload.size(), hipMemcpyHostToDevice, s);
 	if (e != hipSuccess)
 		return set_error(ctx, (int) e, "render_batch: argument upload: %s", hipGetErrorString(e));
-	const uint64_t grid = (uint64_t) ((host[0].tile_count + 7u) / 8u) * 8u * host[0].blocks_per_tile * n;
+	const uint64_t grid = (uint64_t) ((max_tiles + 7u) / 8u) * 8u * host[0].blocks_per_tile * n;
 	if (grid > 0x7fffffffull)
 		return set_error(ctx, VKV_E_UNSUPPORTED, "render_batch: too many workgroups for one launch");
 	const bool ert  = P[0].options.early_ray_termination != 0;
@@ -524,14 +624,16 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	// switch: measured 0.183 vs 0.169 ms per frame on C3 with 8 frames per launch)
 	const bool        sequential = T.batch_sequential != 0;
 	const uint32_t    gpf        = sequential ? (uint32_t) (grid / n / 8) : 0u;
-	LeanChoice        choice     = choose_lean(host[0], T);
+	LeanChoice        choice     = choose_lean(host[ref], T);
 	bool              no_counts  = true;        // no frame reads the per-pixel counters (no counter buffer, no sample-count test output): the loop without them
 	for (uint32_t i = 0; i < n; ++i)
-		no_counts = no_counts && !wants_counts(host[i]);
-	for (uint32_t i = 1; i < n; ++i)
+		no_counts = no_counts && (host[i].nblocks == 0 || !wants_counts(host[i]));
+	for (uint32_t i = 0; i < n; ++i)
 	{        // one kernel for all frames: the most general choice any of them needs
+		if (i == ref || host[i].nblocks == 0)
+			continue;
 		const LeanChoice c = choose_lean(host[i], T);
-		if (c.kind != choice.kind || c.lds != choice.lds || host[i].lut_words != host[0].lut_words)
+		if (c.kind != choice.kind || c.lds != choice.lds || host[i].lut_words != host[ref].lut_words)
 			choice = {0, 0};
 	}
 	// VkvTuning.batch_mode = 1 (pull): resident workgroups whose waves pull 8x8 units from per-XCD ticket counters (k_raymarch_lean_pull), possible
@@ -539,8 +641,8 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	// frames per launch: the CU stays full (7 900 of 8 192 wave slots against 5 300) and everything but the last marching tiles is done after
 	// 0.83 ms instead of 1.0, but those last tiles - the volume's silhouette, 100-250 iterations of cold probes - then run 340 us with their
 	// four 8x8 units on four different CUs (150 us as one workgroup on one CU): 0.151 ms per frame against 0.137.  Not the default.
-	bool              pull      = T.batch_mode == 1 && !sequential;
-	const uint64_t    units     = (uint64_t) host[0].tile_count * host[0].blocks_per_tile * 4u * n;
+	bool              pull      = T.batch_mode == 1 && !sequential && same_count;        // (its tickets count one tile count for every frame)
+	const uint64_t    units     = (uint64_t) max_tiles * host[0].blocks_per_tile * 4u * n;
 	for (uint32_t i = 1; i < n && pull; ++i)
 	{
 		const RayMarchArgs &a = host[i], &b = host[0];

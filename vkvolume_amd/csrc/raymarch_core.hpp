@@ -51,7 +51,8 @@ struct RayMarchArgs
 	float *         out_depth;
 	const float *   in_depth;           // scene depth (options.depth_attachment) or null
 	uint32_t        depth_attachment, blend;
-	uint32_t        img_w, img_h, tile_w, tile_h, tiles_x, tile_first, tile_stride, tile_count, compact;
+	uint32_t        img_w, img_h, tile_w, tile_h, tiles_x, tile_first, tile_stride, tile_count, compact;        // tiles_x: tile columns of the schedule's rectangle
+	uint32_t        org_x, org_y;   // first pixel column / row of the schedule's tile rectangle (VkvTileSchedule.rect; 0, 0 = the whole image)
 	uint32_t        blocks_per_tile_x, blocks_per_tile, nblocks;
 	int             test;
 	unsigned long long *trace;      // diagnostic (tools/wave_trace.py): kTraceWords x u64 per wave {t_start, t_end, iterations, unit, phase sums}, or null
@@ -732,7 +733,7 @@ __device__ __forceinline__ bool unit_pixel(const RayMarchArgs &A, uint32_t u, ui
 	const uint32_t t = A.tile_first + k * A.tile_stride;
 	const uint32_t lx = (sb % A.blocks_per_tile_x) * 16 + (w & 1) * 8 + (slot & 7);
 	const uint32_t ly = (sb / A.blocks_per_tile_x) * 16 + (w >> 1) * 8 + (slot >> 3);
-	px = (t % A.tiles_x) * A.tile_w + lx, py = (t / A.tiles_x) * A.tile_h + ly;
+	px = A.org_x + (t % A.tiles_x) * A.tile_w + lx, py = A.org_y + (t / A.tiles_x) * A.tile_h + ly;
 	o  = A.compact ? (k * A.tile_h + ly) * A.tile_w + lx : py * A.img_w + px;
 	return px < A.img_w && py < A.img_h;
 }
@@ -918,7 +919,7 @@ __device__ __forceinline__ bool block_pixel(const RayMarchArgs &A, uint32_t b, u
 	const uint32_t k = b / A.blocks_per_tile, sb = b % A.blocks_per_tile;
 	const uint32_t t  = A.tile_first + k * A.tile_stride;
 	const uint32_t lx = (sb % A.blocks_per_tile_x) * 16 + bx, ly = (sb / A.blocks_per_tile_x) * 16 + by;
-	px = (t % A.tiles_x) * A.tile_w + lx, py = (t / A.tiles_x) * A.tile_h + ly;
+	px = A.org_x + (t % A.tiles_x) * A.tile_w + lx, py = A.org_y + (t / A.tiles_x) * A.tile_h + ly;
 	o  = A.compact ? (k * A.tile_h + ly) * A.tile_w + lx : py * A.img_w + px;
 	return px < A.img_w && py < A.img_h;
 }

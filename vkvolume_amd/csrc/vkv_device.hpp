@@ -228,6 +228,7 @@ struct vkv_ctx
 	{
 		const void *target;
 		uint32_t    img_w, img_h, tile_w, tile_h, first, stride, count;
+		uint32_t    org_x, org_y, tiles_x;        // the schedule's tile rectangle as the launcher sees it (pixels of its first tile, tile columns)
 		uint32_t *  d_cost, *d_order;
 		bool        has_cost;        // a frame has been rendered into this target with the cost buffer attached
 		uint32_t    frames;          // frames rendered into this target so far (costs are measured and sorted every few frames)

@@ -19,7 +19,7 @@ EXPORTS = [
     "vkv_packed_volume_bytes", "vkv_pack_volume", "vkv_transfer_function_bits", "vkv_transfer_function_tables",
     "vkv_occupied_voxel_count", "vkv_load_header", "vkv_load_data", "vkv_convert_volume", "vkv_gather_tiles", "vkv_assemble_frame",
     "vkv_assemble_frames", "vkv_get_tuning", "vkv_set_tuning", "vkv_prepare_render", "vkv_register_target", "vkv_forget_target",
-    "vkv_release_stream", "vkv_trim", "vkv_release_captured",
+    "vkv_release_stream", "vkv_trim", "vkv_release_captured", "vkv_screen_tile_rect",
 ]
 # include/vkvolume_amd_debug.h (diagnostics: tools/ and the exhaustive numerics tests)
 DEBUG_EXPORTS = ["vkv_debug_trace", "vkv_debug_tile_orders", "vkv_debug_check"]
@@ -67,9 +67,10 @@ def load():
     L.vkv_render.argtypes = [vp, P(abi.RenderParams), vp]
     L.vkv_render_batch.argtypes = [vp, P(abi.RenderParams), C.c_uint32, vp]
     L.vkv_gather_tiles.argtypes = [vp, vp, vp, C.c_size_t, i32, vp, vp]
-    L.vkv_assemble_frame.argtypes = [vp, vp, vp, vp] + [C.c_uint32] * 8 + [i32, vp, vp]
-    L.vkv_scatter_tiles.argtypes = [vp, vp, vp, u32, u32, u32, u32, u32, u32, u32, vp]
-    L.vkv_assemble_frames.argtypes = [vp, vp, vp, P(vp)] + [u32] * 9 + [i32, vp, vp]
+    L.vkv_assemble_frame.argtypes = [vp, vp, vp, vp, u32, u32, u32, u32, P(abi.TileRect), u32, u32, u32, i32, vp, vp]
+    L.vkv_scatter_tiles.argtypes = [vp, vp, vp, u32, u32, u32, u32, P(abi.TileRect), u32, u32, u32, vp]
+    L.vkv_assemble_frames.argtypes = [vp, vp, vp, P(vp), u32, u32, u32, u32, u32, P(abi.TileRect), u32, u32, u32, i32, P(i32), vp, vp]
+    L.vkv_screen_tile_rect.argtypes = [P(abi.RayCastUniform), P(abi.RayGen), u32, u32, u32, u32, u32, P(abi.TileRect)]
     L.vkv_get_tuning.argtypes = [vp, P(abi.Tuning)]
     L.vkv_set_tuning.argtypes = [vp, P(abi.Tuning)]
     L.vkv_prepare_render.argtypes = [vp, P(abi.RenderParams), u32, vp]
@@ -155,19 +156,22 @@ class Context:
     def gather_tiles(self, d_tiles, d_gathered, bytes_per_rank, root, nccl_comm, stream=0):
         self.check(self._lib.vkv_gather_tiles(self.handle, d_tiles, d_gathered, bytes_per_rank, root, nccl_comm, stream))
 
-    def assemble_frame(self, d_tiles, d_gathered, d_image, image_size, tile_size, n_ranks, rank, tiles_per_rank, bytes_per_pixel, root, nccl_comm,
-                       stream=0):
-        """vkv_assemble_frame: ncclGather of the compact tile buffers to `root` + de-interleave there, on `stream`."""
+    def assemble_frame(self, d_tiles, d_gathered, d_image, image_size, tile_size, n_ranks, rank, bytes_per_pixel, root, nccl_comm, stream=0, rect=None):
+        """vkv_assemble_frame: ncclGather of the compact tile buffers (the tiles of `rect`, a TileRect; None = the whole image) to `root` +
+        de-interleave there, on `stream`."""
         self.check(self._lib.vkv_assemble_frame(self.handle, d_tiles, d_gathered, d_image, image_size[0], image_size[1], tile_size[0], tile_size[1],
-                                                n_ranks, rank, tiles_per_rank, bytes_per_pixel, root, nccl_comm, stream))
+                                                None if rect is None else C.byref(rect), n_ranks, rank, bytes_per_pixel, root, nccl_comm, stream))
 
-    def assemble_frames(self, d_tiles, d_gathered, d_images, n_frames, image_size, tile_size, n_ranks, rank, tiles_per_rank, bytes_per_pixel, root,
-                        nccl_comm, stream=0):
-        """vkv_assemble_frames: ONE ncclGather for the [frame][tiles] block of a whole launch + one de-interleave kernel on the root
-        (d_images: the root's n_frames image pointers; None elsewhere)."""
+    def assemble_frames(self, d_tiles, d_gathered, d_images, n_frames, image_size, tile_size, n_ranks, rank, bytes_per_pixel, root, nccl_comm, stream=0,
+                        rects=None, roots=None):
+        """vkv_assemble_frames: the exchange of a whole launch - frame f with tile rectangle rects[f] (None: the whole image) to its owner
+        roots[f] (None: all to `root`, ONE ncclGather of the launch's block; else one group of gathers) + one de-interleave kernel on every owner
+        (d_images: n_frames image pointers, entry f read on the owner of frame f only; None on ranks that own nothing)."""
         arr = (C.c_void_p * n_frames)(*d_images) if d_images is not None else None
+        rarr = (abi.TileRect * n_frames)(*rects) if rects is not None else None
+        oarr = (C.c_int32 * n_frames)(*roots) if roots is not None else None
         self.check(self._lib.vkv_assemble_frames(self.handle, d_tiles, d_gathered, arr, n_frames, image_size[0], image_size[1], tile_size[0], tile_size[1],
-                                                 n_ranks, rank, tiles_per_rank, bytes_per_pixel, root, nccl_comm, stream))
+                                                 rarr, n_ranks, rank, bytes_per_pixel, root, oarr, nccl_comm, stream))
 
     # ---- set-up calls ----
     def get_tuning(self):
@@ -210,9 +214,9 @@ class Context:
         """Like render() but returns the status code instead of raising (error-path tests)."""
         return self._lib.vkv_render(self.handle, C.byref(params), stream)
 
-    def scatter_tiles(self, d_gathered, d_image, image_size, tile_size, n_ranks, tiles_per_rank, bytes_per_pixel, stream=0):
+    def scatter_tiles(self, d_gathered, d_image, image_size, tile_size, n_ranks, rank_stride_tiles, bytes_per_pixel, stream=0, rect=None):
         self.check(self._lib.vkv_scatter_tiles(self.handle, d_gathered, d_image, image_size[0], image_size[1], tile_size[0],
-                                               tile_size[1], n_ranks, tiles_per_rank, bytes_per_pixel, stream))
+                                               tile_size[1], None if rect is None else C.byref(rect), n_ranks, rank_stride_tiles, bytes_per_pixel, stream))
 
     def synth_volume(self, d_volume, extent, kind, seed, stream=0):
         self.check(self._lib.vkv_synth_volume(self.handle, d_volume, extent, kind, seed, stream))
@@ -267,6 +271,15 @@ def build_uniforms(view, proj, node_transform, image_transform, clip_distance, i
     if rc != 0:
         raise VkvError(rc, "vkv_build_uniforms")
     return cam, rc_, rg
+
+
+def screen_tile_rect(ray_cast, ray_gen, image_size, tile_size=(16, 16), align_tiles=1):
+    """vkv_screen_tile_rect: the tile rectangle the fragments of a frame with these uniforms can lie in (pure CPU; every rank derives the same)"""
+    out = abi.TileRect()
+    rc = load().vkv_screen_tile_rect(C.byref(ray_cast), C.byref(ray_gen), image_size[0], image_size[1], tile_size[0], tile_size[1], align_tiles, C.byref(out))
+    if rc != 0:
+        raise VkvError(rc, "vkv_screen_tile_rect")
+    return out
 
 
 def load_header(path):

@@ -3,28 +3,58 @@
 Rays are independent, so the path shards by screen tiles with the volume replicated per GPU and exactly one exchange
 step: every rank's compact tile buffer is gathered to the frame's owner (RCCL gather over xGMI = 7 concurrent point-to-point
 transfers, one per link into the root), where ``vkv_scatter_tiles`` de-interleaves them into the frame.  The owner can rotate
-over the ranks frame by frame (``any_root``), which spreads the inbound traffic and the de-interleave over all GPUs.
+over the ranks launch by launch (``any_root``) or - round 6 - the frames of ONE launch can have different owners (``roots``): every
+GPU then receives at the same time over its own inbound links.
 
 Tiles are dealt round-robin (tile t -> rank t mod world) because empty-space skipping makes per-pixel cost vary by
 more than 10x; contiguous strips would not balance.
+
+Round 6: only the tiles a frame HAS are scheduled and exchanged.  ``lib.screen_tile_rect`` (vkv_screen_tile_rect) derives from the uniforms
+alone the tile rectangle the clipped box projects into - the reference's rasteriser only shades fragments of the box's faces
+(src/volume_render_subpass.cpp:262-293) - every rank derives the same rectangle, tiles are numbered inside it, and the de-interleave clears the
+rest of the image.  A frame with rectangle R moves ceil(|R| / world) tiles per rank instead of ceil(all tiles / world).
 """
 import numpy as np
 
 from . import abi
 
 
+def tiles_per_rank(rect, world):
+    """tiles a rank holds of a frame whose scheduled tiles are those of `rect` (ragged deals round up: the fixed size of the collective)"""
+    return (rect.w * rect.h + world - 1) // world
+
+
+def launch_layout(rects, world):
+    """[frame][tiles] block of one launch: (tiles per rank of every frame, tile offset of every frame inside a rank's block, the block's tiles)"""
+    tpr = [tiles_per_rank(r, world) for r in rects]
+    off = [0]
+    for n in tpr:
+        off.append(off[-1] + n)
+    return tpr, off[:-1], off[-1]
+
+
+def rect_ray_count(rect, rank, world, frame_size, tile):
+    """in-image pixels of rank's tiles of `rect` (edge tiles of the image are partial)"""
+    fw, fh = frame_size
+    t = np.arange(rank, rect.w * rect.h, world, dtype=np.int64)
+    x0, y0 = (rect.x0 + t % rect.w) * tile, (rect.y0 + t // rect.w) * tile
+    return int((np.minimum(tile, fw - x0) * np.minimum(tile, fh - y0)).sum())
+
+
 class TileGather:
-    """Double-buffered gather of per-rank compact tile buffers to rank 0, overlapping the collective of frame k with the
-    render of frame k+1.  Works with any torch.distributed backend (nccl == RCCL on ROCm; gloo in the CPU tests)."""
+    """Double-buffered gather of per-rank compact tile buffers to the frame's owner, overlapping the collective of frame k with the
+    render of frame k+1.  Works with any torch.distributed backend (nccl == RCCL on ROCm; gloo in the CPU tests).  ``rect`` (a TileRect) on
+    start(): only the rectangle's tiles travel; the buffers are sized for the whole image."""
 
     def __init__(self, dist, rank, world, frame_size, tile=16, bytes_per_pixel=4, device="cuda", n_buffers=2, any_root=False):
         import torch
         self.dist, self.rank, self.world = dist, rank, world
         self.frame_size, self.tile, self.bpp = frame_size, tile, bytes_per_pixel
         fw, fh = frame_size
-        self.tiles_x, self.tiles_y = (fw + tile - 1) // tile, (fh + tile - 1) // tile
+        self.whole = abi.whole_image_rect(fw, fh, tile, tile)
+        self.tiles_x, self.tiles_y = self.whole.w, self.whole.h
         self.total_tiles = self.tiles_x * self.tiles_y
-        self.tiles_per_rank = (self.total_tiles + world - 1) // world
+        self.tiles_per_rank = (self.total_tiles + world - 1) // world  # capacity: a whole image's share
         self.schedule = abi.full_frame_tiles(fw, fh, tile, tile, rank, world, compact=True)
         n = self.tiles_per_rank * tile * tile
         self.buffers = [torch.zeros((n, bytes_per_pixel), dtype=torch.uint8, device=device) for _ in range(n_buffers)]
@@ -37,26 +67,27 @@ class TileGather:
         self.works = [None] * n_buffers
         self.roots = [0] * n_buffers
 
-    def my_ray_count(self):
-        """in-image pixels of this rank's tiles (edge tiles are partial)"""
+    def rect_schedule(self, rect=None):
+        """this rank's VkvTileSchedule of a frame whose scheduled tiles are those of `rect` (None: the whole image)"""
         fw, fh = self.frame_size
-        n = 0
-        for k in range(self.schedule.tile_count):
-            t = self.schedule.tile_first + k * self.schedule.tile_stride
-            x0, y0 = (t % self.tiles_x) * self.tile, (t // self.tiles_x) * self.tile
-            n += min(self.tile, fw - x0) * min(self.tile, fh - y0)
-        return n
+        return abi.full_frame_tiles(fw, fh, self.tile, self.tile, self.rank, self.world, compact=True, rect=rect)
 
-    def start(self, b, root=0):
-        """launch the gather of buffer b to `root` (asynchronous); every rank must pass the same root"""
+    def my_ray_count(self, rect=None):
+        """in-image pixels of this rank's tiles (edge tiles are partial)"""
+        return rect_ray_count(rect if rect is not None and rect.w and rect.h else self.whole, self.rank, self.world, self.frame_size, self.tile)
+
+    def start(self, b, root=0, rect=None):
+        """launch the gather of buffer b to `root` (asynchronous); every rank must pass the same root and rectangle"""
         if root != 0 and not self.any_root:
             raise ValueError("TileGather was created for rank 0 as the only frame owner")
-        gl = [self.flat[b][r] for r in range(self.world)] if self.rank == root else None
+        n = tiles_per_rank(rect if rect is not None and rect.w and rect.h else self.whole, self.world) * self.tile * self.tile
+        gl = [self.flat[b][r, :n] for r in range(self.world)] if self.rank == root else None
         self.roots[b] = root
-        self.works[b] = self.dist.gather(self.buffers[b], gl, dst=root, async_op=True)
+        self.works[b] = self.dist.gather(self.buffers[b][:n], gl, dst=root, async_op=True)
 
     def finish(self, b):
-        """wait for buffer b's gather; returns the root's [world, n, bpp] tensor (None on the other ranks / if nothing pending)"""
+        """wait for buffer b's gather; returns the root's [world, n, bpp] tensor (None on the other ranks / if nothing pending): rank r's
+        tiles start at r * tiles_per_rank tiles (the capacity), whatever the rectangle"""
         if self.works[b] is None:
             return None
         self.works[b].wait()
@@ -65,10 +96,11 @@ class TileGather:
 
 
 class BatchTileGather(TileGather):
-    """The exchange of a whole vkv_render_batch launch in ONE collective: every rank sends the compact tile buffers of the launch's
-    frames as one block [frames][tiles_per_rank x tile pixels]; the owner of the launch receives [world][frames][...] and
-    de-interleaves frame f with vkv_scatter_tiles on the block's f-th slice (rank stride = frames x tiles_per_rank tiles).  One
-    gather and one host call per launch instead of one per frame."""
+    """The exchange of a whole vkv_render_batch launch through torch.distributed.  A launch's frames have their own tile rectangles
+    (``rects``): a rank's block is [frame f][tiles_per_rank(rects[f]) tiles] back to back (``launch_layout``), rendered straight into
+    set b at those offsets (``frame_pointer``).  One owner for the launch (``roots`` None): ONE gather of the block, the owner holds
+    [rank][block] and de-interleaves frame f with vkv_scatter_tiles on the block's f-th slice (rank stride = the block's tiles).  Owners
+    spread over the launch's frames (``roots``): one gather per frame to its owner, which holds [rank][tiles of the frame]."""
 
     def __init__(self, dist, rank, world, frame_size, tile=16, bytes_per_pixel=4, device="cuda", frames=8, n_sets=2, any_root=False, host_staging=False):
         import torch
@@ -76,47 +108,78 @@ class BatchTileGather(TileGather):
         # host_staging: the backend cannot gather device tensors (gloo): the block goes through host memory - a functional path for tests
         # of the N > 1 orchestration (bench.py --backend gloo), not a data path anybody should measure
         self.host_staging, self._host = host_staging, [None] * n_sets
-        n = self.tiles_per_rank * tile * tile
         self.frames = frames
-        self.sets = [torch.zeros((frames, n, bytes_per_pixel), dtype=torch.uint8, device=device) for _ in range(n_sets)]
-        self.buffers = [s[j] for s in self.sets for j in range(frames)]  # buffer of frame j of set b: buffers[b * frames + j]
+        self.tile_bytes = tile * tile * bytes_per_pixel
+        cap = frames * self.tiles_per_rank * self.tile_bytes  # bytes of a rank's block when every frame is a whole image
+        self.sets = [torch.zeros(cap, dtype=torch.uint8, device=device) for _ in range(n_sets)]
         self.flat = None
         if rank == 0 or any_root:
-            self.flat = [torch.zeros((world, frames, n, bytes_per_pixel), dtype=torch.uint8, device=device) for _ in range(n_sets)]
-        self.works, self.roots, self.counts = [None] * n_sets, [0] * n_sets, [0] * n_sets
+            self.flat = [torch.zeros(world * cap, dtype=torch.uint8, device=device) for _ in range(n_sets)]
+        self.works, self.pending = [None] * n_sets, [None] * n_sets
 
-    def start(self, b, root=0, n_frames=None):
-        """gather the first n_frames frames of set b to `root` (asynchronous); every rank passes the same root and count"""
-        if root != 0 and not self.any_root:
+    def frame_pointer(self, b, tile_offset):
+        """device pointer of the compact buffer of the frame that starts `tile_offset` tiles into this rank's block of set b"""
+        return self.sets[b].data_ptr() + tile_offset * self.tile_bytes
+
+    def start(self, b, root=0, rects=None, roots=None, n_frames=None):
+        """gather the launch rendered into set b (asynchronous): frames with tile rectangles `rects` (None: n_frames whole images) to `root`, or
+        frame f to roots[f]; every rank passes the same arguments"""
+        import torch
+        if rects is None:
+            rects = [self.whole] * (self.frames if n_frames is None else n_frames)
+        owners = [root] * len(rects) if roots is None else list(roots)
+        if any(o != 0 for o in owners) and not self.any_root:
             raise ValueError("BatchTileGather was created for rank 0 as the only frame owner")
-        n = self.frames if n_frames is None else n_frames
-        self.roots[b], self.counts[b] = root, n
+        tpr, off, total = launch_layout(rects, self.world)
+        tb, W = self.tile_bytes, self.world
+        one = roots is None  # one gather of the whole block, or one gather per frame (the same rule as vkv_assemble_frames)
+        self.pending[b] = (rects, owners, tpr, off, total, one)
+        works = []
+        if one:
+            spans = [(owners[0], 0, total)]  # (owner, first tile of the span in a rank's block, tiles)
+        else:
+            spans = [(owners[f], off[f], tpr[f]) for f in range(len(rects))]
         if self.host_staging:
-            import torch
-            mine = self.sets[b][:n].cpu()  # (waits for the render on the current stream)
-            gl = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == root else None
-            self._host[b] = gl
-            self.works[b] = self.dist.gather(mine, gl, dst=root, async_op=True)
-            return
-        gl = [self.flat[b][r, :n] for r in range(self.world)] if self.rank == root else None
-        self.works[b] = self.dist.gather(self.sets[b][:n], gl, dst=root, async_op=True)
+            self._host[b] = []
+        for owner, o, n in spans:
+            mine = self.sets[b][o * tb:(o + n) * tb]
+            # the owner's receive area: [rank][span] - at tile W * o of flat[b] (one owner: o = 0, the whole block per rank)
+            dst = self.flat[b][W * o * tb:W * (o + n) * tb].view(W, n * tb) if self.rank == owner else None
+            if self.host_staging:
+                mine_h = mine.cpu()  # (waits for the render on the current stream)
+                gl = [torch.empty_like(mine_h) for _ in range(W)] if self.rank == owner else None
+                self._host[b].append((dst, gl))
+                works.append(self.dist.gather(mine_h, gl, dst=owner, async_op=True))
+            else:
+                gl = [dst[r] for r in range(W)] if self.rank == owner else None
+                works.append(self.dist.gather(mine, gl, dst=owner, async_op=True))
+        self.works[b] = works
 
     def finish(self, b):
-        """wait for set b's gather; on its owner returns (flat [world, frames, n, bpp], number of frames), elsewhere None"""
+        """wait for set b's exchange; returns the frames this rank owns as a list of (frame index, source pointer, rank stride in tiles, rect)
+        for vkv_scatter_tiles (empty on ranks that own nothing), or None if nothing was pending"""
         if self.works[b] is None:
             return None
-        self.works[b].wait()
+        for w in self.works[b]:
+            w.wait()
         self.works[b] = None
-        if self.host_staging and self.rank == self.roots[b]:
-            for r in range(self.world):
-                self.flat[b][r, :self.counts[b]].copy_(self._host[b][r])
+        rects, owners, tpr, off, total, one = self.pending[b]
+        if self.host_staging:
+            for dst, gl in self._host[b]:
+                if dst is not None:
+                    for r in range(self.world):
+                        dst[r].copy_(gl[r])
             self._host[b] = None
-        return (self.flat[b], self.counts[b]) if self.rank == self.roots[b] else None
-
-    def frame_source(self, flat, f):
-        """(device pointer, rank stride in tiles) that make vkv_scatter_tiles read frame f of a gathered launch"""
-        per_rank_bytes = self.tiles_per_rank * self.tile * self.tile * self.bpp
-        return flat.data_ptr() + f * per_rank_bytes, self.frames * self.tiles_per_rank
+        tb, W, base = self.tile_bytes, self.world, self.flat[b].data_ptr() if self.flat is not None else 0
+        out = []
+        for f, r in enumerate(rects):
+            if owners[f] != self.rank:
+                continue
+            if one:
+                out.append((f, base + off[f] * tb, total, r))  # [rank][block]: frame f starts off[f] tiles into every rank's block
+            else:
+                out.append((f, base + W * off[f] * tb, tpr[f], r))  # [rank][tiles of frame f] at tile W * off[f]
+        return out
 
 
 class NativeExchange:
@@ -131,7 +194,8 @@ class NativeExchange:
         self.ctx, self.rank, self.world = ctx, rank, world
         self.frame_size, self.tile, self.bpp = frame_size, tile, bytes_per_pixel
         fw, fh = frame_size
-        self.tiles_x, self.tiles_y = (fw + tile - 1) // tile, (fh + tile - 1) // tile
+        self.whole = abi.whole_image_rect(fw, fh, tile, tile)
+        self.tiles_x, self.tiles_y = self.whole.w, self.whole.h
         self.total_tiles = self.tiles_x * self.tiles_y
         self.tiles_per_rank = (self.total_tiles + world - 1) // world
         self.schedule = abi.full_frame_tiles(fw, fh, tile, tile, rank, world, compact=True)
@@ -164,9 +228,10 @@ class NativeExchange:
             raise RuntimeError("ncclCommInitRank failed: %d" % rc)
 
     my_ray_count = TileGather.my_ray_count
+    rect_schedule = TileGather.rect_schedule
 
-    def assemble(self, b, root, stream, scatter_stream=None):
-        """enqueue gather + de-interleave of buffer b on `stream` (a torch stream); every rank must pass the same root.
+    def assemble(self, b, root, stream, scatter_stream=None, rect=None):
+        """enqueue gather + de-interleave of buffer b on `stream` (a torch stream); every rank must pass the same root and rectangle.
         With ``scatter_stream`` the de-interleave runs there, behind an event recorded after the gather (the gather of the next frame
         then does not queue behind this frame's de-interleave).  Returns the stream whose completion frees buffer b."""
         if root != 0 and not self.any_root:
@@ -175,10 +240,11 @@ class NativeExchange:
         if scatter_stream is None:
             self.ctx.assemble_frame(self.buffers[b].data_ptr(), self.flat[b].data_ptr() if is_root else None,
                                     self.images[b].data_ptr() if is_root else None, self.frame_size, (self.tile, self.tile), self.world, self.rank,
-                                    self.tiles_per_rank, self.bpp, root, self._comm.value, stream.cuda_stream)
+                                    self.bpp, root, self._comm.value, stream.cuda_stream, rect=rect)
             return stream
         import torch
-        self.ctx.gather_tiles(self.buffers[b].data_ptr(), self.flat[b].data_ptr() if is_root else None, self.buffers[b].numel(), root,
+        tpr = tiles_per_rank(rect if rect is not None and rect.w and rect.h else self.whole, self.world)
+        self.ctx.gather_tiles(self.buffers[b].data_ptr(), self.flat[b].data_ptr() if is_root else None, tpr * self.tile * self.tile * self.bpp, root,
                               self._comm.value, stream.cuda_stream)
         if not is_root:
             return stream
@@ -186,7 +252,7 @@ class NativeExchange:
         gathered.record(stream)
         scatter_stream.wait_event(gathered)
         self.ctx.scatter_tiles(self.flat[b].data_ptr(), self.images[b].data_ptr(), self.frame_size, (self.tile, self.tile), self.world,
-                               self.tiles_per_rank, self.bpp, scatter_stream.cuda_stream)
+                               tpr, self.bpp, scatter_stream.cuda_stream, rect=rect)
         return scatter_stream
 
     def comm_count(self):
@@ -208,40 +274,48 @@ class NativeExchange:
 
 class NativeBatchExchange(NativeExchange):
     """The exchange of a whole vkv_render_batch launch through the C ABI: ``vkv_assemble_frames`` = ONE ``ncclGather`` of the launch's
-    [frame][tiles] block to the launch's owner + ONE de-interleave kernel there, enqueued on a HIP stream; the same launches and the
-    same buffer sets as BatchTileGather, without torch.distributed on the data path."""
+    [frame][tiles] block to the launch's owner (or one group of gathers, frame f to roots[f]) + ONE de-interleave kernel on every owner,
+    enqueued on a HIP stream; the same launches, rectangles and buffer sets as BatchTileGather, without torch.distributed on the data path."""
 
     def __init__(self, ctx, dist, rank, world, frame_size, tile=16, bytes_per_pixel=4, frames=8, n_sets=2, any_root=False, rccl_path=None):
         import torch
         super().__init__(ctx, dist, rank, world, frame_size, tile, bytes_per_pixel, n_buffers=0, any_root=any_root, rccl_path=rccl_path)
         fw, fh = frame_size
-        n = self.tiles_per_rank * tile * tile
         self.frames = frames
-        self.sets = [torch.zeros((frames, n, bytes_per_pixel), dtype=torch.uint8, device="cuda") for _ in range(n_sets)]
-        self.buffers = [s[j] for s in self.sets for j in range(frames)]  # buffer of frame j of set b: buffers[b * frames + j]
+        self.tile_bytes = tile * tile * bytes_per_pixel
+        cap = frames * self.tiles_per_rank * self.tile_bytes
+        self.sets = [torch.zeros(cap, dtype=torch.uint8, device="cuda") for _ in range(n_sets)]
         own = rank == 0 or any_root
-        self.flat = [torch.zeros((world, frames, n, bytes_per_pixel), dtype=torch.uint8, device="cuda") for _ in range(n_sets)] if own else None
+        self.flat = [torch.zeros(world * cap, dtype=torch.uint8, device="cuda") for _ in range(n_sets)] if own else None
         self.images = [torch.zeros((fh, fw, bytes_per_pixel), dtype=torch.uint8, device="cuda") for _ in range(n_sets * frames)] if own else None
 
-    def assemble(self, b, root, n_frames, stream):
-        """enqueue the exchange of the first n_frames frames of buffer set b on `stream` (a torch stream): the images of the launch land
-        in images[b * frames + j] on `root`.  Every rank passes the same root and count."""
-        if root != 0 and not self.any_root:
+    frame_pointer = BatchTileGather.frame_pointer
+
+    def assemble(self, b, root, n_frames, stream, rects=None, roots=None):
+        """enqueue the exchange of the first n_frames frames of buffer set b on `stream` (a torch stream): the image of frame j lands in
+        images[b * frames + j] on its owner (`root`, or roots[j]).  Every rank passes the same arguments."""
+        owners = [root] * n_frames if roots is None else list(roots)
+        if any(o != 0 for o in owners) and not self.any_root:
             raise ValueError("NativeBatchExchange was created for rank 0 as the only frame owner")
-        is_root = self.rank == root
-        imgs = [self.images[b * self.frames + j].data_ptr() for j in range(n_frames)] if is_root else None
-        self.ctx.assemble_frames(self.sets[b].data_ptr(), self.flat[b].data_ptr() if is_root else None, imgs, n_frames, self.frame_size,
-                                 (self.tile, self.tile), self.world, self.rank, self.tiles_per_rank, self.bpp, root, self._comm.value, stream.cuda_stream)
+        mine = any(o == self.rank for o in owners)
+        imgs = [self.images[b * self.frames + j].data_ptr() if owners[j] == self.rank else None for j in range(n_frames)] if mine else None
+        self.ctx.assemble_frames(self.sets[b].data_ptr(), self.flat[b].data_ptr() if mine else None, imgs, n_frames, self.frame_size,
+                                 (self.tile, self.tile), self.world, self.rank, self.bpp, root, self._comm.value, stream.cuda_stream, rects=rects, roots=roots)
         return stream
 
 
-def deinterleave_reference(flat, frame_size, tile, world):
-    """numpy statement of vkv_scatter_tiles (tests only): flat[rank, k*tile*tile + ly*tile + lx, c] -> image[y, x, c]."""
+def deinterleave_reference(flat, frame_size, tile, world, rect=None):
+    """numpy statement of vkv_scatter_tiles (tests only): flat[rank, k*tile*tile + ly*tile + lx, c] -> image[y, x, c]; tiles numbered row-major
+    inside `rect` (None: the whole image), pixels outside it zero."""
     fw, fh = frame_size
-    tiles_x = (fw + tile - 1) // tile
+    if rect is None or not (rect.w and rect.h):
+        rect = abi.whole_image_rect(fw, fh, tile, tile)
     flat = np.asarray(flat)
     img = np.zeros((fh, fw, flat.shape[-1]), flat.dtype)
     y, x = np.mgrid[0:fh, 0:fw]
-    t = (y // tile) * tiles_x + (x // tile)
-    img[y, x] = flat[t % world, ((t // world) * tile + (y % tile)) * tile + (x % tile)]
+    tx, ty = x // tile - rect.x0, y // tile - rect.y0
+    inside = (tx >= 0) & (tx < rect.w) & (ty >= 0) & (ty < rect.h)
+    t = np.where(inside, ty * rect.w + tx, 0)
+    val = flat[t % world, ((t // world) * tile + (y % tile)) * tile + (x % tile)]
+    img[inside] = val[inside]
     return img
