@@ -135,7 +135,11 @@ if ROOT not in sys.path:
 
 from vkvolume_amd import abi, camera, lib, multigpu, volume as V  # noqa: E402
 
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r5_traffic.json")  # PMC-measured HBM bytes per launch (own rocprofv3 passes)
+def traffic_file(workload):
+    """PMC-measured HBM bytes per launch (own rocprofv3 passes, tools/collect_profiles.sh): one file per workload that has been profiled"""
+    return os.path.join(ROOT, "profiles", "r6_traffic.json" if workload == "c3" else "r6_%s_traffic.json" % workload)
+
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 WORKLOADS = {
@@ -212,12 +216,15 @@ def occupied_voxel_percent(ctx, v, tf):
     return 100.0 * float(count.item()) / float(v.extent.count)
 
 
-def cameras(v, aspect):
+def cameras(v, aspect, moving=0, step=1.0):
     """8 azimuths, elevation 20 deg, radius 1.5 x bounding-sphere radius of the scaled volume."""
     m = (v.node_transform.astype(np.float64).T @ v.image_transform.astype(np.float64).T)[:3, :3]
     half_diag = 0.5 * math.sqrt(sum(float(np.linalg.norm(m[:, i])) ** 2 for i in range(3)))
     radius = 1.5 * half_diag
     proj = camera.perspective_vulkan(60.0, aspect, 0.1, 1000.0)
+    if moving:
+        # a camera that moves: `moving` views one degree of orbit apart (a renderer's consecutive frames)
+        return [(camera.orbit_camera(step * i, 20.0, radius), proj) for i in range(moving)]
     return [(camera.orbit_camera(45.0 * i, 20.0, radius), proj) for i in range(N_VIEWS)]
 
 
@@ -248,6 +255,11 @@ def main():
     ap.add_argument("--frame-owner", default="rotate", choices=["rotate", "spread", "rank0"], help="N > 1: rank that assembles a launch's frames: launch l on rank l mod N "
                     "(rotate, default: the inbound xGMI links and the de-interleave of consecutive launches are disjoint), frame j of launch l on rank (l + j) mod N "
                     "(spread: every GPU receives at once; batch submission), or always rank 0")
+    ap.add_argument("--camera", default="static", choices=["static", "moving"], help="static (default): 8 orbit views 45 degrees apart, each render target showing one of "
+                    "them (the reference's benchmark also holds its camera still, src/volume_render.cpp:224-234); moving: every frame a new view, one degree of "
+                    "orbit from the last, the targets taking the frames in turn (what a renderer's swap chain sees)")
+    ap.add_argument("--camera-step", type=float, default=1.0, help="--camera moving: degrees of orbit between two frames")
+    ap.add_argument("--no-feedback", action="store_true", help="VkvTuning.feedback = 0: every frame starts its tiles centre-first, no start order from measured tile costs")
     ap.add_argument("--tile-rect", default="on", choices=["on", "off"], help="N > 1 / --virtual-rank / --force-gather: schedule and exchange only the tiles of each "
                     "frame's screen rectangle (vkv_screen_tile_rect: the clipped box's projection, derived by every rank from the uniforms; default) or every "
                     "tile of the frame (off: rounds 1-5)")
@@ -400,14 +412,36 @@ def main():
             out["c5_strong"] = brief(o2) if o2 is not None else tmp.get("c5")
         if o2 is not None or rank != 0:
             with_native(out["c5_strong"] if rank == 0 and o2 is not None else None, **{k: c5[k] for k in ("workload", "scaling", "skip", "tf", "no_ert")})
-    # N = 1: the literal 1024^3 of BASELINE.json's metric line on the same clock, and the integrator's two asymptotes
-    default_run = args.workload == "c3" and args.skip is None and args.tf == "app" and not args.no_ert and submit == "batch"
+    # N = 1, behind the headline (each a short block that can never cost it): the other single-GPU configurations of BASELINE.json on the same
+    # clock - the literal 1024^3 of the metric line, configs[1] (c2: 512^3, block ESS) and configs[3] (c4: 2048^3, anisotropic maps, 3840x2160,
+    # "the HBM-roofline run") -, the same submission with a camera that MOVES and with the start-order feedback off, and the integrator's asymptotes
+    default_run = args.workload == "c3" and args.skip is None and args.tf == "app" and not args.no_ert and submit == "batch" and args.camera == "static" and not args.no_feedback
     if world == 1 and not use_gather and not args.virtual_rank and (args.extras == "on" or (args.extras == "auto" and default_run)):
         short = dict(steps=min(args.steps, 16), warmup=min(args.warmup, 4), min_seconds=min(args.min_seconds, 0.5))
-        o3 = side_block("c3cube", out, workload="c3cube", **short)
-        if o3 is not None:
-            out["c3cube"] = brief(o3, ("single_frame",))
-            out["c3cube"]["note"] = "BASELINE.json's metric line names 1024^3: the same submission on the literal cube, a short block behind the headline"
+        for key, wl, note in (("c3cube", "c3cube", "BASELINE.json's metric line names 1024^3: the same submission on the literal cube"),
+                              ("c2", "c2", "BASELINE.json configs[1]: 512^3, occupancy-grid (block) ESS only"),
+                              ("c4", "c4", "BASELINE.json configs[3], 'the HBM-roofline run': 2048^3 (37 GB packed sampling image, 1.1 GiB of maps), "
+                                           "anisotropic Chebyshev maps, 3840x2160")):
+            o3 = side_block(key, out, workload=wl, **short)
+            if o3 is not None:
+                out[key] = brief(o3, ("single_frame",))
+                out[key]["note"] = note + "; a short block behind the headline, on the driver's clock"
+                for k in ("traffic", "traffic_over_algorithmic", "traffic_source", "wait_frac", "valu_issue_frac", "waves_per_simd", "valu_active_lanes"):
+                    if o3["roofline"].get(k) is not None:
+                        out[key][k] = o3["roofline"][k]
+        # a camera that moves (every frame a new view, one degree of orbit from the last, targets in turn) and the start-order feedback switched
+        # off, each measured here: the headline holds 8 views still, each target showing one of them - the best case for the feedback
+        cam = {}
+        for key, over in (("static", dict()), ("static_feedback_off", dict(no_feedback=True)), ("moving", dict(camera="moving")),
+                          ("moving_feedback_off", dict(camera="moving", no_feedback=True))):
+            o6 = side_block(key, cam, workload=args.workload, **over, **short)
+            if o6 is not None:
+                cam[key] = {"ms_per_step": o6["ms_per_step"], "frac": o6["roofline"]["frac"], "value": o6["value"], "steps": o6["steps"], "repeats": o6["repeats"]}
+        cam["what"] = ("the headline's submission with --camera moving (one degree of orbit per frame; a block sweeps its %d frames forwards, the next one backwards, so the "
+                       "camera never jumps; the targets take the frames in turn, a target's consecutive frames are up to %d degrees apart) and / or with "
+                       "VkvTuning.feedback = 0 (every frame starts its tiles centre-first); `static` = the headline's configuration once more in these short blocks "
+                       "(%d steps: a block's launches do not fill the headline's streams, compare the four with each other)" % (short["steps"], short["steps"] - 1, short["steps"]))
+        out["camera_and_feedback"] = cam
         asym = {}
         o4 = side_block("dense", asym, workload=args.workload, skip="none", no_ert=True, steps=min(args.steps, 8), warmup=2, min_seconds=min(args.min_seconds, 0.3))
         if o4 is not None:
@@ -419,13 +453,14 @@ def main():
                                   "volume_samples_per_s": o5["volume_samples_per_s"],
                                   "what": "the same box with every voxel empty and the 0 / 255 block map: a ray samples once, then walks one map cell per probe "
                                           "to the far side (1 B per probe)"}
-        # lanes per block execution and the gain if every block execution were full: from the oracle's event traces of the bench views, priced with the
-        # shipped loop's block costs (profiles/HISTORY.md section 5.2; tools/sim_traces.py + tools/sched_policies_sim.py) - a property of the frag's
-        # event sequences on this scene, not of a kernel build
-        asym["lane_occupancy"] = {"probe_block": 27, "sample_block": 28, "of": 64, "mixed_iterations": 0.62,
-                                  "source": "oracle event traces of the 8 bench views, profiles/HISTORY.md 5.2"}
-        asym["ideal_full_blocks"] = {"speedup": 2.11, "frac": round(2.11 * out["roofline"]["frac"], 4),
-                                     "what": "the unreachable ideal of lane = ray: every probe / sample block execution with 64 live lanes; the north-star 0.70 is above it"}
+        # lanes per VALU instruction of the headline's kernel, from the PMC passes behind roofline.traffic (digest-tied to the kernel sources like
+        # it): with every instruction on 64 lanes the same instruction stream would deliver 64 / valu_active_lanes times the events - the ceiling of
+        # lane = ray, unreachable (no re-packing scheme keeps the frag's event sequence for free, profiles/HISTORY.md section 5.2)
+        lanes = out["roofline"].get("valu_active_lanes")
+        if lanes:
+            asym["full_lanes"] = {"valu_active_lanes": lanes, "of": 64, "speedup": round(64.0 / lanes, 3), "frac": round(64.0 / lanes * out["roofline"]["frac"], 4),
+                                  "what": "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU of the headline's kernel (rocprofv3 --pmc, %s): the average number of live "
+                                          "lanes of a VALU instruction; frac = the headline's fraction if every instruction ran on 64" % os.path.basename(traffic_file(args.workload))}
         out["asymptotes"] = asym
     emit()
     if dist is not None:
@@ -436,6 +471,12 @@ def job(args, env):
     """One measurement (scene set-up, pre-pass, warm-up, the timed blocks) of args.workload on the ranks of `env`; returns the result
     line as a dict on rank 0, None elsewhere."""
     world, rank, local_rank, dist, ctx, use_gather, submit = (env[k] for k in ("world", "rank", "local_rank", "dist", "ctx", "use_gather", "submit"))
+    if getattr(args, "no_feedback", False) and ctx.get_tuning().feedback:
+        ctx.set_tuning(feedback=0)  # every frame starts its tiles centre-first
+        try:
+            return job(args, env)
+        finally:
+            ctx.set_tuning(feedback=1)
     v, tf, frame, skip = build_scene(ctx, args.workload, args.tf, empty=getattr(args, "empty_volume", False))
     if args.skip is not None:
         skip = {"none": abi.SKIP_NONE, "block": abi.SKIP_BLOCK, "distance": abi.SKIP_DISTANCE, "anisotropic": abi.SKIP_ANISOTROPIC_DISTANCE}[args.skip]
@@ -444,7 +485,18 @@ def job(args, env):
     scaling = args.scaling or WORKLOADS[args.workload][6]
     sx, sy = GRID[world] if scaling == "weak" else (1, 1)
     fw, fh = frame[0] * sx, frame[1] * sy
-    views = cameras(v, frame[0] / frame[1])  # the SAME frustum for every N
+    # --camera moving: every frame of a block is a new view, one degree of orbit from the last (blocks sweep forwards and backwards in turn, so the
+    # camera never jumps and every block renders the same views); the default holds 8 views still, each target showing one of them
+    moving = getattr(args, "camera", "static") == "moving"
+    views = cameras(v, frame[0] / frame[1], max(args.steps, args.warmup) if moving else 0, getattr(args, "camera_step", 1.0))  # the SAME frustum for every N
+    n_views = len(views)
+    direction = [0]  # moving camera: 0 = this block sweeps forwards, 1 = backwards
+
+    def vidx(k):
+        """view of step k of the current block"""
+        if not moving:
+            return k % n_views
+        return k if direction[0] == 0 else args.steps - 1 - k
     opts = abi.RenderOptions(skipping_type=skip, clip_distance=1.0, early_ray_termination=not args.no_ert)
     sp = V.VolumeRenderSubpass(ctx, v, opts, (fw, fh))
     virtual = None
@@ -535,7 +587,7 @@ def job(args, env):
     if compact:
         rays_v = [multigpu.rect_ray_count(r, my_rank, n_ranks, (fw, fh), TILE) for r in rects]
     else:
-        rays_v = [fw * fh] * N_VIEWS
+        rays_v = [fw * fh] * n_views
     # what the exchange moves: ceil(tiles of the view's rectangle / N) tiles of RGBA8 from every rank to the frame's owner
     exchange_bytes_v = [multigpu.tiles_per_rank(r, n_ranks) * TILE * TILE * B_OUT for r in rects]
     exchange_bytes_whole = multigpu.tiles_per_rank(whole_rect, n_ranks) * TILE * TILE * B_OUT
@@ -551,12 +603,18 @@ def job(args, env):
     # algorithmic bytes of one frame (this rank's part): 8 B per trilinear footprint of the volume, 8 more for the gradient map's when the
     # transfer function has a gradient term, 1 B per distance probe
     b_sample = 16 if tf.use_gradient else 8
-    frame_bytes = [n_vs[i] * b_sample + n_ds[i] * 1 + rays_v[i] * B_OUT for i in range(N_VIEWS)]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(max(fif, nbs) - 1)]
+    frame_bytes = [n_vs[i] * b_sample + n_ds[i] * 1 + rays_v[i] * B_OUT for i in range(n_views)]
+    # the HIP streams live as long as the process (one pool for the headline and its side blocks: a stream a context has seen keeps a scratch block)
+    pool = env.setdefault("streams", [])
+    while len(pool) < max(fif, nbs) - 1:
+        pool.append(torch.cuda.Stream())
+    streams = [torch.cuda.current_stream()] + pool[:max(fif, nbs) - 1]
     # the exchange streams get the higher priority: their small kernels (RCCL's gather, the de-interleave) must not queue behind the render
     # workgroups of the next frames (native exchange with a one-rank group: 0.25 -> 0.19 ms per step)
-    side = torch.cuda.Stream(priority=-1) if gather else None
-    xchg = torch.cuda.Stream(priority=-1) if gather else None  # native exchange: RCCL's gather here, the de-interleave on `side`
+    if gather and "side" not in env:
+        env["side"], env["xchg"] = torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1)
+    side = env["side"] if gather else None
+    xchg = env["xchg"] if gather else None  # native exchange: RCCL's gather here, the de-interleave on `side`
     freed = [None] * (nsets if batch_gather else nbuf)
     launches = []  # (start event, stop event, algorithmic bytes) of the timed launches of the last block
     phases = []  # gather path, launches this rank owns: (render start, render end, gathered or None, de-interleaved) events
@@ -582,11 +640,11 @@ def job(args, env):
     launch_cache = {}
 
     def launch_params(k, n, slot, depth):
-        key = (k % N_VIEWS, n, slot, depth)
+        idx = tuple(vidx(k + j) for j in range(n))
+        key = (idx, slot, depth)
         hit = launch_cache.get(key)
         if hit is not None:
             return hit
-        idx = [(k + j) % N_VIEWS for j in range(n)]
         rl = [rects[i] for i in idx]
         off = multigpu.launch_layout(rl, world)[1] if batch_gather else None
         plist = []
@@ -602,17 +660,19 @@ def job(args, env):
         return launch_cache[key]
 
     if submit == "batch":
-        for n_steps in (args.warmup, args.steps):
+        for n_steps, rev in ((args.warmup, 0), (args.steps, 0), (args.steps, 1)):
+            direction[0] = rev if moving else 0
             for k, n, _, slot, _, _ in plan(n_steps):
                 launch_params(k, n, slot, False)
                 if want_depth:
                     launch_params(k, n, slot, True)
+        direction[0] = 0
     else:
         for j, t in enumerate(bufs):
-            register(t.data_ptr(), j % N_VIEWS)
+            register(t.data_ptr(), j % n_views)
     torch.cuda.synchronize()
 
-    last_slot, last_owner = [0], [0]
+    last_slot, last_owner, last_view = [0], [0], [0]
     with_depth = [False]
     native = gather is not None and args.exchange == "native"
 
@@ -620,7 +680,7 @@ def job(args, env):
         for k, n, si, slot, owner, roots in plan(n_steps):
             st = streams[si]  # stream of this launch
             plist, rl = launch_params(k, n, slot, with_depth[0])
-            last_slot[0] = slot * fpl + n - 1  # output buffer of the block's last step (--verify)
+            last_slot[0], last_view[0] = slot * fpl + n - 1, vidx(k + n - 1)  # output buffer and view of the block's last step (--verify)
             mine = (rank in roots) if roots else (rank == owner)  # this rank assembles a frame of the launch
             with torch.cuda.stream(st):
                 if gather and freed[slot] is not None:
@@ -634,7 +694,7 @@ def job(args, env):
                     ctx.render_batch(plist, st.cuda_stream)
                 if timed:
                     e1.record(st)
-                    launches.append((e0, e1, sum(frame_bytes[(k + j) % N_VIEWS] for j in range(n)), n))
+                    launches.append((e0, e1, sum(frame_bytes[vidx(k + j)] for j in range(n)), n))
                 if gather and native:
                     rendered = torch.cuda.Event()
                     rendered.record(st)
@@ -683,20 +743,21 @@ def job(args, env):
                 if ev:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(st)
-                sp.draw(params[k % N_VIEWS], rgba8=bufs[b])
+                sp.draw(params[vidx(k)], rgba8=bufs[b])
+                last_view[0] = vidx(k)
                 if ev:
                     e1.record(st)
-                    launches.append((e0, e1, frame_bytes[k % N_VIEWS], 1))
+                    launches.append((e0, e1, frame_bytes[vidx(k)], 1))
                 if gather and native:
                     rendered = torch.cuda.Event()
                     rendered.record(st)
                 elif gather:
                     # RCCL gather of frame k (ordered after the render) overlaps the renders of the next frames
-                    gather.start(b, k % world if rotate else 0, rects[k % N_VIEWS])
+                    gather.start(b, k % world if rotate else 0, rects[vidx(k)])
             if gather and native:
                 # gather + de-interleave of frame k on the assembly stream, behind its render: nothing waits on the host
                 xchg.wait_event(rendered)
-                last = gather.assemble(b, k % world if rotate else 0, xchg, side, rect=rects[k % N_VIEWS])
+                last = gather.assemble(b, k % world if rotate else 0, xchg, side, rect=rects[vidx(k)])
                 freed[b] = torch.cuda.Event()
                 freed[b].record(last)
             elif gather:
@@ -704,7 +765,7 @@ def job(args, env):
                     flat = gather.finish(b)
                     if flat is not None:
                         ctx.scatter_tiles(flat.data_ptr(), images[b].data_ptr(), (fw, fh), (TILE, TILE), world, gather.tiles_per_rank, 4,
-                                          side.cuda_stream, rect=rects[k % N_VIEWS])
+                                          side.cuda_stream, rect=rects[vidx(k)])
                     freed[b] = torch.cuda.Event()
                     freed[b].record(side)
 
@@ -728,6 +789,7 @@ def job(args, env):
         del launches[:]
         del phases[:]
         fence()
+        direction[0] = (len(blocks) % 2) if moving else 0  # moving camera: forwards, backwards, forwards, ...
         t0 = time.perf_counter()
         run(args.steps, True)
         host_enqueue = time.perf_counter() - t0  # the host's share: how long the loop took to enqueue the block
@@ -781,7 +843,7 @@ def job(args, env):
 
     # ---- one frame at a time (outside the timed region): the latency of a single frame's launch ---------------------
     single = None
-    if not use_gather and not virtual:
+    if not use_gather and not virtual and not moving:
         # one target per view (a static camera per target, as in the timed loop), 2 untimed + 5 timed launches of a view back to back as in
         # the earlier rounds' figure; the median per view (one frame in eight also measures tile costs and is followed by the 20 us sort
         # kernel: inside the bracket, outside the median)
@@ -807,14 +869,15 @@ def job(args, env):
                   "note": "one vkv_render launch per frame with nothing else on the GPU: a view rendered 7 times in a row into its own target (a static camera: start order from the costs measured on the first of them, caches warm from the same view; the views in turn measure about 0.245, VKV_RAYMARCH_FEEDBACK=0 about 0.25 / 0.245 ms), median of the last 5, mean over the 8 views"}
 
     # whole-job sample rates need every rank's counters
-    tot = torch.tensor([sum(n_vs[k % N_VIEWS] for k in range(args.steps)), sum(n_ds[k % N_VIEWS] for k in range(args.steps)),
-                        sum(n_cov[k % N_VIEWS] for k in range(args.steps))], dtype=torch.float64, device="cuda")
+    direction[0] = 0
+    tot = torch.tensor([sum(n_vs[vidx(k)] for k in range(args.steps)), sum(n_ds[vidx(k)] for k in range(args.steps)),
+                        sum(n_cov[vidx(k)] for k in range(args.steps))], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tot)
     vs_total, ds_total, cov_total = float(tot[0].item()), float(tot[1].item()), float(tot[2].item())
 
     if args.verify:
-        verify(ctx, sp, v, views, params, args.steps, nbuf, (last_slot[0] + 1) if submit == "batch" else 0, (fw, fh), bufs, images, gather, rank,
+        verify(ctx, sp, v, views[last_view[0]], params, args.steps, nbuf, (last_slot[0] + 1) if submit == "batch" else 0, (fw, fh), bufs, images, gather, rank,
                last_owner[0] if submit == "batch" else ((args.steps - 1) % world if rotate else 0))
     if rank != 0:
         if native:
@@ -822,7 +885,7 @@ def job(args, env):
         return None
 
     value = rays_per_frame_all * args.steps / elapsed / 1e6
-    aggregate_gbs = sum(frame_bytes[k % N_VIEWS] for k in range(args.steps)) / elapsed / 1e9
+    aggregate_gbs = sum(frame_bytes[vidx(k)] for k in range(args.steps)) / elapsed / 1e9
     kernel_name = "k_raymarch_lean_batch" if (submit == "batch" and fpl > 1) else "k_raymarch_lean"
     concurrent = nbs if submit == "batch" else fif
     extent = WORKLOADS[args.workload][0]
@@ -845,8 +908,9 @@ def job(args, env):
                    if world > 1 else "1 GPU",
                    "output": "RGBA8",
                    "submission": ("vkv_render_batch, up to %d frames per launch, consecutive launches on %d HIP stream(s); tile start order from the "
-                                  "tile costs measured on earlier frames into the same target (each target shows the same orbit view every block: the best "
-                                  "case for that feedback; VKV_RAYMARCH_FEEDBACK=0 measured 0.1027 instead of 0.0986 ms per frame on c3)" % (fpl, nbs)) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams (measured start order per target as well; each of the %d targets shows one orbit view)" % (fif, fif, nbuf)),
+                                  "tile costs measured on earlier frames into the same target%s" % (fpl, nbs, " (switched off: VkvTuning.feedback = 0)" if args.no_feedback else
+                                                                                                    (" (a camera that moves one degree of orbit per frame, the targets taking the frames in turn)" if moving else
+                                                                                                     " (each target shows the same orbit view every block: the best case for that feedback; the line's camera_and_feedback block measures the others)"))) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams (measured start order per target as well; each of the %d targets shows one orbit view)" % (fif, fif, nbuf)),
                    "occupied_voxel_percent": round(occupied_voxel_percent(ctx, v, tf), 4)},
         "covered_Mray_per_s": round(cov_total / elapsed / 1e6, 3), "covered_fraction": round(cov_total / (rays_per_frame_all * args.steps), 4),
         "volume_samples_per_s": round(vs_total / elapsed, 1), "distance_probes_per_s": round(ds_total / elapsed, 1),
@@ -869,7 +933,7 @@ def job(args, env):
     if compact:
         # what the exchange moves per frame: every rank sends ceil(tiles of the view's screen rectangle / N) tiles of RGBA8 to the frame's owner;
         # `whole_frame` = the same with every tile of the frame (rounds 1-5, --tile-rect off)
-        per_rank = float(np.mean([exchange_bytes_v[k % N_VIEWS] for k in range(args.steps)]))
+        per_rank = float(np.mean([exchange_bytes_v[vidx(k)] for k in range(args.steps)]))
         out["exchange_bytes_per_frame"] = {"per_rank": int(per_rank), "all_ranks": int(per_rank * n_ranks), "whole_frame_all_ranks": int(exchange_bytes_whole * n_ranks),
                                            "ratio": round(per_rank / exchange_bytes_whole, 4), "tile_rect": "on" if use_rect else "off",
                                            "frame_owner": ("spread: frame j of launch l on rank (l + j) mod N" if spread else ("rotate: launch l on rank l mod N" if rotate else "rank 0")) if use_gather else None,
@@ -889,23 +953,24 @@ def job(args, env):
     # pattern, tools/micro/gather_fetch.hip), committed under profiles/.  The file names the sources it was measured on (a digest of the
     # integrator's source files + the commit): a tree whose integrator differs gets "traffic": null instead of a stale figure.
     try:
-        with open(TRAFFIC_FILE) as f:
+        with open(traffic_file(args.workload)) as f:
             tr = json.load(f)
         out["roofline"]["traffic_commit"] = tr.get("commit")
         if (tr.get("workload") == args.workload and world == 1 and tr.get("kernel") == out["roofline"]["kernel"] and args.tf == "app"
-                and args.skip is None and not args.no_ert):
+                and args.skip is None and not args.no_ert and not moving and not args.no_feedback and not virtual):
             if tr.get("kernel_source_sha256") == kernel_source_digest():
                 # measured with 8 frames per launch: scaled to this run's average launch
                 out["roofline"]["traffic"] = int(tr["traffic_bytes_per_launch"] * out["roofline"]["frames_per_launch"] / tr.get("frames_per_launch", 8))
                 out["roofline"]["traffic_source"] = tr["source"]
+                out["roofline"]["traffic_over_algorithmic"] = round(out["roofline"]["traffic"] / max(1, out["roofline"]["algorithmic_bytes_per_launch"]), 3)
                 # the binding limit (same PMC passes, DESIGN.md section 6 has the formulas): valu_issue_frac = the launch's VALU wave-instructions
                 # by SQ counter class x the issue cost measured for the opcodes of that class on gfx950 / the SIMD cycles of the launch;
                 # wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES (share of a resident wave's time parked in s_waitcnt); waves_per_simd = resident waves
-                for k in ("valu_issue_frac", "wait_frac", "waves_per_simd"):
+                for k in ("valu_issue_frac", "wait_frac", "waves_per_simd", "valu_active_lanes"):
                     if tr.get(k) is not None:
                         out["roofline"][k] = tr[k]
             else:
-                out["roofline"]["traffic_source"] = "withheld: %s was measured on other integrator sources than this tree's" % os.path.basename(TRAFFIC_FILE)
+                out["roofline"]["traffic_source"] = "withheld: %s was measured on other integrator sources than this tree's" % os.path.basename(traffic_file(args.workload))
     except (OSError, ValueError, KeyError):
         pass
 
@@ -919,7 +984,7 @@ def job(args, env):
     return out
 
 
-def verify(ctx, sp, v, views, params, steps, nbuf, fpl, frame, bufs, images, gather, rank, owner):
+def verify(ctx, sp, v, view, params, steps, nbuf, fpl, frame, bufs, images, gather, rank, owner):
     """The frame left in the last step's buffer (on the rank that owns it) must equal a direct single-launch render of the same
     view, bit for bit."""
     if rank != owner:
@@ -927,7 +992,7 @@ def verify(ctx, sp, v, views, params, steps, nbuf, fpl, frame, bufs, images, gat
     k = steps - 1
     fw, fh = frame
     direct = torch.zeros((fh, fw, 4), dtype=torch.uint8, device="cuda")
-    sp.draw(sp.make_params(*views[k % N_VIEWS], abi.full_frame_tiles(fw, fh, TILE, TILE)), rgba8=direct)
+    sp.draw(sp.make_params(*view, abi.full_frame_tiles(fw, fh, TILE, TILE)), rgba8=direct)
     torch.cuda.synchronize()
     slot = (fpl - 1) if fpl else (k % nbuf)  # batch submission: `fpl` carries the last step's output buffer index + 1
     got = (images[slot] if fpl else images[k % nbuf]) if gather else bufs[slot].view(fh, fw, 4)

@@ -1,6 +1,6 @@
 """Build profiles/<round>_traffic.json (what bench.py's roofline.traffic / valu_issue_frac / wait_frac / waves_per_simd replay) from the PMC passes of tools/collect_profiles.sh.
 
-    python tools/make_traffic_json.py gpurun_out/<tag> r3 > profiles/r3_traffic.json
+    python tools/make_traffic_json.py gpurun_out/<tag> r3 [workload] > profiles/r3_traffic.json
 
 HBM bytes per launch of the ray-march kernel = (FETCH_SIZE x 2 + WRITE_SIZE) x 1024: FETCH_SIZE tallies every 128-byte request at 64 bytes on
 gfx950 (MI355X_MICROARCH.md, HBM) - calibrated on a coalesced stream in round 1 AND on the integrator's own 2-byte-aligned dword gathers in
@@ -11,7 +11,8 @@ profiles/r2_micro_valu_mix.txt: 2.4 - 2.9 cycles for v_fma / v_add / v_mul / log
 divided by the launch's SIMD cycles 1024 x GRBM_GUI_ACTIVE / 8 (rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs).  It replaces round 3's
 valu_busy (the gfx9 formula SQ_ACTIVE_INST_VALU x 4 / SIMDs / cycles, which prices every instruction at 4 cycles: 0.96 for a kernel whose
 priced figure is 0.84).  wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES: the share of a resident wave's time parked in s_waitcnt;
-waves_per_simd = SQ_WAVE_CYCLES x 4 / (1024 x GRBM_GUI_ACTIVE / 8) (the SQ wave counters tick in quad-cycles, MI355X_MICROARCH.md).
+waves_per_simd = SQ_WAVE_CYCLES x 4 / (1024 x GRBM_GUI_ACTIVE / 8) (the SQ wave counters tick in quad-cycles, MI355X_MICROARCH.md);
+valu_active_lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU: the average number of live lanes (of 64) of a VALU instruction.
 The file names the integrator sources it was measured on (sha256 over raymarch_core.hpp, raymarch.hip, vkv_device.hpp, Makefile: bench.py
 recomputes it and withholds the figures when the tree differs; comments and whitespace do not count)."""
 import collections
@@ -37,6 +38,7 @@ def averages(pattern, kernel):
 
 def main():
     out_dir, rnd = sys.argv[1], sys.argv[2]
+    workload = sys.argv[3] if len(sys.argv) > 3 else "c3"
     kernel = "k_raymarch_lean_batch"
     avg, n = averages(os.path.join(out_dir, "pmc_batch8_*"), kernel)
     import bench
@@ -51,17 +53,19 @@ def main():
         insts = {"CVT": avg["SQ_INSTS_VALU_CVT"], "FMA_F32": avg["SQ_INSTS_VALU_FMA_F32"], "INT32": avg["SQ_INSTS_VALU_INT32"]}
         insts["OTHER"] = avg["SQ_INSTS_VALU"] - sum(insts.values())
         issue = sum(insts[k] * model[k]["cycles_per_instruction"] for k in insts) / simd_cycles
+    # average number of live lanes of a VALU instruction (both counters tick in quad-cycles; the second is the first weighted by the threads that ran)
+    lanes = avg["SQ_THREAD_CYCLES_VALU"] / avg["SQ_ACTIVE_INST_VALU"] if avg.get("SQ_THREAD_CYCLES_VALU") and avg.get("SQ_ACTIVE_INST_VALU") else None
     if avg.get("SQ_WAIT_ANY") and avg.get("SQ_WAVE_CYCLES"):
         wait = avg["SQ_WAIT_ANY"] / avg["SQ_WAVE_CYCLES"]
         if simd_cycles:
             waves = avg["SQ_WAVE_CYCLES"] * 4.0 / simd_cycles
     print(json.dumps({
         "_comment": " ".join(__doc__.split("\n\n")[2:]).replace("\n", " "),
-        "workload": "c3", "kernel": kernel, "frames_per_launch": 8,
+        "workload": workload, "kernel": kernel, "frames_per_launch": 8,
         "fetch_size_kib_avg": fetch, "write_size_kib_avg": write,
         "traffic_bytes_per_launch": int((fetch * 2 + write) * 1024) if fetch and write else None,
         "valu_issue_frac": round(issue, 4) if issue else None, "wait_frac": round(wait, 4) if wait else None,
-        "waves_per_simd": round(waves, 2) if waves else None, "valu_issue_cost_model": model,
+        "waves_per_simd": round(waves, 2) if waves else None, "valu_active_lanes": round(lanes, 2) if lanes else None, "valu_issue_cost_model": model,
         "counters_avg": {k: round(v, 1) for k, v in sorted(avg.items())}, "launches_averaged": n,
         "kernel_source_sha256": digest, "commit": commit,
         "source": "profiles/%s_rocprof.txt" % os.path.basename(out_dir.rstrip("/")),
