@@ -1165,12 +1165,15 @@ typedef struct
 	float cx, cy, cz, irx, iry, irz, slope, amp, lo2, hi2;
 } Shell;
 
-static void synth_shells(VkvExtent3D e, uint32_t seed, Shell *sh)
+/* kind = 1 | shells << 8 | thickness << 16 (include/vkvolume_amd.h, vkv_synth_volume): the first `shells` (0 = all 40) of the seed's shells,
+ * their thickness scaled by thickness / 256 (0 = 1) - the knobs tools/benchmark_sweep.py tunes the occupied share of its scenes with */
+static void synth_shells(VkvExtent3D e, uint32_t seed, uint32_t kind, Shell *sh)
 {
 	uint64_t    s  = (0x5EEDull << 32) | (uint64_t) seed;
 	const float Wf = (float) e.width, Hf = (float) e.height, Df = (float) e.depth;
 	const float dm = fmaxf(fmaxf(Wf, Hf), Df);
-	const float th = 0.001f * dm + 1.0f;
+	const uint32_t tq = kind >> 16;
+	const float th = (0.001f * dm + 1.0f) * (tq ? (float) tq * (1.0f / 256.0f) : 1.0f);
 	for (int k = 0; k < SYNTH_SHELLS; ++k)
 	{
 		sh[k].cx = (0.15f + 0.70f * u01(&s)) * Wf;
@@ -1204,7 +1207,7 @@ static inline uint32_t synth_hash(uint32_t seed, uint32_t x, uint32_t y, uint32_
 void vkvo_synth_volume(uint8_t *vol, VkvExtent3D e, uint32_t kind, uint32_t seed)
 {
 	const int W = (int) e.width, H = (int) e.height, D = (int) e.depth;
-	if (kind == 0)
+	if ((kind & 255u) == 0)
 	{ /* C1 soft sphere: v = round(255 * clamp((R0 - r) / (R0 - R1), 0, 1)), R0 = 0.375 dim, R1 = 0.25 dim */
 		const float dm = (float) i_max(i_max(W, H), D);
 		const float R0 = 0.375f * dm, R1 = 0.25f * dm;
@@ -1221,13 +1224,15 @@ void vkvo_synth_volume(uint8_t *vol, VkvExtent3D e, uint32_t kind, uint32_t seed
 		return;
 	}
 	Shell sh[SYNTH_SHELLS];
-	synth_shells(e, seed, sh);
+	synth_shells(e, seed, kind, sh);
+	const uint32_t nq = (kind >> 8) & 255u;
+	const int      n_shells = nq && nq < SYNTH_SHELLS ? (int) nq : SYNTH_SHELLS;
 	for (int z = 0; z < D; ++z)
 		for (int y = 0; y < H; ++y)
 			for (int x = 0; x < W; ++x)
 			{
 				float best = 0.0f;
-				for (int k = 0; k < SYNTH_SHELLS; ++k)
+				for (int k = 0; k < n_shells; ++k)
 				{
 					const float dx = ((float) x - sh[k].cx) * sh[k].irx;
 					const float dy = ((float) y - sh[k].cy) * sh[k].iry;

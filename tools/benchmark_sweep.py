@@ -40,6 +40,17 @@ PRESETS = [
 ]
 
 
+# the `occupancy` column of the reference's rows for these presets (scripts/benchmark_results_0.csv:2, 7, 12, 17, 22, 27), in per cent
+REFERENCE_OCCUPANCY = [7.13484, 1.84919, 3.96725, 1.31172, 0.669954, 0.547355]
+# the generator knobs that bring each synthetic scene to that occupied share (tools/tune_sweep_scenes.py, within 10 % relative): vkv_synth_volume's
+# kind = 1 | shells << 8 | thickness << 16 (the first `shells` of the seed's 40 ellipsoid shells, their thickness scaled by thickness / 256)
+SCENE_KIND = [1, 1, 1, 1, 1, 1]
+
+
+def preset_seed(extent):
+    return 0xC0FFEE00 + extent[2] % 251
+
+
 def image_label(preset, assets):
     """what the `image` column says: the scan's file name only when the real file was rendered"""
     name, extent = preset[0], preset[1]
@@ -56,7 +67,7 @@ def run(preset, blocksize, skipmode, frames, assets, frames_in_flight):
     if assets and os.path.exists(os.path.join(assets, name)):
         cmd.append(os.path.join(assets, name))
     else:
-        cmd.append("--synthetic=%dx%dx%d:1:%d" % (*extent, 0xC0FFEE00 + extent[2] % 251))
+        cmd.append("--synthetic=%dx%dx%d:%d:%d" % (*extent, SCENE_KIND[PRESETS.index(preset)], preset_seed(extent)))
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800).stdout.decode()
     fps = re.search(r"ran [\d]+ frames, averaged ([\d\.e\+\-]+) fps", out)
     upd = re.search(r"Updated occupancy/distance map in ([\d\.e\+\-]+)ms", out)

@@ -1,0 +1,64 @@
+"""Tune the six synthetic scenes of tools/benchmark_sweep.py to the occupied-voxel share of the reference's datasets (GPU).
+
+The reference's CSVs carry an `occupancy` column (scripts/benchmark_results_0.csv:2,7,12,17,22,27: 7.13 / 1.85 / 3.97 / 1.31 / 0.67 / 0.55 % for its
+six dataset x transfer-function presets: the analytic-TF voxel count of src/compute_occupied_voxel_count.cpp).  The scans are not published, so
+the sweep renders synthetic shell volumes of the same extents under the same transfer-function windows; this tool finds, per preset, the
+generator knobs (vkv_synth_volume: kind = 1 | shells << 8 | thickness << 16, the seed is kept) whose occupied share is closest to the
+reference's - a search over the shell count and a bisection of the thickness - and prints the table benchmark_sweep.py carries.
+usage: python tools/tune_sweep_scenes.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools.benchmark_sweep import PRESETS, REFERENCE_OCCUPANCY, preset_seed  # noqa: E402
+from vkvolume_amd import abi, lib, volume as V  # noqa: E402
+
+
+def occupancy(ctx, extent, kind, seed, imin, imax, gmin, gmax):
+    v = V.Volume(ctx)
+    v.options = abi.VolumeOptions(intensity_min=imin, intensity_max=imax, gradient_min=gmin, gradient_max=gmax)
+    v.load_synthetic(extent, kind=kind, seed=seed, distance_map_block_size=4)
+    tf = v.get_transfer_function_uniform()
+    V.ComputeGradientMap(ctx).compute(v, tf)
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ctx.occupied_voxel_count(v.volume.data_ptr(), v.gradient.data_ptr(), tf, v.extent, count.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return 100.0 * float(count.item()) / float(v.extent.count)
+
+
+def main():
+    torch.cuda.set_device(0)
+    ctx = lib.Context(0)
+    for (name, extent, imin, imax, gmin, gmax), target in zip(PRESETS, REFERENCE_OCCUPANCY):
+        seed = preset_seed(extent)
+        best = None
+        for shells in (40, 32, 26, 20, 16, 12, 9, 7, 5, 4, 3, 2, 1):
+            lo, hi = 0.5, 2.5  # thickness scale: a shell stays at least ~ a voxel thick, at most a few
+            f = lambda t: occupancy(ctx, extent, 1 | (shells << 8) | (int(round(t * 256)) << 16), seed, imin, imax, gmin, gmax)
+            olo, ohi = f(lo), f(hi)
+            if not (min(olo, ohi) <= target <= max(olo, ohi)):
+                continue
+            for _ in range(12):
+                mid = 0.5 * (lo + hi)
+                om = f(mid)
+                if (om < target) == (olo < ohi):
+                    lo = mid
+                else:
+                    hi = mid
+            t = 0.5 * (lo + hi)
+            tq = int(round(t * 256))
+            occ = f(tq / 256.0)
+            cand = (abs(t - 1.0), shells, tq, occ)  # prefer the shell count whose thickness stays closest to the default
+            if abs(occ - target) <= 0.1 * target and (best is None or cand < best):
+                best = cand
+        if best is None:
+            print("%-34s imin %.3f gmin %.2f gmax %.2f: target %.3f %%  NOT REACHED" % (name, imin, gmin, gmax, target))
+            continue
+        _, shells, tq, occ = best
+        print("%-34s imin %.3f gmin %.2f gmax %.2f: target %.3f %%  shells %2d thickness %3d/256  -> %.3f %%   kind = %d" % (
+            name, imin, gmin, gmax, target, shells, tq, occ, 1 | (shells << 8) | (tq << 16)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1303,7 +1303,7 @@ __global__ void __launch_bounds__(256) k_synth_sphere(uint8_t *__restrict__ vol,
 	vol[vidx(x, y, z, W, H)] = (uint8_t) __builtin_rintf(255.0f * t);
 }
 
-__global__ void __launch_bounds__(256) k_synth_shells(uint8_t *__restrict__ vol, int W, int H, int D, uint32_t seed, uint32_t blocks_x, SynthArgs args)
+__global__ void __launch_bounds__(256) k_synth_shells(uint8_t *__restrict__ vol, int W, int H, int D, uint32_t seed, uint32_t blocks_x, int n_shells, SynthArgs args)
 {
 	__shared__ SynthShell s_sh[kSynthShells];
 	for (int i = threadIdx.x; i < kSynthShells * 10; i += 256)
@@ -1315,7 +1315,7 @@ __global__ void __launch_bounds__(256) k_synth_shells(uint8_t *__restrict__ vol,
 	if (x >= W || y >= H)
 		return;
 	float best = 0.0f;
-	for (int k = 0; k < kSynthShells; ++k)
+	for (int k = 0; k < n_shells; ++k)
 	{
 		const float dx = ((float) x - s_sh[k].cx) * s_sh[k].irx;
 		const float dy = ((float) y - s_sh[k].cy) * s_sh[k].iry;
@@ -1903,18 +1903,21 @@ int launch_synth_volume(vkv_ctx *ctx, uint8_t *d_vol, VkvExtent3D e, uint32_t ki
 		return set_error(ctx, VKV_E_UNSUPPORTED, "synth_volume: volume too large for one launch");
 	const dim3 grid(blocks_x * ((e.height + 3) / 4), e.depth);
 	const int  W = (int) e.width, H = (int) e.height, D = (int) e.depth;
-	if (kind == 0)
+	if ((kind & 255u) == 0)
 	{
 		hipLaunchKernelGGL(k_synth_sphere, grid, dim3(256), 0, s, d_vol, W, H, D, blocks_x);
 		return check_launch(ctx, "synth_volume");
 	}
-	if (kind != 1)
-		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "synth_volume: unknown kind %u", kind);
+	if ((kind & 255u) != 1)
+		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "synth_volume: unknown kind %u", kind & 255u);
+	// kind = 1 | shells << 8 | thickness << 16: the first `shells` (0 = all 40) of the seed's shells, their thickness scaled by thickness / 256 (0 = 1)
+	const uint32_t nq = (kind >> 8) & 255u, tq = kind >> 16;
+	const int      n_shells = nq && nq < (uint32_t) kSynthShells ? (int) nq : kSynthShells;
 	SynthArgs   args;
 	uint64_t    st = (0x5EEDull << 32) | (uint64_t) seed;
 	const float Wf = (float) e.width, Hf = (float) e.height, Df = (float) e.depth;
 	const float dm = fmaxf(fmaxf(Wf, Hf), Df);
-	const float th = 0.001f * dm + 1.0f;
+	const float th = (0.001f * dm + 1.0f) * (tq ? (float) tq * (1.0f / 256.0f) : 1.0f);
 	for (int k = 0; k < kSynthShells; ++k)
 	{
 		SynthShell &sh = args.sh[k];
@@ -1933,7 +1936,7 @@ int launch_synth_volume(vkv_ctx *ctx, uint8_t *d_vol, VkvExtent3D e, uint32_t ki
 		sh.lo2 = lo > 0.0f ? lo * lo : 0.0f;
 		sh.hi2 = hi * hi;
 	}
-	hipLaunchKernelGGL(k_synth_shells, grid, dim3(256), 0, s, d_vol, W, H, D, seed, blocks_x, args);
+	hipLaunchKernelGGL(k_synth_shells, grid, dim3(256), 0, s, d_vol, W, H, D, seed, blocks_x, n_shells, args);
 	return check_launch(ctx, "synth_volume");
 }
 
