@@ -457,9 +457,10 @@ int vkv_assemble_frames(vkv_ctx *ctx, const void *d_tiles, void *d_gathered, voi
                         uint32_t bytes_per_pixel, int32_t root, const int32_t *roots, void *nccl_comm, void *stream);
 
 /* Deterministic synthetic uint8 volume, generated on the device. kind 0 = soft
- * sphere (config C1), kind 1 = ellipsoid shells + hash noise (configs C2..C5).  The shells take two knobs in the upper bits of `kind`
- * (kind = 1 | shells << 8 | thickness << 16): only the first `shells` (1 .. 39; 0 = all 40) of the seed's shells, their thickness scaled
- * by thickness / 256 (0 = 1.0) - tools/benchmark_sweep.py tunes the occupied-voxel share of its scenes to the reference's datasets with them. */
+ * sphere (config C1), kind 1 = ellipsoid shells + hash noise (configs C2..C5).  The shells take three knobs in the upper bits of `kind`
+ * (kind = 1 | shells << 8 | thickness << 16 | noise << 28): only the first `shells` (1 .. 39; 0 = all 40) of the seed's shells, their
+ * thickness scaled by thickness / 256 (12 bits; 0 = 1.0), the hash noise 0 .. noise (4 bits; 0 = the default 0 .. 20) -
+ * tools/benchmark_sweep.py tunes the occupied-voxel share of its scenes to the reference's datasets with them. */
 int vkv_synth_volume(vkv_ctx *ctx, uint8_t *d_volume, VkvExtent3D extent, uint32_t kind, uint32_t seed, void *stream);
 
 #ifdef __cplusplus

@@ -1165,14 +1165,15 @@ typedef struct
 	float cx, cy, cz, irx, iry, irz, slope, amp, lo2, hi2;
 } Shell;
 
-/* kind = 1 | shells << 8 | thickness << 16 (include/vkvolume_amd.h, vkv_synth_volume): the first `shells` (0 = all 40) of the seed's shells,
- * their thickness scaled by thickness / 256 (0 = 1) - the knobs tools/benchmark_sweep.py tunes the occupied share of its scenes with */
+/* kind = 1 | shells << 8 | thickness << 16 | noise << 28 (include/vkvolume_amd.h, vkv_synth_volume): the first `shells` (0 = all 40) of the seed's
+ * shells, their thickness scaled by thickness / 256 (12 bits, 0 = 1), hash noise 0 .. noise (4 bits, 0 = the default 0 .. 20) - the knobs
+ * tools/benchmark_sweep.py tunes the occupied share of its scenes with */
 static void synth_shells(VkvExtent3D e, uint32_t seed, uint32_t kind, Shell *sh)
 {
 	uint64_t    s  = (0x5EEDull << 32) | (uint64_t) seed;
 	const float Wf = (float) e.width, Hf = (float) e.height, Df = (float) e.depth;
 	const float dm = fmaxf(fmaxf(Wf, Hf), Df);
-	const uint32_t tq = kind >> 16;
+	const uint32_t tq = (kind >> 16) & 0xfffu;
 	const float th = (0.001f * dm + 1.0f) * (tq ? (float) tq * (1.0f / 256.0f) : 1.0f);
 	for (int k = 0; k < SYNTH_SHELLS; ++k)
 	{
@@ -1227,6 +1228,7 @@ void vkvo_synth_volume(uint8_t *vol, VkvExtent3D e, uint32_t kind, uint32_t seed
 	synth_shells(e, seed, kind, sh);
 	const uint32_t nq = (kind >> 8) & 255u;
 	const int      n_shells = nq && nq < SYNTH_SHELLS ? (int) nq : SYNTH_SHELLS;
+	const uint32_t noise_mod = (kind >> 28) ? (kind >> 28) + 1u : 21u;
 	for (int z = 0; z < D; ++z)
 		for (int y = 0; y < H; ++y)
 			for (int x = 0; x < W; ++x)
@@ -1246,7 +1248,7 @@ void vkvo_synth_volume(uint8_t *vol, VkvExtent3D e, uint32_t kind, uint32_t seed
 							best = val;
 					}
 				}
-				const uint32_t noise = synth_hash(seed, (uint32_t) x, (uint32_t) y, (uint32_t) z) % 21u;
+				const uint32_t noise = synth_hash(seed, (uint32_t) x, (uint32_t) y, (uint32_t) z) % noise_mod;
 				const uint32_t v     = (uint32_t) best + noise;
 				vol[vidx(x, y, z, W, H)] = (uint8_t) (v > 255u ? 255u : v);
 			}

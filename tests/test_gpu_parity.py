@@ -41,7 +41,7 @@ def make_gpu_volume(ctx, scene):
 @pytest.mark.parametrize("shape,kind,seed", [((64, 64, 64), 0, 1), ((64, 64, 64), 1, 0xC0FFEE02), ((97, 50, 33), 1, 7),
                                              ((130, 70, 41), 0, 3),
                                              # the generator's knobs (kind = 1 | shells << 8 | thickness << 16): 12 shells at 0.7 x, all 40 at 2 x, 3 at the default thickness
-                                             ((97, 50, 33), 1 | (12 << 8) | (179 << 16), 7), ((64, 64, 64), 1 | (512 << 16), 0xC0FFEE02), ((70, 60, 50), 1 | (3 << 8), 5)])
+                                             ((97, 50, 33), 1 | (12 << 8) | (179 << 16), 7), ((64, 64, 64), 1 | (512 << 16), 0xC0FFEE02), ((70, 60, 50), 1 | (3 << 8) | (9 << 28), 5)])
 def test_synth_volume_matches_oracle(ctx, shape, kind, seed):
     w, h, d = shape
     t = torch.empty((d, h, w), dtype=torch.uint8, device="cuda")

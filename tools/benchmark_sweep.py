@@ -7,9 +7,12 @@ MI355X results sit next to scripts/benchmark_results_{0..3}.csv.  It drives `vkv
 the same three log lines the reference harness parses.
 
 The reference's scans (present / stag beetle / kingsnake) are not published, so each preset uses a synthetic uint8
-volume of the same extent (`--synthetic`) and the `image` column says so: `synthetic_<W>x<H>x<D>` - ellipsoid shells with
-2 - 10 x the occupied-voxel share of the scans, NOT comparable row by row with the reference's CSVs.  Pass --assets DIR to use
-real `<name>` + `<name>.header` files instead (the `image` column then carries the file name).
+volume of the same extent (`--synthetic`) and the `image` column says so: `synthetic_<W>x<H>x<D>` - ellipsoid shells whose count,
+thickness and noise floor are tuned per preset (SCENE_KIND, tools/tune_sweep_scenes.py) so that the `occupancy` column - the
+analytic-TF voxel count of src/compute_occupied_voxel_count.cpp - matches the reference's row within 1 % (round 6; rounds 1-5 ran
+the same seeds at 2 - 10 x the scans' occupied share).  The STRUCTURE of the scenes still differs from a CT scan's (thin closed shells
+against a noise floor): same regime, not the same image.  Pass --assets DIR to use real `<name>` + `<name>.header` files instead (the
+`image` column then carries the file name).
 
 `--frames-in-flight N` (default 8): vkv_offscreen renders N frames per vkv_render_batch launch (the reference's swap-chain images in
 flight), so `framerate` is batch throughput; `--frames-in-flight 1` is the frame-serial figure (one launch per frame, each waiting for
@@ -44,7 +47,7 @@ PRESETS = [
 REFERENCE_OCCUPANCY = [7.13484, 1.84919, 3.96725, 1.31172, 0.669954, 0.547355]
 # the generator knobs that bring each synthetic scene to that occupied share (tools/tune_sweep_scenes.py, within 10 % relative): vkv_synth_volume's
 # kind = 1 | shells << 8 | thickness << 16 (the first `shells` of the seed's 40 ellipsoid shells, their thickness scaled by thickness / 256)
-SCENE_KIND = [1, 1, 1, 1, 1, 1]
+SCENE_KIND = [4047448065, 4040626177, 15800833, 16451841, 15667201, 16975617]  # -> 7.115 / 1.845 / 3.955 / 1.308 / 0.668 / 0.545 % (profiles/r6_tune_scenes.txt)
 
 
 def preset_seed(extent):
@@ -59,7 +62,8 @@ def image_label(preset, assets):
     return "synthetic_%dx%dx%d" % extent
 
 
-def run(preset, blocksize, skipmode, frames, assets, frames_in_flight):
+def run(preset, blocksize, skipmode, frames, assets, frames_in_flight, kind=None, extra=()):
+    """one vkv_offscreen --benchmark run -> (fps, map update ms, occupied voxels %); `kind`: generator word instead of the preset's"""
     name, extent, imin, imax, gmin, gmax = preset
     cmd = [APP, "--width=%d" % WIDTH, "--height=%d" % HEIGHT, "--benchmark=%d" % frames, "--imin=%g" % imin, "--imax=%g" % imax,
            "--gmin=%g" % gmin, "--gmax=%g" % gmax, "--blocksize=%d" % blocksize, "--skipmode=%d" % skipmode,
@@ -67,7 +71,8 @@ def run(preset, blocksize, skipmode, frames, assets, frames_in_flight):
     if assets and os.path.exists(os.path.join(assets, name)):
         cmd.append(os.path.join(assets, name))
     else:
-        cmd.append("--synthetic=%dx%dx%d:%d:%d" % (*extent, SCENE_KIND[PRESETS.index(preset)], preset_seed(extent)))
+        cmd.append("--synthetic=%dx%dx%d:%d:%d" % (*extent, kind if kind is not None else SCENE_KIND[PRESETS.index(preset)], preset_seed(extent)))
+    cmd += list(extra)
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800).stdout.decode()
     fps = re.search(r"ran [\d]+ frames, averaged ([\d\.e\+\-]+) fps", out)
     upd = re.search(r"Updated occupancy/distance map in ([\d\.e\+\-]+)ms", out)

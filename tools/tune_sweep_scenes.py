@@ -3,7 +3,7 @@
 The reference's CSVs carry an `occupancy` column (scripts/benchmark_results_0.csv:2,7,12,17,22,27: 7.13 / 1.85 / 3.97 / 1.31 / 0.67 / 0.55 % for its
 six dataset x transfer-function presets: the analytic-TF voxel count of src/compute_occupied_voxel_count.cpp).  The scans are not published, so
 the sweep renders synthetic shell volumes of the same extents under the same transfer-function windows; this tool finds, per preset, the
-generator knobs (vkv_synth_volume: kind = 1 | shells << 8 | thickness << 16, the seed is kept) whose occupied share is closest to the
+generator knobs (vkv_synth_volume: kind = 1 | shells << 8 | thickness << 16 | noise << 28, the seed is kept) whose occupied share is closest to the
 reference's - a search over the shell count and a bisection of the thickness - and prints the table benchmark_sweep.py carries.
 usage: python tools/tune_sweep_scenes.py"""
 import os
@@ -33,9 +33,12 @@ def main():
     for (name, extent, imin, imax, gmin, gmax), target in zip(PRESETS, REFERENCE_OCCUPANCY):
         seed = preset_seed(extent)
         best = None
+        # hash noise strictly below the transfer function's threshold (the default 0 .. 20 would be "occupied" under imin 0.071 = 18.1)
+        noise = 0 if imin * 255.0 > 20.0 else max(1, min(15, int(imin * 255.0) - 1))
+        nbits = noise << 28
         for shells in (40, 32, 26, 20, 16, 12, 9, 7, 5, 4, 3, 2, 1):
             lo, hi = 0.5, 2.5  # thickness scale: a shell stays at least ~ a voxel thick, at most a few
-            f = lambda t: occupancy(ctx, extent, 1 | (shells << 8) | (int(round(t * 256)) << 16), seed, imin, imax, gmin, gmax)
+            f = lambda t: occupancy(ctx, extent, 1 | (shells << 8) | (int(round(t * 256)) << 16) | nbits, seed, imin, imax, gmin, gmax)
             olo, ohi = f(lo), f(hi)
             if not (min(olo, ohi) <= target <= max(olo, ohi)):
                 continue
@@ -57,7 +60,7 @@ def main():
             continue
         _, shells, tq, occ = best
         print("%-34s imin %.3f gmin %.2f gmax %.2f: target %.3f %%  shells %2d thickness %3d/256  -> %.3f %%   kind = %d" % (
-            name, imin, gmin, gmax, target, shells, tq, occ, 1 | (shells << 8) | (tq << 16)))
+            name, imin, gmin, gmax, target, shells, tq, occ, 1 | (shells << 8) | (tq << 16) | nbits) + ("  (noise 0..%d)" % noise if noise else ""))
 
 
 if __name__ == "__main__":

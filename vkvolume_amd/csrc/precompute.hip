@@ -1303,7 +1303,8 @@ __global__ void __launch_bounds__(256) k_synth_sphere(uint8_t *__restrict__ vol,
 	vol[vidx(x, y, z, W, H)] = (uint8_t) __builtin_rintf(255.0f * t);
 }
 
-__global__ void __launch_bounds__(256) k_synth_shells(uint8_t *__restrict__ vol, int W, int H, int D, uint32_t seed, uint32_t blocks_x, int n_shells, SynthArgs args)
+__global__ void __launch_bounds__(256) k_synth_shells(uint8_t *__restrict__ vol, int W, int H, int D, uint32_t seed, uint32_t blocks_x, int n_shells, uint32_t noise_mod,
+                                                      SynthArgs args)
 {
 	__shared__ SynthShell s_sh[kSynthShells];
 	for (int i = threadIdx.x; i < kSynthShells * 10; i += 256)
@@ -1329,7 +1330,7 @@ __global__ void __launch_bounds__(256) k_synth_shells(uint8_t *__restrict__ vol,
 				best = val;
 		}
 	}
-	const uint32_t noise = synth_hash(seed, (uint32_t) x, (uint32_t) y, (uint32_t) z) % 21u;
+	const uint32_t noise = synth_hash(seed, (uint32_t) x, (uint32_t) y, (uint32_t) z) % noise_mod;
 	const uint32_t v     = (uint32_t) best + noise;
 	vol[vidx(x, y, z, W, H)] = (uint8_t) min(v, 255u);
 }
@@ -1910,8 +1911,9 @@ int launch_synth_volume(vkv_ctx *ctx, uint8_t *d_vol, VkvExtent3D e, uint32_t ki
 	}
 	if ((kind & 255u) != 1)
 		return set_error(ctx, VKV_E_INVALID_ARGUMENT, "synth_volume: unknown kind %u", kind & 255u);
-	// kind = 1 | shells << 8 | thickness << 16: the first `shells` (0 = all 40) of the seed's shells, their thickness scaled by thickness / 256 (0 = 1)
-	const uint32_t nq = (kind >> 8) & 255u, tq = kind >> 16;
+	// kind = 1 | shells << 8 | thickness << 16 | noise << 28: the first `shells` (0 = all 40) of the seed's shells, their thickness scaled by
+	// thickness / 256 (12 bits, 0 = 1), hash noise 0 .. noise (4 bits, 0 = the default 0 .. 20)
+	const uint32_t nq = (kind >> 8) & 255u, tq = (kind >> 16) & 0xfffu, noise_mod = (kind >> 28) ? (kind >> 28) + 1u : 21u;
 	const int      n_shells = nq && nq < (uint32_t) kSynthShells ? (int) nq : kSynthShells;
 	SynthArgs   args;
 	uint64_t    st = (0x5EEDull << 32) | (uint64_t) seed;
@@ -1936,7 +1938,7 @@ int launch_synth_volume(vkv_ctx *ctx, uint8_t *d_vol, VkvExtent3D e, uint32_t ki
 		sh.lo2 = lo > 0.0f ? lo * lo : 0.0f;
 		sh.hi2 = hi * hi;
 	}
-	hipLaunchKernelGGL(k_synth_shells, grid, dim3(256), 0, s, d_vol, W, H, D, seed, blocks_x, n_shells, args);
+	hipLaunchKernelGGL(k_synth_shells, grid, dim3(256), 0, s, d_vol, W, H, D, seed, blocks_x, n_shells, noise_mod, args);
 	return check_launch(ctx, "synth_volume");
 }
 

@@ -9,6 +9,7 @@
 //                 [--second-synthetic=WxHxD[:kind[:seed]] --second-offset=X,Y,Z --dump-params2=file]   a second volume in the same
 //                                  subpass (VolumeRenderSubpass::draw loops over its volumes, src/volume_render_subpass.cpp:219)
 //                 [--reload]       load the volume twice into the same Volume object
+//                 [--ert[=0|1]]    early ray termination on / off whatever the mode says (the benchmark mode of the reference switches it off)
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -45,6 +46,7 @@ struct Args
 	std::string second_synthetic;
 	float       second_offset[3] = {0.0f, 0.0f, 0.0f};
 	bool        reload           = false;
+	int         ert              = -1;        // --ert[=0|1]: -1 = the mode's own setting (benchmark mode: off)
 };
 
 bool flag(const char *arg, const char *name, std::string &value)
@@ -97,6 +99,7 @@ Args parse(int argc, char **argv)
 				throw std::runtime_error("--second-offset=X,Y,Z");
 		}
 		else if (flag(s, "--reload", v)) a.reload = true;
+		else if (flag(s, "--ert", v)) a.ert = v.empty() ? 1 : std::stoi(v);
 		else if (s[0] != '-') a.dataset = s;
 		else throw std::runtime_error(std::string("unknown flag ") + s);
 	}
@@ -155,6 +158,8 @@ int main(int argc, char **argv)
 			render_options.early_ray_termination = false;
 			render_options.test                  = VolumeRenderSubpass::Test::NumTextureSamples;
 		}
+		if (args.ert >= 0)        // --ert[=0|1]: early ray termination as asked for (the reference's benchmark mode switches it off)
+			render_options.early_ray_termination = args.ert != 0;
 
 		Volume volume(args.dataset.empty() ? "synthetic" : args.dataset);
 		volume.options.intensity_min            = args.imin;
