@@ -150,12 +150,14 @@ WORKLOADS = {
     "c4": ((2048, 2048, 2048), 0xC0FFEE04, (1.0, 1.0, 1.0), (1.0, 0.0, 0.0, 0.0), (3840, 2160), abi.SKIP_ANISOTROPIC_DISTANCE, "weak"),
     "c5": ((2048, 2048, 2048), 0xC0FFEE04, (1.0, 1.0, 1.0), (1.0, 0.0, 0.0, 0.0), (7680, 4320), abi.SKIP_ANISOTROPIC_DISTANCE, "strong"),
     "odd": ((493, 493, 443), 0xC0FFEE05, (1.0, 1.0, 1.0), (1.0, 0.0, 0.0, 0.0), (1920, 1080), abi.SKIP_DISTANCE, "weak"),
+    "even": ((492, 492, 442), 0xC0FFEE05, (1.0, 1.0, 1.0), (1.0, 0.0, 0.0, 0.0), (1920, 1080), abi.SKIP_DISTANCE, "weak"),
     "small": ((128, 128, 100), 0xC0FFEE03, (0.0003, 0.0003, 0.0007), (1.0, 0.0, 0.0, 90.0), (320, 192), abi.SKIP_DISTANCE, "weak"),
 }
 WORKLOAD_NOTE = {
     "c3": "BASELINE.json configs[2] (stag-beetle shape)", "c3cube": "the literal 1024^3 of BASELINE.json's metric line",
     "c2": "BASELINE.json configs[1]", "c4": "BASELINE.json configs[3]", "c5": "BASELINE.json configs[4]: fixed 7680x4320 frame, screen tiles over the ranks",
-    "small": "smoke size", "odd": "no extent a multiple of 4: the byte-wise fallback kernels of the precompute stages (tools/time_precompute.py odd)",
+    "small": "smoke size", "odd": "no extent a multiple of 4: rows at every byte alignment (tools/time_precompute.py odd; the byte-wise fallback kernels until round 5)",
+    "even": "the odd workload's neighbour with every extent a multiple of 2 and the width one of 4 (tools/time_precompute.py even)",
 }
 GRID = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
 TILE = 16

@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256) k_gradient_map(const uint8_t *__restrict_
 	grad[vidx(x, y, z, W, H)] = store_unorm8(g);
 }
 
-// LDS-tiled version (the one the launcher uses when the rows are dword-aligned, W % 4 == 0): a workgroup computes 64 x 8 x 8 blocks of
+// LDS-tiled version (the one the launcher uses for every width >= 4; until round 5 only for dword-aligned rows, W % 4 == 0): a workgroup computes 64 x 8 x 8 blocks of
 // voxels from (64+8) x 10 x 10 halo tiles staged in LDS with coalesced dword loads, so every volume byte is fetched ~1.8x (mostly from
 // L2) instead of 4x with byte gathers.
 //
@@ -104,6 +104,21 @@ __global__ void __launch_bounds__(256) k_check_numerics(int what, uint32_t first
 		atomicAdd(mismatches, 1ull);
 }
 
+// Four bytes of a voxel row as ONE dword, whatever the row's alignment (round 6: the tiled kernels no longer need W % 4 == 0).  Rows of a volume
+// whose width is no multiple of 4 start at every byte alignment; global loads need none on gfx950 (the integrator's own footprint gathers are
+// 2-byte aligned), the type only tells the compiler not to assume one.
+typedef uint32_t u32_any_align __attribute__((aligned(1)));
+__device__ __forceinline__ uint32_t load_u32_any(const uint8_t *p) { return *reinterpret_cast<const u32_any_align *>(p); }
+// Dword column dc (voxels 4 dc .. 4 dc + 3) of a row of W >= 4 voxels, dc < ceil(W / 4): the last, partial column of an odd width is read as the
+// row's LAST four bytes and shifted down - nothing past the row is touched, the bytes of x >= W come back zero.
+__device__ __forceinline__ uint32_t row_dword(const uint8_t *row, int dc, int W)
+{
+	const int x = 4 * dc;
+	if (x + 4 <= W)
+		return load_u32_any(row + x);
+	return load_u32_any(row + (W - 4)) >> (8 * (x + 4 - W));
+}
+
 constexpr int kGradTileX = 64, kGradTileY = 8, kGradTileZ = 8, kGradPitch = 72;        // pitch = 64 + 4 texels of halo on each side
 constexpr int kGradSegment = 10;                                                       // tiles one workgroup marches over
 
@@ -121,6 +136,10 @@ __device__ __forceinline__ void store_u8_uniform_base(uint8_t *base, uint32_t of
 // on 1024 x 1024 x 795).  The tile holds 16-bit OFFSETS into the 256-entry table of b / 255 (4 b: the shift between the tap read and the
 // table read is paid once per staged texel, not four times per voxel), two per half of a staged dword, which puts the texels of every
 // group of four in the order 0, 2, 1, 3.
+// ALIGNED: W % 4 == 0 and a dword-aligned volume - the staging loads are plain aligned dwords (scalar base + 32-bit lane offset addressing);
+// otherwise (round 6) rows start at any alignment and the last column of a row may be partial: row_dword / load_u32_any, measured 11 - 18 %
+// slower on aligned volumes (64-bit vector addresses per load), 2.4 x faster than the byte-wise kernel on odd ones.
+template <bool ALIGNED>
 __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__restrict__ vol, uint8_t *__restrict__ grad, int W, int H, int D,
                                                             float modifier, uint32_t tiles_x, uint32_t tiles_y, uint32_t tiles_z, uint32_t seg,
                                                             uint32_t n_wgs)
@@ -133,11 +152,11 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
 	const int      x0 = (int) (t % tiles_x) * kGradTileX;
 	const int      y0 = (int) ((t / tiles_x) % tiles_y) * kGradTileY;
 	const uint32_t k0 = (t / (tiles_x * tiles_y)) * seg, k1 = min(k0 + seg, tiles_z);
-	const int      wd = W >> 2;        // dwords per row
+	const int      wd = (W + 3) >> 2;        // dword columns of a row (round 6: the last one partial when W % 4 != 0; rows then start at any alignment)
 	const float    quarter_modifier = 0.25f * modifier;
 	// per-thread staging slots (100 rows x 18 dwords, 8 per thread): row / column of the tile are the same for every tile of the march,
 	// only z moves; rows clamp in y and z, dword columns clamp in x
-	int  off_xy[kIter], rz[kIter];
+	int  row_xy[kIter], colc[kIter], rz[kIter];
 	bool left[kIter], right[kIter];
 #pragma unroll
 	for (int j = 0; j < kIter; ++j)
@@ -147,20 +166,23 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
 		const int gy = min(max(y0 - 1 + row % (kGradTileY + 2), 0), H - 1);
 		const int gc = (x0 >> 2) - 1 + col;
 		left[j] = gc < 0, right[j] = gc >= wd;        // clamp-to-edge in x: texel x = -1 is voxel 0, texel x = W is voxel W - 1
-		off_xy[j] = gy * wd + min(max(gc, 0), wd - 1);
+		row_xy[j] = gy * W, colc[j] = min(max(gc, 0), wd - 1);
 		rz[j]     = row / (kGradTileY + 2) - 1;
 	}
-	const uint32_t *vol32 = reinterpret_cast<const uint32_t *>(vol);
-	const size_t    plane = (size_t) H * (size_t) wd;
-	uint32_t        v[kIter];
-	auto            fetch_edge = [&](uint32_t k) {
+	const size_t plane = (size_t) H * (size_t) W;        // bytes of a z slice
+	uint32_t     v[kIter];
+	auto         fetch_edge = [&](uint32_t k) {
 #pragma unroll
 		for (int j = 0; j < kIter; ++j)
 		{
 			const int gz = min(max((int) k * kGradTileZ + rz[j], 0), D - 1);
-			uint32_t  w  = vol32[(size_t) gz * plane + (size_t) off_xy[j]];
-			w            = left[j] ? (w << 24) : w;
-			v[j]         = right[j] ? (w >> 24) : w;
+			const uint8_t *row = vol + (size_t) gz * plane + (size_t) row_xy[j];
+			uint32_t       w   = ALIGNED ? reinterpret_cast<const uint32_t *>(row)[colc[j]] : row_dword(row, colc[j], W);
+			const int      nv  = W - 4 * colc[j];        // voxels of this column inside the row: 1 .. 3 in the last column of an odd width
+			if (!ALIGNED && nv < 4)
+				w |= (((w >> (8 * (nv - 1))) & 255u) * 0x01010101u) << (8 * nv);        // clamp-to-edge: the texels x >= W of the column are voxel W - 1
+			w    = left[j] ? (w << 24) : w;
+			v[j] = right[j] ? (w >> 24) : w;
 		}
 	};
 	// tiles whose halo needs no clamp in x and z (nearly all of them): one wave-uniform base per tile and a constant 32-bit byte offset per
@@ -168,18 +190,18 @@ __global__ void __launch_bounds__(256) k_gradient_map_tiled(const uint8_t *__res
 	uint32_t voff[kIter];
 #pragma unroll
 	for (int j = 0; j < kIter; ++j)
-		voff[j] = (uint32_t) (((size_t) (rz[j] + 1) * plane + (size_t) off_xy[j]) * 4u);
+		voff[j] = (uint32_t) ((size_t) (rz[j] + 1) * plane + (size_t) row_xy[j] + (size_t) (4 * colc[j]));
 	const bool inner_x = x0 > 0 && x0 + kGradTileX + 4 <= W;
 	auto       fetch   = [&](uint32_t k) {
         if (inner_x && k > 0 && (int) (k + 1) * kGradTileZ < D)
         {
-            const uint8_t *base = vol + ((size_t) k * kGradTileZ - 1) * plane * 4u;
+            const uint8_t *base = vol + ((size_t) k * kGradTileZ - 1) * plane;
 #pragma unroll
             for (int j = 0; j < kIter; ++j)
             {
                 uint32_t o = voff[j];
                 asm volatile("" : "+v"(o));        // keeps the zero-extension next to the load: scalar base + 32-bit lane offset addressing
-                v[j] = *reinterpret_cast<const uint32_t *>(base + o);
+                v[j] = ALIGNED ? *reinterpret_cast<const uint32_t *>(base + o) : load_u32_any(base + o);
             }
         }
         else
@@ -399,7 +421,11 @@ __global__ void __launch_bounds__(256) k_occupancy_map_waves(const uint8_t *__re
 	const int      xd = (int) (task % spans_x) * 64 + (int) lane, cy0 = (int) (task / spans_x) * cy_per_wave, cz = (int) blockIdx.y;
 	if (cy0 >= mh || xd * 4 >= W || vmin == 256u)
 		return;
-	const uint32_t xo = (uint32_t) xd * 4u;        // the lane's byte offset inside a row: scalar row base + 32-bit lane offset per load
+	// the lane's byte offset inside a row: scalar row base + 32-bit lane offset per load.  The last lane of an odd width (x + 4 > W) loads the
+	// row's last four bytes instead and shifts them down (row_dword); its voxels past the row are masked out of the result
+	const uint32_t xo_ = (uint32_t) xd * 4u, xo = min(xo_, (uint32_t) (W - 4)), shr = (xo_ - xo) * 8u;
+	const uint32_t valid   = xo_ + 4u <= (uint32_t) W ? 0xfu : (1u << ((uint32_t) W - xo_)) - 1u;
+	const bool     shifted = __builtin_amdgcn_ballot_w64(shr != 0u) != 0ull;        // wave-uniform: only the wave that holds the row's end
 	// "some byte of x is >= vmin" for four bytes at once: byte + (256 - vmin) carries out of its eight bits.  The low seven bits are added
 	// per byte (no carry between bytes: 127 + 127 < 256), the carry out of bit 7 is then majority(byte's bit 7, the constant's bit 7, the
 	// sum's bit 7), i.e. an OR or an AND with the constant's bit 7 known
@@ -452,7 +478,9 @@ __global__ void __launch_bounds__(256) k_occupancy_map_waves(const uint8_t *__re
 					row[j]          = (size_t) (cz * bz + min(r / by, nz - 1)) * zs + (size_t) min(c * by + r % by, H - 1) * (size_t) W;
 				}
 				row[j] = uniform_u64(row[j]);        // wave-uniform by construction: a scalar base for the two loads of this row
-				v4[j]  = *reinterpret_cast<const uint32_t *>(vol + row[j] + xo);
+				v4[j]  = load_u32_any(vol + row[j] + xo);
+				if (shifted)
+					v4[j] >>= shr;
 			}
 			if (vmin != 0u)
 			{
@@ -469,7 +497,11 @@ __global__ void __launch_bounds__(256) k_occupancy_map_waves(const uint8_t *__re
 			uint32_t g4[ROWS];
 #pragma unroll
 			for (int j = 0; j < ROWS; ++j)
-				g4[j] = GRAD == 1 ? *reinterpret_cast<const uint32_t *>(grad + row[j] + xo) : 0xffffffffu;
+			{
+				g4[j] = GRAD == 1 ? load_u32_any(grad + row[j] + xo) : 0xffffffffu;
+				if (GRAD == 1 && shifted)
+					g4[j] >>= shr;
+			}
 #pragma unroll
 			for (int j = 0; j < ROWS; ++j)
 #pragma unroll
@@ -482,6 +514,7 @@ __global__ void __launch_bounds__(256) k_occupancy_map_waves(const uint8_t *__re
 #pragma unroll
 		for (int k = 0; k < CRB; ++k)
 		{
+			occ[k] &= valid;        // (the voxels a row's last lane holds past the row's end)
 			if (cy + k >= cy_end || occ[k] == 0u)
 				continue;
 			uint8_t *out = map + ((size_t) cz * mh + (size_t) (cy + k)) * (size_t) mw;
@@ -636,7 +669,7 @@ __global__ void __launch_bounds__(256) k_tf_bits_analytic(uint32_t *__restrict__
 
 // GRAD as in k_occupancy_map.  Each thread walks voxels with a grid stride of whole x rows; a wave counts with
 // ballot + popcount, a workgroup adds once to the 64-bit total.
-template <int GRAD, bool DWORDS>
+template <int GRAD, int DWORDS>        // DWORDS: 0 = a voxel per lane, 1 = four per lane from aligned dwords (W % 4 == 0), 2 = four per lane at any alignment / width
 __global__ void __launch_bounds__(256) k_occupied_voxel_count(const uint8_t *__restrict__ vol, const uint8_t *__restrict__ grad,
                                                               const uint32_t *__restrict__ tf_bits, unsigned long long *__restrict__ total, int W, int H,
                                                               int D, float modifier, float imin, float iinv, float gmin, float ginv, uint32_t blocks_x,
@@ -655,6 +688,8 @@ __global__ void __launch_bounds__(256) k_occupied_voxel_count(const uint8_t *__r
 		const int      xd     = (int) (bx * 64 + (threadIdx.x & 63));        // dword column
 		const uint32_t stride = gridDim.x / blocks_x;
 		constexpr int  kBatch = 8;        // row groups fetched together: 16 loads in flight per lane
+		// (any width >= 4: the row's last lane reads the row's last four bytes and shifts, row_dword; its voxels past the row do not count)
+		const int n_valid = min(4, W - 4 * xd);
 		if (xd * 4 < W)
 			for (uint32_t rg0 = blockIdx.x / blocks_x; rg0 < n_row_groups; rg0 += stride * kBatch)
 			{
@@ -665,8 +700,16 @@ __global__ void __launch_bounds__(256) k_occupied_voxel_count(const uint8_t *__r
 					const uint32_t row = (rg0 + (uint32_t) j * stride) * 4 + (threadIdx.x >> 6);
 					const bool     ok  = rg0 + (uint32_t) j * stride < n_row_groups && row < rows;
 					const size_t   o   = (size_t) (ok ? row : 0u) * (size_t) W;
-					v4[j]              = ok ? reinterpret_cast<const uint32_t *>(vol + o)[xd] : 0u;
-					g4[j]              = (ok && GRAD == 1) ? reinterpret_cast<const uint32_t *>(grad + o)[xd] : (ok ? 0xffffffffu : 0u);
+					if (DWORDS == 1)
+					{
+						v4[j] = ok ? reinterpret_cast<const uint32_t *>(vol + o)[xd] : 0u;
+						g4[j] = (ok && GRAD == 1) ? reinterpret_cast<const uint32_t *>(grad + o)[xd] : (ok ? 0xffffffffu : 0u);
+					}
+					else
+					{
+						v4[j] = ok ? row_dword(vol + o, xd, W) : 0u;
+						g4[j] = (ok && GRAD == 1) ? row_dword(grad + o, xd, W) : (ok ? 0xffffffffu : 0u);
+					}
 				}
 #pragma unroll
 				for (int j = 0; j < kBatch; ++j)
@@ -676,7 +719,7 @@ __global__ void __launch_bounds__(256) k_occupied_voxel_count(const uint8_t *__r
 					for (int i = 0; i < 4; ++i)
 					{
 						const uint32_t bit = ((g4[j] >> (8 * i)) & 255u) * 256u + ((v4[j] >> (8 * i)) & 255u);
-						n += ok ? (s_bits[bit >> 5] >> (bit & 31u)) & 1u : 0u;        // per-lane partial sums, reduced below
+						n += (ok && (DWORDS == 1 || i < n_valid)) ? (s_bits[bit >> 5] >> (bit & 31u)) & 1u : 0u;        // per-lane partial sums, reduced below
 					}
 				}
 			}
@@ -1161,7 +1204,7 @@ __global__ void __launch_bounds__(THREADS) k_dm_rmq(const DmPasses passes, uint3
 // tile that it stages with coalesced dword loads (volume and gradient once each), then writes the bricks as whole 256-byte lines.
 // 8 x 4 x 4 (the launcher's choice for volumes of at least 16 bricks in y and z): every lane has 2 x 11 dwords in flight before the
 // barrier (8 x 2 x 2: 2 x 3 - not enough outstanding bytes per CU to cover the HBM latency) and the apron re-read drops from 1.42 to 1.27.
-template <int BY, int BZ, int PITCH>
+template <int BY, int BZ, int PITCH, bool ALIGNED>        // ALIGNED: W % 4 == 0 and dword-aligned buffers (plain dword loads); else row_dword
 __global__ void __launch_bounds__(256) k_pack_volume_tiled(const uint8_t *__restrict__ vol, const uint8_t *__restrict__ grad, uint8_t *__restrict__ packed,
                                                            int W, int H, int D, PackedDims pd, uint32_t groups_x)
 {
@@ -1172,7 +1215,7 @@ __global__ void __launch_bounds__(256) k_pack_volume_tiled(const uint8_t *__rest
 	// x-neighbouring workgroups stage parts of the same 128-byte lines: consecutive groups go to one XCD (own L2)
 	const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
 	const int      bx0 = (int) (bid % groups_x) * 8, by0 = (int) (bid / groups_x) * BY, bz0 = (int) blockIdx.y * BZ;
-	const int wd  = W >> 2;
+	const int wd  = (W + 3) >> 2;        // dword columns of a row; the last one partial when W % 4 != 0 (its texels x >= W are fixed up below)
 	// ---- stage: row = (jz, jy) of the padded tile, 9 dwords per row starting one dword left of the tile; a lane's (row, column) advance by
 	// constants from one of its loads to the next (256 = 28 * 9 + 4), so the divisions are done once
 	{
@@ -1188,8 +1231,8 @@ __global__ void __launch_bounds__(256) k_pack_volume_tiled(const uint8_t *__rest
 			const int y = min(max(by0 * 4 + ry - 1, 0), H - 1), z = min(max(bz0 * 4 + rz - 1, 0), D - 1);
 			const int dc = min(max(bx0 - 1 + c, 0), wd - 1);
 			const size_t o = ((size_t) z * H + y) * (size_t) W;
-			v4[j]          = reinterpret_cast<const uint32_t *>(vol + o)[dc];
-			g4[j]          = grad ? reinterpret_cast<const uint32_t *>(grad + o)[dc] : 0u;
+			v4[j]          = ALIGNED ? reinterpret_cast<const uint32_t *>(vol + o)[dc] : row_dword(vol + o, dc, W);
+			g4[j]          = grad ? (ALIGNED ? reinterpret_cast<const uint32_t *>(grad + o)[dc] : row_dword(grad + o, dc, W)) : 0u;
 			row += 28, c += 4;
 			if (c >= 9)
 				c -= 9, ++row;
@@ -1427,7 +1470,8 @@ int launch_gradient_map(vkv_ctx *ctx, const uint8_t *d_vol, uint8_t *d_grad, Vkv
 	// the tiled kernel folds the three factors 0.25 into the modifier: exact unless 0.25 * modifier is denormal (or the modifier no number)
 	const float m_abs    = std::fabs(tf->grad_magnitude_modifier);
 	const bool  m_normal = m_abs == 0.0f || (m_abs >= 1e-30f && m_abs <= 1e30f);
-	if (tf->use_gradient && m_normal && (e.width & 3u) == 0 && (((uintptr_t) d_vol) & 3u) == 0 && (uint64_t) e.width * e.height * (kGradTileZ + 2) <= 0xffffffffull)
+	// round 6: any width >= 4 and any alignment of the volume (the staging loads need none: row_dword / load_u32_any)
+	if (tf->use_gradient && m_normal && e.width >= 4 && (uint64_t) e.width * e.height * (kGradTileZ + 2) <= 0xffffffffull)
 	{
 		const uint64_t tx = (e.width + kGradTileX - 1) / kGradTileX, ty = (e.height + kGradTileY - 1) / kGradTileY,
 		               tz = (e.depth + kGradTileZ - 1) / kGradTileZ;
@@ -1439,8 +1483,12 @@ int launch_gradient_map(vkv_ctx *ctx, const uint8_t *d_vol, uint8_t *d_grad, Vkv
 		const uint64_t n_wgs = tx * ty * ((tz + seg - 1) / seg);
 		if (n_wgs <= 0x7fffffffull)
 		{
-			hipLaunchKernelGGL(k_gradient_map_tiled, dim3((uint32_t) n_wgs), dim3(256), 0, s, d_vol, d_grad, (int) e.width, (int) e.height, (int) e.depth,
-			                   tf->grad_magnitude_modifier, (uint32_t) tx, (uint32_t) ty, (uint32_t) tz, seg, (uint32_t) n_wgs);
+			if ((e.width & 3u) == 0 && (((uintptr_t) d_vol) & 3u) == 0)
+				hipLaunchKernelGGL(k_gradient_map_tiled<true>, dim3((uint32_t) n_wgs), dim3(256), 0, s, d_vol, d_grad, (int) e.width, (int) e.height, (int) e.depth,
+				                   tf->grad_magnitude_modifier, (uint32_t) tx, (uint32_t) ty, (uint32_t) tz, seg, (uint32_t) n_wgs);
+			else
+				hipLaunchKernelGGL(k_gradient_map_tiled<false>, dim3((uint32_t) n_wgs), dim3(256), 0, s, d_vol, d_grad, (int) e.width, (int) e.height, (int) e.depth,
+				                   tf->grad_magnitude_modifier, (uint32_t) tx, (uint32_t) ty, (uint32_t) tz, seg, (uint32_t) n_wgs);
 			return check_launch(ctx, "gradient_map");
 		}
 	}
@@ -1494,10 +1542,11 @@ int launch_occupancy_map(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_gr
 #undef VKV_OCC_DWORD
 		return check_launch(ctx, "occupancy_map");
 	}
-	const bool dword_ok = (e.width & 3u) == 0 && (!tf->use_gradient || precomputed) && (((uintptr_t) d_vol | (uintptr_t) d_grad) & 3u) == 0;
+	// round 6: any width >= 4 and any alignment (the kernel's loads need none; the last lane of an odd row reads the row's last four bytes)
+	const bool dword_ok = e.width >= 4 && (!tf->use_gradient || precomputed);
 	if (dword_ok && T_occ.occupancy_kernel != 1)
 	{        // any block width: a wave per 64 dwords (k_occupancy_map_waves)
-		const uint32_t spans_x = (uint32_t) ((e.width / 4 + 63) / 64);
+		const uint32_t spans_x = (uint32_t) (((e.width + 3) / 4 + 63) / 64);
 		const int      n_rows  = by * bz;
 		int            rows = 8, crb = 1;
 		if (n_rows == 1 || n_rows == 2 || n_rows == 4)
@@ -1578,8 +1627,10 @@ int launch_occupied_voxel_count(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_
 	const hipError_t me = hipMemsetAsync(d_count, 0, sizeof(uint64_t), s);
 	if (me != hipSuccess)
 		return set_error(ctx, (int) me, "occupied_voxel_count: %s", hipGetErrorString(me));
-	const bool     dwords       = (e.width & 3u) == 0 && ((((uintptr_t) d_vol) | ((uintptr_t) d_grad)) & 3u) == 0 && (!tf->use_gradient || d_grad);
-	const uint32_t blocks_x     = dwords ? (e.width / 4 + 63) / 64 : (e.width + 63) / 64;
+	// four voxels per lane for every width >= 4 and every alignment (row_dword); the byte path only for the on-the-fly gradient and tiny rows
+	const bool     dwords       = e.width >= 4 && (!tf->use_gradient || d_grad);
+	const bool     aligned      = (e.width & 3u) == 0 && ((((uintptr_t) d_vol) | ((uintptr_t) d_grad)) & 3u) == 0;
+	const uint32_t blocks_x     = dwords ? ((e.width + 3) / 4 + 63) / 64 : (e.width + 63) / 64;
 	const uint64_t rows         = (uint64_t) e.height * e.depth;
 	const uint64_t n_row_groups = (rows + 3) / 4;
 	if (n_row_groups > 0xffffffffull)
@@ -1594,14 +1645,14 @@ int launch_occupied_voxel_count(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_
 	                   tf->intensity_min, tf->intensity_range_inv, tf->gradient_min, tf->gradient_range_inv, blocks_x, (uint32_t) n_row_groups)
 	if (!tf->use_gradient)
 	{
-		if (dwords) VKV_COUNT(0, true); else VKV_COUNT(0, false);
+		if (dwords && aligned) VKV_COUNT(0, 1); else if (dwords) VKV_COUNT(0, 2); else VKV_COUNT(0, 0);
 	}
 	else if (d_grad)
 	{
-		if (dwords) VKV_COUNT(1, true); else VKV_COUNT(1, false);
+		if (dwords && aligned) VKV_COUNT(1, 1); else if (dwords) VKV_COUNT(1, 2); else VKV_COUNT(1, 0);
 	}
 	else
-		VKV_COUNT(2, false);
+		VKV_COUNT(2, 0);
 #undef VKV_COUNT
 	return check_launch(ctx, "occupied_voxel_count");
 }
@@ -1804,7 +1855,7 @@ int launch_check_numerics(vkv_ctx *ctx, int what, uint32_t first_bits, uint64_t 
 int launch_pack_volume(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_grad, VkvExtent3D e, void *d_packed, hipStream_t s)
 {
 	const PackedDims pd = packed_dims((int) e.width, (int) e.height, (int) e.depth);
-	if ((e.width & 3u) == 0 && ((((uintptr_t) d_vol) | ((uintptr_t) d_grad)) & 3u) == 0)
+	if (e.width >= 4)        // round 6: any width and alignment (row_dword: the staging loads need no alignment, an odd row's last column is shifted in)
 	{
 		const int tile_env = tuning_of(ctx).pack_tile;        // A/B switch: 2 or 4
 		const bool     big = tile_env ? tile_env == 4 : (pd.by >= 16 && pd.bz >= 16);
@@ -1814,12 +1865,19 @@ int launch_pack_volume(vkv_ctx *ctx, const uint8_t *d_vol, const uint8_t *d_grad
 		{
 			// row pitch 40 texels; 38 (19 banks, odd: no bank conflicts, 70 % of the LDS cycles otherwise) measured the same 1.34 ms: the
 			// kernel follows its 5.3 GB of traffic, not the LDS or the VALU (50 % busy)
+			const bool aligned = (e.width & 3u) == 0 && ((((uintptr_t) d_vol) | ((uintptr_t) d_grad)) & 3u) == 0;
+#define VKV_PACK(T, A)                                                                                                                              \
+	hipLaunchKernelGGL((k_pack_volume_tiled<T, T, 40, A>), dim3(gx * gy, gz), dim3(256), 0, s, d_vol, d_grad, (uint8_t *) d_packed, (int) e.width,     \
+	                   (int) e.height, (int) e.depth, pd, gx)
 			if (big)
-				hipLaunchKernelGGL((k_pack_volume_tiled<4, 4, 40>), dim3(gx * gy, gz), dim3(256), 0, s, d_vol, d_grad, (uint8_t *) d_packed, (int) e.width,
-				                   (int) e.height, (int) e.depth, pd, gx);
+			{
+				if (aligned) VKV_PACK(4, true); else VKV_PACK(4, false);
+			}
 			else
-				hipLaunchKernelGGL((k_pack_volume_tiled<2, 2, 40>), dim3(gx * gy, gz), dim3(256), 0, s, d_vol, d_grad, (uint8_t *) d_packed, (int) e.width,
-				                   (int) e.height, (int) e.depth, pd, gx);
+			{
+				if (aligned) VKV_PACK(2, true); else VKV_PACK(2, false);
+			}
+#undef VKV_PACK
 			return check_launch(ctx, "pack_volume");
 		}
 	}
