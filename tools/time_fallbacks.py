@@ -1,6 +1,6 @@
 """Diagnostic (GPU): the fallback kernels odd shapes get - a volume with no extent a multiple of 4 (bench workload "odd", 493x493x443: k_gradient_map,
 k_occupancy_map, k_pack_volume instead of the tiled / dword kernels) is timed by tools/time_precompute.py odd; this script adds the x pass of the
-distance transform for map rows longer than 1024 cells (k_dm_x instead of k_dm_x_wave)."""
+distance transform for map rows longer than 1024 cells (until round 5 the serial k_dm_x; round 6: k_dm_x_wave with 32 cells per lane up to 2048 cells)."""
 import os
 import sys
 
@@ -32,4 +32,4 @@ for mw, mh, md in ((1536, 128, 64), (1024, 128, 96)):
     torch.cuda.synchronize()
     n = mw * mh * md
     print("isotropic transform of a %dx%dx%d map (%s x pass): %.3f ms per update incl. the copy of the occupancy map, %.1f Mcell" % (
-        mw, mh, md, "k_dm_x" if mw > 1024 else "k_dm_x_wave", s.elapsed_time(e) / 10, n / 1e6))
+        mw, mh, md, "k_dm_x_wave, 32 cells per lane (round 6; k_dm_x until round 5)" if mw > 1024 else "k_dm_x_wave", s.elapsed_time(e) / 10, n / 1e6))

@@ -830,7 +830,7 @@ __global__ void __launch_bounds__(256) k_dm_x_wave(const uint8_t *src, uint8_t *
 {
 	// a wave takes kRows consecutive rows and has the loads of all of them in flight before it scans the first (one row is 256 bytes to 1 KB:
 	// with one row per wave a CU keeps 8 KB in flight and the pass runs at 1.4 TB/s)
-	constexpr int  kRows = C <= 8 ? 4 : 2;
+	constexpr int  kRows = C <= 8 ? 4 : (C <= 16 ? 2 : 1);        // (C = 32, rows of 1025 .. 2048 cells - round 6: a row is 1 - 2 KB, one per wave)
 	const uint32_t row0  = (blockIdx.x * 4u + (threadIdx.x >> 6)) * kRows;
 	if (row0 >= n_rows)
 		return;        // wave-uniform
@@ -1674,7 +1674,7 @@ static bool dm_whole_lines(int axis, VkvExtent3D me) { return (axis == 1 ? me.he
 template <int MODE>
 static int launch_dm_x(vkv_ctx *ctx, const uint8_t *src, uint8_t *dst, VkvExtent3D me, hipStream_t s)
 {
-	if (me.width <= 1024)
+	if (me.width <= 2048)        // round 6: also rows of 1025 .. 2048 cells in registers (32 cells per lane; the serial scan below was 14 x slower per cell)
 		return launch_dm_rmq<MODE>(ctx, 0, src, dst, nullptr, me, s);
 	// longer rows: serial row scan out of LDS (in place, like the table kernel for short rows)
 	const uint32_t n_rows = me.height * me.depth;
@@ -1699,7 +1699,7 @@ static int launch_dm_rmq(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *ds
 #define VKV_DM_XW(C)                                                                                                                            \
 	do                                                                                                                                          \
 	{                                                                                                                                           \
-		const uint32_t rows_per_wg = 4u * ((C) <= 8 ? 4u : 2u); /* kRows of the kernel */                                                       \
+		const uint32_t rows_per_wg = 4u * ((C) <= 8 ? 4u : ((C) <= 16 ? 2u : 1u)); /* kRows of the kernel */                                    \
 		const dim3     grid((n_rows + rows_per_wg - 1u) / rows_per_wg);                                                                         \
 		if (vec)                                                                                                                                \
 			hipLaunchKernelGGL((k_dm_x_wave<MODE, C, true>), grid, dim3(256), 0, s, src, dst, dst2, len, n_rows);                                \
@@ -1710,8 +1710,10 @@ static int launch_dm_rmq(vkv_ctx *ctx, int axis, const uint8_t *src, uint8_t *ds
 			VKV_DM_XW(4);
 		else if (len <= 512)
 			VKV_DM_XW(8);
-		else
+		else if (len <= 1024)
 			VKV_DM_XW(16);
+		else
+			VKV_DM_XW(32);        // up to 2048 cells (the widest map dm_check_extent lets through)
 #undef VKV_DM_XW
 		return check_launch(ctx, "distance_map x pass");
 	}
