@@ -910,9 +910,9 @@ def job(args, env):
                    if world > 1 else "1 GPU",
                    "output": "RGBA8",
                    "submission": ("vkv_render_batch, up to %d frames per launch, consecutive launches on %d HIP stream(s); tile start order from the "
-                                  "tile costs measured on earlier frames into the same target%s" % (fpl, nbs, " (switched off: VkvTuning.feedback = 0)" if args.no_feedback else
-                                                                                                    (" (a camera that moves one degree of orbit per frame, the targets taking the frames in turn)" if moving else
-                                                                                                     " (each target shows the same orbit view every block: the best case for that feedback; the line's camera_and_feedback block measures the others)"))) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams (measured start order per target as well; each of the %d targets shows one orbit view)" % (fif, fif, nbuf)),
+                                  "tile costs measured on earlier frames into the same target%s" % (fpl, nbs, (" (switched off: VkvTuning.feedback = 0)" if args.no_feedback else "") +
+                                                                                                    (" (a camera that moves %g degree(s) of orbit per frame, the targets taking the frames in turn)" % args.camera_step if moving else
+                                                                                                     (" (each target shows the same orbit view every block: the best case for that feedback; the line's camera_and_feedback block measures the others)" if not args.no_feedback else "")))) if submit == "batch" else ("%d single-frame launches in flight on %d HIP streams (measured start order per target as well; each of the %d targets shows one orbit view)" % (fif, fif, nbuf)),
                    "occupied_voxel_percent": round(occupied_voxel_percent(ctx, v, tf), 4)},
         "covered_Mray_per_s": round(cov_total / elapsed / 1e6, 3), "covered_fraction": round(cov_total / (rays_per_frame_all * args.steps), 4),
         "volume_samples_per_s": round(vs_total / elapsed, 1), "distance_probes_per_s": round(ds_total / elapsed, 1),

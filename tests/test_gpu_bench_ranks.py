@@ -90,3 +90,33 @@ def test_bench_one_rank_group_carries_both_exchanges():
     assert "error" not in ns, ns
     assert ns["ms_per_step"] > 0 and "exchange_ms" in ns["phases"] and "spread" in ns["exchange_bytes_per_frame"]["frame_owner"]
     assert d["exchange_bytes_per_frame"]["ratio"] < 0.9 and ne["exchange_bytes_per_frame"]["per_rank"] == d["exchange_bytes_per_frame"]["per_rank"]
+
+
+def test_bench_moving_camera_and_feedback_switch():
+    """bench.py --camera moving (every frame a new view, one degree of orbit from the last, blocks sweeping forwards and backwards) and
+    --no-feedback (VkvTuning.feedback = 0), the blocks the default line reports as camera_and_feedback: the frame left by the last step must
+    equal a direct render of that step's view (--verify), and the default line's side blocks come without an error."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    for more in (["--camera", "moving"], ["--camera", "moving", "--camera-step", "3", "--no-feedback"], ["--no-feedback"]):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "small", "--steps", "11", "--warmup", "3", "--min-seconds", "0.3", "--verify",
+               "--extras", "off", "--no-cpu-baseline"] + more
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert d["value"] > 0 and d["repeats"] >= 2 and "verify ok" in r.stderr
+        assert ("moves" in d["config"]["submission"]) == ("--camera" in more) and ("switched off" in d["config"]["submission"]) == ("--no-feedback" in more)
+        assert d["roofline"]["traffic"] is None  # the PMC figures belong to the static-camera headline only
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "small", "--steps", "8", "--warmup", "2", "--min-seconds", "0.2", "--extras", "on",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    for key in ("static", "static_feedback_off", "moving", "moving_feedback_off"):
+        assert d["camera_and_feedback"][key]["ms_per_step"] > 0, d["camera_and_feedback"]
+    for key in ("dense", "probe_only"):
+        assert "error" not in d["asymptotes"][key], d["asymptotes"]
