@@ -35,10 +35,23 @@ __device__ __forceinline__ void tile_order_from_cost(uint32_t *__restrict__ cost
 			const uint32_t t = base + (uint32_t) j * 256u + threadIdx.x;
 			c[j]             = t < count ? min(cost[t], (uint32_t) kCostBins - 1u) : 0xffffffffu;
 		}
+		// Half of a frame's tiles cost nothing (no ray of theirs marches): one LDS atomic per tile puts 4 000 of them on ONE address, which the
+		// LDS serialises; the zero-cost tiles of a wave are counted with one ballot and one atomic by the wave's first such lane.  (Round 6,
+		// the sort alone on 8 160 tiles: 23 us, of which 4.9 launch, ~5 the loads, 3.8 the histogram, 9.3 prefix + scatter - one workgroup is
+		// a chain of latencies; it runs once per 8 launches and stream, 0.5 % of the frame time, and was left at that.)
 #pragma unroll
 		for (int j = 0; j < kPerThread; ++j)
-			if (c[j] != 0xffffffffu)
+		{
+			const bool               zero = c[j] == 0u;
+			const unsigned long long zm   = __ballot(zero);
+			if (zero)
+			{
+				if ((zm & ((1ull << (threadIdx.x & 63u)) - 1ull)) == 0ull)
+					atomicAdd(&s_bin[kCostBins - 1], (uint32_t) __popcll(zm));
+			}
+			else if (c[j] != 0xffffffffu)
 				atomicAdd(&s_bin[kCostBins - 1 - c[j]], 1u);        // bin 0 = the dearest tiles
+		}
 		if (base + 256u * kPerThread >= count)
 		{        // the common case (up to 10 240 tiles, a 2560 x 1024 frame): one pass, the scatter reuses the registers
 			__syncthreads();
@@ -66,8 +79,19 @@ __device__ __forceinline__ void tile_order_from_cost(uint32_t *__restrict__ cost
 #pragma unroll
 				for (int j = 0; j < kPerThread; ++j)
 				{
-					const uint32_t t = (uint32_t) j * 256u + threadIdx.x;
-					if (c[j] != 0xffffffffu)
+					const uint32_t           t    = (uint32_t) j * 256u + threadIdx.x;
+					const bool               zero = c[j] == 0u;
+					const unsigned long long zm   = __ballot(zero);
+					if (zero)
+					{        // the wave's zero-cost tiles take consecutive places behind one atomic (their costs are zero already)
+						const unsigned long long below = zm & ((1ull << (threadIdx.x & 63u)) - 1ull);
+						uint32_t                 first = 0;
+						if (below == 0ull)
+							first = atomicAdd(&s_bin[kCostBins - 1], (uint32_t) __popcll(zm));
+						first = (uint32_t) __shfl((int) first, __ffsll((long long) zm) - 1);
+						order_out[first + (uint32_t) __popcll(below)] = t;
+					}
+					else if (c[j] != 0xffffffffu)
 					{
 						order_out[atomicAdd(&s_bin[kCostBins - 1 - c[j]], 1u)] = t;
 						cost[t] = 0;
@@ -146,6 +170,7 @@ static void load_render_code(int skip, bool ert)
 // the start-order kernels of this file (vkv_register_target: the first launch into a registered target would load them otherwise)
 void load_feedback_code()
 {
+
 	hipFuncAttributes at;
 	(void) hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_tile_order_from_cost));
 }
@@ -433,7 +458,22 @@ static bool apply_feedback(vkv_ctx *ctx, RayMarchArgs &a, hipStream_t s)
 	}
 	const bool     stale   = f->has_cost && !(cosine >= 0.978f && moved2 <= 0.04f * dist2);
 	const uint32_t since   = f->frames - f->measured_at;
-	const bool     measure = !f->has_cost || since >= f->period;
+	// Round 6: a target is only measured again while its camera holds still or moves slowly - this frame's view within the same ~12 degrees
+	// of the PREVIOUS frame into the target.  A camera that moves fast between a target's frames (24 targets in flight and one degree per
+	// frame: 6 - 72 degrees from one frame into a target to the next) cannot use a measured order, and measuring cost it 0.3 - 2.9 % (the
+	// cost atomics of every measured frame, the sort behind it: profiles/r6_feedback_moving_camera.txt); now it pays for the first frame only.
+	float prev_cos = 0.0f, prev_moved2 = 0.0f, prev_dist2 = 0.0f;
+	for (int i = 0; i < 3; ++i)
+	{
+		prev_cos += dir[i] * f->prev_dir[i];
+		prev_moved2 += (a.cam[i] - f->prev_pos[i]) * (a.cam[i] - f->prev_pos[i]);
+		prev_dist2 += (f->prev_pos[i] - 0.5f) * (f->prev_pos[i] - 0.5f);
+	}
+	const bool steady = f->has_prev && prev_cos >= 0.978f && prev_moved2 <= 0.04f * prev_dist2;
+	for (int i = 0; i < 3; ++i)
+		f->prev_dir[i] = dir[i], f->prev_pos[i] = a.cam[i];
+	f->has_prev        = true;
+	const bool measure = !f->has_cost || (since >= f->period && steady);
 	if (measure)
 	{
 		// a measurement whose order no frame could use (the target kept jumping between far views) doubles the distance to the next

@@ -236,6 +236,8 @@ struct vkv_ctx
 		uint32_t    period = 8;      // frames until the next measurement (doubles while no frame can use the measured order)
 		uint32_t    used = 0;        // frames since the last measurement that started in its order
 		float       view_dir[3] = {0, 0, 0}, view_pos[3] = {0, 0, 0};        // central ray and camera position (texture space) of the measured frame
+		float       prev_dir[3] = {0, 0, 0}, prev_pos[3] = {0, 0, 0};        // ... of the previous frame into the target (measured or not)
+		bool        has_prev = false;
 	};
 	std::vector<TileFeedback *> feedback;
 };
