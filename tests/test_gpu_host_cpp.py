@@ -159,3 +159,19 @@ def test_offscreen_loads_a_volume_file(tmp_path):
     counts = np.fromfile(tmp_path / "c.raw", np.uint32).reshape(64, 96, 3)
     assert ref.counts[..., 0].sum() > 0 and np.array_equal(counts, ref.counts)
     del rng
+
+
+@pytest.mark.parametrize("ranks,skipmode", [(3, 2), (8, 3)])
+def test_offscreen_virtual_ranks_assemble_the_frame(tmp_path, ranks, skipmode):
+    """The multi-GPU decomposition through the C++ host mirror (VolumeRenderSubpass::rank_schedule -> draw -> vkv_scatter_tiles, INTEGRATION.md
+    section 5): one GPU plays every rank in turn; each renders its share of the tiles of the frame's screen rectangle into a compact buffer,
+    the owner's de-interleave assembles them and clears the rest - byte-equal to the frame one launch renders."""
+    full, assembled = tmp_path / "full.bin", tmp_path / "assembled.bin"
+    cmd = [EXE, "--width=330", "--height=200", "--skipmode=%d" % skipmode, "--synthetic=72x64x56:1:7", "--azimuth=35", "--elevation=15",
+           "--dump-rgba8=%s" % full, "--virtual-ranks=%d" % ranks, "--dump-assembled=%s" % assembled]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = np.fromfile(full, np.uint8), np.fromfile(assembled, np.uint8)
+    assert a.size == 330 * 200 * 4 and a.any() and np.array_equal(a, b)
+    m = re.search(r"rectangle (\d+)x(\d+) tiles at \((\d+), (\d+)\) of (\d+)x(\d+)", r.stdout)
+    assert m and int(m.group(1)) * int(m.group(2)) < int(m.group(5)) * int(m.group(6)), r.stdout  # the rectangle is smaller than the frame

@@ -10,6 +10,9 @@
 //                                  subpass (VolumeRenderSubpass::draw loops over its volumes, src/volume_render_subpass.cpp:219)
 //                 [--reload]       load the volume twice into the same Volume object
 //                 [--ert[=0|1]]    early ray termination on / off whatever the mode says (the benchmark mode of the reference switches it off)
+//                 [--virtual-ranks=N --dump-assembled=file]   the multi-GPU decomposition on one GPU: rank r of N renders
+//                                  VolumeRenderSubpass::rank_schedule(r, N) - its share of the tiles of the frame's screen rectangle - into a compact
+//                                  buffer, vkv_scatter_tiles assembles the N buffers (what the frame's owner does behind ncclGather)
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -47,6 +50,8 @@ struct Args
 	float       second_offset[3] = {0.0f, 0.0f, 0.0f};
 	bool        reload           = false;
 	int         ert              = -1;        // --ert[=0|1]: -1 = the mode's own setting (benchmark mode: off)
+	int         virtual_ranks    = 0;         // --virtual-ranks=N: this GPU plays N ranks in turn, --dump-assembled gets their assembled frame
+	std::string dump_assembled;
 };
 
 bool flag(const char *arg, const char *name, std::string &value)
@@ -100,6 +105,8 @@ Args parse(int argc, char **argv)
 		}
 		else if (flag(s, "--reload", v)) a.reload = true;
 		else if (flag(s, "--ert", v)) a.ert = v.empty() ? 1 : std::stoi(v);
+		else if (flag(s, "--virtual-ranks", v)) a.virtual_ranks = std::stoi(v);
+		else if (flag(s, "--dump-assembled", v)) a.dump_assembled = v;
 		else if (s[0] != '-') a.dataset = s;
 		else throw std::runtime_error(std::string("unknown flag ") + s);
 	}
@@ -386,6 +393,30 @@ int main(int argc, char **argv)
 			const VkvRenderParams p = subpass.make_params(volume2, target, nullptr, true);
 			std::ofstream         f(args.dump_params2, std::ios::binary);
 			f.write(reinterpret_cast<const char *>(&p), sizeof(p));
+		}
+		if (args.virtual_ranks > 0 && !args.dump_assembled.empty() && volumes.size() == 1)
+		{
+			const uint32_t N = (uint32_t) args.virtual_ranks, tile = 16;
+			const VkvTileSchedule s0 = subpass.rank_schedule(volume, target, 0, N);        // every rank derives the same rectangle
+			const uint32_t tiles_per_rank = (s0.rect.w * s0.rect.h + N - 1) / N;
+			const size_t   rank_bytes     = (size_t) tiles_per_rank * tile * tile * 4;
+			uint8_t *      d_gathered     = device_alloc<uint8_t>(rank_bytes * N);        // [rank][tiles]: what ncclGather delivers to the owner
+			uint8_t *      d_image        = device_alloc<uint8_t>(n_pixels * 4);
+			(void) hipMemsetAsync(d_image, 0x5a, n_pixels * 4, stream);
+			for (uint32_t r = 0; r < N; ++r)
+			{
+				const VkvTileSchedule sr = subpass.rank_schedule(volume, target, r, N);
+				RenderTarget          tr = target;
+				tr.rgba8 = d_gathered + r * rank_bytes, tr.counts = nullptr;
+				subpass.draw(tr, &sr);
+			}
+			if (vkv_scatter_tiles(ctx, d_gathered, d_image, args.width, args.height, tile, tile, &s0.rect, N, tiles_per_rank, 4, stream) != VKV_OK)
+				throw std::runtime_error(std::string("vkv_scatter_tiles: ") + vkv_last_error(ctx));
+			dump(args.dump_assembled, d_image, n_pixels * 4, stream);
+			std::printf("assembled %u virtual ranks: rectangle %ux%u tiles at (%u, %u) of %ux%u, %u tiles per rank\n", N, s0.rect.w, s0.rect.h, s0.rect.x0, s0.rect.y0,
+			            (args.width + tile - 1) / tile, (args.height + tile - 1) / tile, tiles_per_rank);
+			(void) hipFree(d_gathered);
+			(void) hipFree(d_image);
 		}
 		if (!args.dump_rgba8.empty())
 			dump(args.dump_rgba8, target.rgba8, n_pixels * 4, stream);

@@ -47,6 +47,17 @@ VkvRenderParams VolumeRenderSubpass::make_params(Volume &volume, const RenderTar
 	return p;
 }
 
+VkvTileSchedule VolumeRenderSubpass::rank_schedule(Volume &volume, const RenderTarget &target, uint32_t rank, uint32_t n_ranks, uint32_t align_tiles) const
+{
+	const VkvRenderParams p = make_params(volume, target, nullptr);
+	const uint32_t        t = 16;
+	VkvTileRect           rect{};
+	if (n_ranks == 0 || vkv_screen_tile_rect(&p.ray_cast, &p.ray_gen, target.width, target.height, t, t, align_tiles, &rect) != VKV_OK)
+		throw std::runtime_error("VolumeRenderSubpass: bad rank schedule");
+	const uint32_t total = rect.w * rect.h;
+	return VkvTileSchedule{t, t, rank, n_ranks, total > rank ? (total - rank + n_ranks - 1) / n_ranks : 0u, 1u, rect};
+}
+
 void VolumeRenderSubpass::prepare_targets(const std::vector<RenderTarget> &targets, const VkvTileSchedule *tiles)
 {
 	for (const RenderTarget &t : targets)

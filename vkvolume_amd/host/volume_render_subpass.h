@@ -80,6 +80,12 @@ class VolumeRenderSubpass
 	// the parameter block of one volume (what draw() binds), exposed for tests / the multi-GPU driver
 	VkvRenderParams make_params(Volume &volume, const RenderTarget &target, const VkvTileSchedule *tiles, bool blend = false) const;
 
+	// Multi-GPU: the schedule of rank `rank` of `n_ranks` for this camera - the 16x16 tiles of the rectangle the clipped box
+	// of `volume` projects into (vkv_screen_tile_rect: the counterpart of the rasteriser only shading the box's faces, :262-293), dealt round-robin,
+	// compact outputs.  Every rank derives the same rectangle from the same uniforms; pass it to draw() / draw_batch() and, with `rect`, to
+	// vkv_assemble_frame(s).  align_tiles > 1 rounds the rectangle outwards (fewer distinct schedules for a camera that moves).
+	VkvTileSchedule rank_schedule(Volume &volume, const RenderTarget &target, uint32_t rank, uint32_t n_ranks, uint32_t align_tiles = 1) const;
+
   private:
 	DeviceContext &       dc;
 	Camera &              camera;
