@@ -513,17 +513,25 @@ def job(args, env):
     # Sharded frames (N > 1, the one-rank proxies): only the tiles of each view's screen rectangle are scheduled and exchanged - the tile rectangle
     # the clipped box projects into, derived by every rank from the uniforms alone (vkv_screen_tile_rect); the de-interleave clears the rest.
     use_rect = compact and getattr(args, "tile_rect", "on") != "off"
+    # One GPU, whole frames (round 6): the batch launches schedule the tiles of each view's screen rectangle too and their workgroups write the
+    # no-fragment result to every pixel outside it (VkvTileSchedule.fill_outside): the same frame, complete, without a workgroup per empty tile
+    use_fill = not compact and submit == "batch" and getattr(args, "tile_rect", "on") != "off"
     whole_rect = abi.whole_image_rect(fw, fh, TILE, TILE)
-    params, rects, tiles_v = [], [], []
+    whole_tiles = abi.full_frame_tiles(fw, fh, TILE, TILE)
+    params, params_whole, rects, tiles_v = [], [], [], []
     for view, proj in views:
-        p = sp.make_params(view, proj, abi.full_frame_tiles(fw, fh, TILE, TILE))
-        r = lib.screen_tile_rect(p.ray_cast, p.ray_gen, (fw, fh), (TILE, TILE)) if use_rect else whole_rect
-        t = abi.full_frame_tiles(fw, fh, TILE, TILE, my_rank, n_ranks, compact=compact, rect=r if use_rect else None)
+        p = sp.make_params(view, proj, whole_tiles)
+        params_whole.append(abi.RenderParams.from_buffer_copy(p))  # the whole-image schedule: counter pre-pass, single-frame launches, CPU check
+        r = lib.screen_tile_rect(p.ray_cast, p.ray_gen, (fw, fh), (TILE, TILE)) if (use_rect or use_fill) else whole_rect
+        if use_fill:
+            t = abi.full_frame_tiles(fw, fh, TILE, TILE, rect=r, fill_outside=True)
+        else:
+            t = abi.full_frame_tiles(fw, fh, TILE, TILE, my_rank, n_ranks, compact=compact, rect=r if use_rect else None)
         p.tiles = t
         params.append(p)
         rects.append(r)
         tiles_v.append(t)
-    tiles = tiles_v[0]  # (N = 1 without a proxy: the one schedule of every view - all tiles of the frame)
+    tiles = whole_tiles  # (single-frame launches: the whole-image schedule)
     pixels_v = [t.tile_count * TILE * TILE if compact else fw * fh for t in tiles_v]  # output slots of this rank per view
     my_pixels = max(pixels_v)
     # every pixel of the frame is a ray (covered or not), summed over ranks - the assembled frame is complete, whatever was exchanged; a virtual
@@ -533,7 +541,7 @@ def job(args, env):
     # ---- pre-pass (untimed): frag counters per view -> algorithmic bytes per frame ---------------------------------
     counts = torch.zeros((max(my_pixels, 1), 3), dtype=torch.int32, device="cuda")
     n_vs, n_ds, n_cov = [], [], []
-    for p in params:
+    for p in (params if compact else params_whole):
         counts.zero_()
         sp.draw(p, counts=counts)
         torch.cuda.synchronize()
@@ -858,7 +866,7 @@ def job(args, env):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 torch.cuda.synchronize()
                 e0.record()
-                sp.draw(params[i], rgba8=own[i])
+                sp.draw(params_whole[i], rgba8=own[i])
                 e1.record()
                 torch.cuda.synchronize()
                 if rnd >= 2:
@@ -909,6 +917,8 @@ def job(args, env):
                    + ((" (vkv_assemble_frames: one ncclGather + one de-interleave per launch)" if submit == "batch" else " (vkv_assemble_frame: ncclGather + de-interleave)") if native else (" (torch.distributed.gather)" if args.backend == "nccl" else " (torch.distributed.gather over GLOO through host memory: a functional run, not a measurement)"))
                    if world > 1 else "1 GPU",
                    "output": "RGBA8",
+                   "schedule": ("the 16x16 tiles of each view's screen rectangle (vkv_screen_tile_rect: %s of the frame's %d tiles), the launch's workgroups write the no-fragment result to every pixel outside it (VkvTileSchedule.fill_outside): the whole frame, every pixel written" % (
+                       "/".join(str(int(r.w * r.h)) for r in rects[:N_VIEWS]), int(whole_rect.w * whole_rect.h))) if use_fill else ("tiles of each view's screen rectangle, compact buffers" if use_rect else "every tile of the frame"),
                    "submission": ("vkv_render_batch, up to %d frames per launch, consecutive launches on %d HIP stream(s); tile start order from the "
                                   "tile costs measured on earlier frames into the same target%s" % (fpl, nbs, (" (switched off: VkvTuning.feedback = 0)" if args.no_feedback else "") +
                                                                                                     (" (a camera that moves %g degree(s) of orbit per frame, the targets taking the frames in turn)" % args.camera_step if moving else
@@ -980,7 +990,8 @@ def job(args, env):
         out["virtual_rank"] = {"rank": virtual[0], "of": virtual[1], "tiles_per_view": [int(t.tile_count) for t in tiles_v], "rays_per_frame": rays_per_frame_all,
                                "note": "one GPU rendering the tile share of rank %d of %d (compact schedule, no exchange): value and ms_per_step are this share's" % virtual}
     if world == 1 and not args.no_cpu_baseline and not virtual:
-        out["cpu_baseline"] = cpu_baseline(ctx, sp, v, params, (fw, fh), args.cpu_seconds, not args.no_verify_cpu, out)
+        out["cpu_baseline"] = cpu_baseline(ctx, sp, v, params_whole, (fw, fh), args.cpu_seconds, not args.no_verify_cpu, out,
+                                           timed_params=params if use_fill else None)
     if native:
         gather.close()
     return out
@@ -1022,7 +1033,7 @@ def cpu_quota_cores():
         return None
 
 
-def cpu_baseline(ctx, sp, v, params, frame, target_seconds, verify_cpu, out):
+def cpu_baseline(ctx, sp, v, params, frame, target_seconds, verify_cpu, out, timed_params=None):
     """Time the CPU oracle (scalar port of the reference shaders, all host cores) on every s-th pixel in x and y of the
     same 8 frames.  The oracle is only the baseline being timed here; nothing it computes feeds the GPU result.  With
     --verify-cpu the pixels it rendered are then compared with the device's frames (the oracle as the checker)."""
@@ -1068,9 +1079,22 @@ def cpu_baseline(ctx, sp, v, params, frame, target_seconds, verify_cpu, out):
             torch.cuda.synchronize()
             if not np.array_equal(rgba8.cpu().numpy()[sel], last[i].rgba8[sel]):
                 raise SystemExit("verify-cpu failed: view %d: RGBA8 of the launch without counters differs from the oracle's" % i)
+            if timed_params is not None:
+                # ... and exactly what the timed block submits: the view's fill_outside schedule (the tiles of its screen rectangle, the rest filled by the
+                # rendering workgroups) in a vkv_render_batch launch, into a buffer full of garbage - every pixel of the frame, against the oracle
+                a, b = torch.full_like(rgba8, 0x5A), torch.full_like(rgba8, 0xA5)
+                qs = []
+                for t in (a, b):
+                    q = abi.RenderParams.from_buffer_copy(timed_params[i])
+                    q.d_out_rgba8, q.d_out_color, q.d_out_counts, q.d_out_depth, q.d_in_depth, q.blend_over_target = t.data_ptr(), None, None, None, None, 0
+                    qs.append(q)
+                ctx.render_batch(qs, torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                if not (np.array_equal(a.cpu().numpy()[sel], last[i].rgba8[sel]) and torch.equal(a, b)):
+                    raise SystemExit("verify-cpu failed: view %d: RGBA8 of the batch launch through the view's tile rectangle (fill_outside) differs from the oracle's" % i)
             n += last[i].counts[sel].shape[0] * last[i].counts[sel].shape[1]
         out["verified_against_cpu"] = {"views": len(params), "pixels": n, "pixel_stride": stride,
-                                       "what": "3 counters + RGBA8 per pixel, bit-exact; RGBA8 again from the launch without counters (the timed configuration)"}
+                                       "what": "3 counters + RGBA8 per pixel, bit-exact; RGBA8 again from the launch without counters and from the timed configuration (vkv_render_batch through each view's tile rectangle with fill_outside, into a buffer of garbage)"}
         print("verify-cpu ok: %d pixels of %d views match the oracle (counters + RGBA8)" % (n, len(params)), file=sys.stderr)
     # the same port on ONE thread (SURVEY.md §8d asks for both figures): view 0 on a sparser sample, about two seconds
     s1 = max(stride, int(math.ceil(math.sqrt(frame[0] * frame[1] / max(rate / cores * 2.0, 1.0)))))

@@ -150,7 +150,7 @@ typedef struct VkvTileRect
  * The W×H image is cut into tiles of tile_width × tile_height pixels.  The SCHEDULED tiles are those of `rect` (rect.w == 0 or rect.h == 0:
  * every tile of the image), numbered row-major INSIDE the rectangle: tile t is column rect.x0 + t % rect.w, row rect.y0 + t / rect.w.
  * The launch renders tiles tile_first + k*tile_stride, k = 0 .. tile_count-1.  Pixels outside the rectangle are not touched by the launch
- * (vkv_scatter_tiles / vkv_assemble_frames clear them when they assemble a frame).
+ * (vkv_scatter_tiles / vkv_assemble_frames clear them when they assemble a frame) unless fill_outside is set (single-GPU frames).
  * compact == 0: outputs are indexed by image pixel  (y*image_width + x);
  * compact != 0: outputs are indexed by (k*tile_height + ly)*tile_width + lx  (the per-rank
  *               buffer that is gathered over RCCL and de-interleaved by vkv_scatter_tiles); the
@@ -164,6 +164,11 @@ typedef struct VkvTileSchedule
 	uint32_t    tile_first, tile_stride, tile_count;
 	uint32_t    compact;
 	VkvTileRect rect;                    /* all zero: the whole image */
+	uint32_t    fill_outside;            /* single-GPU frames through a rectangle: != 0 = the launch ALSO writes the "no fragment" result (what a pixel whose ray
+	                                        misses the box gets: clear values, or nothing with blend_over_target) to every pixel outside the rectangle, so the
+	                                        frame is complete as with the whole-image schedule - without a workgroup per empty tile (each rendering workgroup
+	                                        fills a share of the outside tiles).  Needs compact == 0 and the whole rectangle in this launch (tile_first 0,
+	                                        tile_stride 1, tile_count rect.w * rect.h); the result equals the whole-image schedule's bit for bit. */
 } VkvTileSchedule;
 
 /* Everything VolumeRenderSubpass::draw binds for one volume

@@ -948,8 +948,21 @@ static void *pool_thread(void *arg)
 	return NULL;
 }
 
-uint64_t vkvo_render(const VkvRenderParams *P, int n_threads, uint32_t pixel_stride)
+uint64_t vkvo_render(const VkvRenderParams *P_in, int n_threads, uint32_t pixel_stride)
 {
+	/* VkvTileSchedule.fill_outside: the launch completes the frame - its result is DEFINED as the whole-image schedule's, and that is what the
+	 * oracle renders (every pixel through the frag, whatever rectangle the caller derived) */
+	VkvRenderParams        whole;
+	const VkvRenderParams *P = P_in;
+	if (P_in->tiles.fill_outside && P_in->tiles.rect.w && P_in->tiles.rect.h && !P_in->tiles.compact)
+	{
+		whole = *P_in;
+		memset(&whole.tiles.rect, 0, sizeof(whole.tiles.rect));
+		whole.tiles.fill_outside = 0, whole.tiles.tile_first = 0, whole.tiles.tile_stride = 1;
+		whole.tiles.tile_count   = ((P_in->image_width + P_in->tiles.tile_width - 1) / P_in->tiles.tile_width) *
+		                         ((P_in->image_height + P_in->tiles.tile_height - 1) / P_in->tiles.tile_height);
+		P = &whole;
+	}
 	float lut[256];
 	build_alpha_lut(&P->transfer_function, lut);
 	if (n_threads < 1)

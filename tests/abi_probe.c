@@ -9,7 +9,7 @@ int main(void)
 	S(VkvExtent3D); S(VkvTransferFunctionUniform); S(VkvVolumeOptions); S(VkvCameraUniform); S(VkvRayCastUniform); S(VkvRayGen);
 	S(VkvRenderOptions); S(VkvTileRect); S(VkvTileSchedule); S(VkvRenderParams); S(VkvTuning);
 	O(VkvTuning, feedback_period); O(VkvTuning, clamp_always); O(VkvTuning, wave_shape); O(VkvTuning, occupancy_kernel); O(VkvTuning, gradient_segment); O(VkvTuning, arena_bytes);
-	O(VkvTileSchedule, compact); O(VkvTileSchedule, rect); O(VkvTileRect, w);
+	O(VkvTileSchedule, compact); O(VkvTileSchedule, rect); O(VkvTileSchedule, fill_outside); O(VkvTileRect, w);
 	O(VkvRenderParams, ray_cast); O(VkvRenderParams, transfer_function); O(VkvRenderParams, ray_gen); O(VkvRenderParams, options);
 	O(VkvRenderParams, use_precomputed_gradient); O(VkvRenderParams, image_width); O(VkvRenderParams, tiles);
 	O(VkvRenderParams, volume_extent); O(VkvRenderParams, map_extent); O(VkvRenderParams, d_volume); O(VkvRenderParams, d_gradient);

@@ -36,13 +36,13 @@ def test_oracle_reproduces_golden_frames(gold, mode, ert):
     assert np.array_equal(r.color, gold["color_m%d_e%d" % (mode, ert)])
     assert np.array_equal(r.depth, gold["depth_m%d_e%d" % (mode, ert)])
     if mode == 2 and ert:
-        # the committed block has the VkvRenderParams layout of rounds 1-5; round 6 put VkvTileSchedule.rect (16 bytes, zero here: the whole
+        # the committed block has the VkvRenderParams layout of rounds 1-5; round 6 put VkvTileSchedule.rect and .fill_outside (16 + 4 bytes, zero here: the whole
         # image) behind the schedule's six words.  Every other byte - uniforms, ray generator, options, schedule, extents - must be the old one.
         import ctypes as C
         new, was = bytes(p), gold["params_m2_e1"].tobytes()
         rect_at = abi.RenderParams.tiles.offset + abi.TileSchedule.rect.offset
         ext_at, ptr_at = abi.RenderParams.volume_extent.offset, abi.RenderParams.d_volume.offset
-        assert new[rect_at:rect_at + C.sizeof(abi.TileRect)] == bytes(16) and ext_at == rect_at + 16
+        assert new[rect_at:rect_at + C.sizeof(abi.TileRect) + 4] == bytes(20) and ext_at == rect_at + 16 + 4  # the rectangle, then fill_outside (all zero here)
         assert new[:rect_at] == was[:rect_at]
         assert new[ext_at:ext_at + 24] == was[rect_at:rect_at + 24]  # volume and map extent
         was_ptr_at = (rect_at + 24 + 7) // 8 * 8

@@ -215,3 +215,88 @@ def test_sample_count_test_mode_without_a_counter_buffer(ctx, skipping_type):
                     assert np.array_equal(got["rgba8"].cpu().numpy(), ref.rgba8), "%s, tables %d, view %d: RGBA8 differs from the oracle" % (name, tables, i)
     finally:
         ctx.set_tuning(address_tables=2)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "16"))))
+def test_fill_outside_schedules_complete_the_frame(ctx, seed):
+    """VkvTileSchedule.fill_outside (round 6): a frame rendered through the tile rectangle of its clipped box, with the workgroups of a
+    vkv_render_batch launch writing the no-fragment result to every pixel outside it, equals the whole-image schedule's frame bit for bit - float
+    colour, RGBA8, the three counters, depth; with the depth attachment (outside pixels carry the scene depth) and with the blend state (outside
+    pixels keep the target's contents) - on the random configurations of test_render_fuzz (cameras inside / beside the box included), against
+    the whole-image launch and against the oracle.  vkv_render (one frame, argument block by value) renders the same frame by scheduling the whole
+    image; the oracle DEFINES a fill_outside schedule's result as the whole-image one."""
+    from tests.test_gpu_parity import COLOR_TOL, dev, fuzz_case
+    scene, v, params, _, label = fuzz_case(ctx, 300 + seed)
+    rng = np.random.default_rng(5100 + seed)
+    size = (params.image_width, params.image_height)
+    variant = ("plain", "depth", "blend")[seed % 3]
+    p = abi.RenderParams.from_buffer_copy(params)
+    in_depth = tgt_color = tgt_rgba8 = None
+    if variant != "plain":
+        p.options.depth_attachment = 1
+        in_depth = np.zeros((size[1], size[0]), np.float32)
+        x0 = int(rng.integers(0, size[0]))
+        in_depth[:, x0:x0 + int(rng.integers(1, size[0]))] = float(rng.choice([0.1 / 90.0, 0.1 / 150.0, 0.5]))
+    if variant == "blend":
+        tgt_color = rng.random((size[1], size[0], 4), dtype=np.float32)
+        tgt_rgba8 = rng.integers(0, 256, (size[1], size[0], 4), dtype=np.uint8)
+    blend = variant == "blend"
+    rect = lib.screen_tile_rect(p.ray_cast, p.ray_gen, size, (16, 16), int(rng.choice([1, 1, 2])))
+    pf = abi.RenderParams.from_buffer_copy(p)
+    pf.tiles = abi.full_frame_tiles(size[0], size[1], 16, 16, rect=rect, fill_outside=True)
+    assert pf.tiles.fill_outside == 1 and pf.tiles.tile_count == rect.tiles
+    ref = scene.render(p, in_depth=in_depth, target_color=tgt_color, target_rgba8=tgt_rgba8, want_rgba8=True)
+    ref_fill = scene.render(pf, in_depth=in_depth, target_color=tgt_color, target_rgba8=tgt_rgba8, want_rgba8=True)
+    assert np.array_equal(ref.counts, ref_fill.counts) and np.array_equal(ref.color, ref_fill.color) and np.array_equal(ref.rgba8, ref_fill.rgba8)
+    sp = V.VolumeRenderSubpass(ctx, v, p.options, size)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def targets():
+        color = torch.from_numpy(tgt_color).cuda() if blend else torch.full((size[1], size[0], 4), -1.0, dtype=torch.float32, device="cuda")
+        rgba8 = torch.from_numpy(tgt_rgba8).cuda() if blend else torch.full((size[1], size[0], 4), 0x5A, dtype=torch.uint8, device="cuda")
+        counts = torch.full((size[1], size[0], 3), 77, dtype=torch.int32, device="cuda")
+        depth = torch.full((size[1], size[0]), -1.0, dtype=torch.float32, device="cuda")
+        return color, rgba8, counts, depth
+
+    def bound(src, outs):
+        q = sp.bind(src)
+        q.d_out_color, q.d_out_rgba8, q.d_out_counts, q.d_out_depth = (t.data_ptr() for t in outs)
+        q.d_in_depth, q.blend_over_target = (dev(in_depth).data_ptr() if in_depth is not None else None), 1 if blend else 0
+        return q
+
+    keep = dev(in_depth) if in_depth is not None else None  # (kept alive; bound() uploads its own copies per call)
+    what = "%s, %s, rect %s of %dx%d tiles" % (label, variant, rect.as_tuple(), -(-size[0] // 16), -(-size[1] // 16))
+    # the whole-image schedule: one launch of two frames (the reference result on the device)
+    whole = [targets(), targets()]
+    q_whole = [bound(p, o) for o in whole]
+    depth_keep = [dev(in_depth) for _ in range(6)] if in_depth is not None else []
+    for i, q in enumerate(q_whole):
+        if in_depth is not None:
+            q.d_in_depth = depth_keep[i].data_ptr()
+    ctx.render_batch(q_whole, st)
+    # the rectangle's schedule with fill_outside: the same launch shape
+    fill = [targets(), targets()]
+    q_fill = [bound(pf, o) for o in fill]
+    for i, q in enumerate(q_fill):
+        if in_depth is not None:
+            q.d_in_depth = depth_keep[2 + i].data_ptr()
+    ctx.render_batch(q_fill, st)
+    # vkv_render of the same schedule (renders the whole image)
+    single = targets()
+    q_single = bound(pf, single)
+    if in_depth is not None:
+        q_single.d_in_depth = depth_keep[4].data_ptr()
+    ctx.render(q_single, st)
+    torch.cuda.synchronize()
+    for name, outs in (("batch, frame 0", fill[0]), ("batch, frame 1", fill[1]), ("vkv_render", single)):
+        for a, b, field in zip(outs, whole[0], ("color", "rgba8", "counts", "depth")):
+            assert torch.equal(a, b), "%s: %s of the fill_outside schedule (%s) differs from the whole-image schedule's" % (what, field, name)
+    assert np.array_equal(fill[0][2].cpu().numpy().astype(np.uint32), ref.counts), what
+    assert float(np.abs(fill[0][0].cpu().numpy() - ref.color).max()) <= COLOR_TOL, what
+    assert np.array_equal(fill[0][1].cpu().numpy(), ref.rgba8), what
+    # argument checks: fill_outside wants the whole rectangle, image-indexed
+    bad = bound(pf, targets())
+    bad.tiles.tile_count = max(0, rect.tiles - 1)
+    if rect.tiles > 1 and (rect.w, rect.h) != (-(-size[0] // 16), -(-size[1] // 16)):
+        assert ctx.render_rc(bad, st) == abi.VKV_E_INVALID_ARGUMENT
+    del keep

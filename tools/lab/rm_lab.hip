@@ -187,7 +187,7 @@ extern "C" int vkv_lab_render(vkv_ctx *ctx, const VkvRenderParams *P, int varian
 		lut[a]        = std::min(std::max(v, 0.0f), 1.0f);
 	}
 	RayMarchArgs a;
-	const int    rc = vkv::fill_render_args(ctx, P, lut, a, (hipStream_t) stream, vkv::tuning_of(ctx), false);
+	const int    rc = vkv::fill_render_args(ctx, P, lut, a, (hipStream_t) stream, vkv::tuning_of(ctx), false, false);
 	if (rc != VKV_OK || a.nblocks == 0)
 		return rc;
 	if (!a.packed || !P->transfer_function.use_gradient || !P->use_precomputed_gradient)

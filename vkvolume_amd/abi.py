@@ -97,7 +97,8 @@ class TileRect(C.Structure):
 class TileSchedule(C.Structure):
     """VkvTileSchedule"""
     _fields_ = [("tile_width", C.c_uint32), ("tile_height", C.c_uint32), ("tile_first", C.c_uint32),
-                ("tile_stride", C.c_uint32), ("tile_count", C.c_uint32), ("compact", C.c_uint32), ("rect", TileRect)]
+                ("tile_stride", C.c_uint32), ("tile_count", C.c_uint32), ("compact", C.c_uint32), ("rect", TileRect),
+                ("fill_outside", C.c_uint32)]
 
 
 class RenderParams(C.Structure):
@@ -128,9 +129,10 @@ class VolumeHeader(C.Structure):
                 ("type", C.c_char * 16), ("endianness", C.c_char * 16), ("image_transform", C.c_float * 16)]
 
 
-def full_frame_tiles(image_width, image_height, tile_width=16, tile_height=16, rank=0, world=1, compact=False, rect=None):
+def full_frame_tiles(image_width, image_height, tile_width=16, tile_height=16, rank=0, world=1, compact=False, rect=None, fill_outside=False):
     """Tile schedule of one rank: every ``world``-th tile starting at ``rank`` (interleaved screen tiles) of the whole image or, with
-    ``rect`` (a TileRect, e.g. from lib.screen_tile_rect), of that tile rectangle."""
+    ``rect`` (a TileRect, e.g. from lib.screen_tile_rect), of that tile rectangle.  ``fill_outside`` (one rank, image-indexed outputs): the
+    launch also writes the no-fragment result outside the rectangle - the whole frame without a workgroup per empty tile."""
     if rect is not None and rect.w and rect.h:
         total, r = rect.w * rect.h, TileRect(rect.x0, rect.y0, rect.w, rect.h)
     else:
@@ -138,7 +140,7 @@ def full_frame_tiles(image_width, image_height, tile_width=16, tile_height=16, r
         tiles_y = (image_height + tile_height - 1) // tile_height
         total, r = tiles_x * tiles_y, TileRect(0, 0, 0, 0)
     count = (total - rank + world - 1) // world if total > rank else 0
-    return TileSchedule(tile_width, tile_height, rank, world, count, 1 if compact else 0, r)
+    return TileSchedule(tile_width, tile_height, rank, world, count, 1 if compact else 0, r, 1 if (fill_outside and r.w and not compact and world == 1) else 0)
 
 
 def whole_image_rect(image_width, image_height, tile_width=16, tile_height=16):

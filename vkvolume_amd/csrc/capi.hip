@@ -1011,6 +1011,8 @@ static int check_render_params(vkv_ctx *ctx, const VkvRenderParams *P)
 		const bool     whole   = t.rect.w == 0 || t.rect.h == 0;
 		if (!whole && ((uint64_t) t.rect.x0 + t.rect.w > tiles_x || (uint64_t) t.rect.y0 + t.rect.h > tiles_y))
 			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: the schedule's tile rectangle runs past the image");
+		if (t.fill_outside && !whole && (t.compact || t.tile_first != 0 || t.tile_stride != 1 || (uint64_t) t.tile_count != (uint64_t) t.rect.w * t.rect.h))
+			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: fill_outside needs image-indexed outputs and the whole rectangle in one launch (tile_first 0, tile_stride 1)");
 		const uint64_t scheduled = whole ? tiles_x * tiles_y : (uint64_t) t.rect.w * t.rect.h;
 		if (t.tile_count && (uint64_t) t.tile_first + (uint64_t) (t.tile_count - 1) * t.tile_stride >= scheduled)
 			return set_error(ctx, VKV_E_INVALID_ARGUMENT, "render: tile schedule runs past the %s", whole ? "image" : "tile rectangle");

@@ -323,7 +323,7 @@ void screen_tile_rect(const VkvRayCastUniform *rc, const VkvRayGen *rg, uint32_t
 }
 
 // VkvRenderParams -> kernel arguments.  Returns VKV_OK with a.nblocks == 0 when the schedule is empty.
-int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, RayMarchArgs &a, hipStream_t s, const VkvTuning &T, bool setup)
+int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, RayMarchArgs &a, hipStream_t s, const VkvTuning &T, bool setup, bool batch)
 {
 	for (int i = 0; i < 3; ++i)
 	{
@@ -354,13 +354,27 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 	a.depth_attachment = P->options.depth_attachment != 0, a.blend = P->blend_over_target != 0;
 	a.img_w = P->image_width, a.img_h = P->image_height;
 	a.tile_w = P->tiles.tile_width, a.tile_h = P->tiles.tile_height;
+	a.tile_first = P->tiles.tile_first, a.tile_stride = P->tiles.tile_stride, a.tile_count = P->tiles.tile_count, a.compact = P->tiles.compact;
+	bool whole_schedule;        // every tile of the image is scheduled (no rectangle, or a fill_outside rectangle handed to a resident-wave scheduler)
 	{        // the schedule's tile rectangle (all zero: the whole image); tiles are numbered row-major inside it
 		const VkvTileRect &r = P->tiles.rect;
-		const bool         whole = r.w == 0 || r.h == 0;
-		a.tiles_x = whole ? (a.img_w + a.tile_w - 1) / a.tile_w : r.w;
+		const uint32_t     full_x = (a.img_w + a.tile_w - 1) / a.tile_w, full_y = (a.img_h + a.tile_h - 1) / a.tile_h;
+		bool               whole  = r.w == 0 || r.h == 0;
+		a.fill_tiles = 0, a.img_tiles_x = full_x, a.rect_tx0 = a.rect_ty0 = a.rect_th = 0;
+		if (!whole && P->tiles.fill_outside)
+		{
+			// fill_outside (checked by check_render_params: the whole rectangle, image-indexed outputs): the workgroups of a vkv_render_batch launch
+			// fill the tiles outside the rectangle themselves; vkv_render (argument block by value: lean_block) and the resident-wave schedulers
+			// (A/B switches) simply render the whole-image schedule - the same frame either way
+			if (!batch || T.scheduler == 1 || T.batch_mode == 1 || (uint64_t) full_x * full_y - (uint64_t) r.w * r.h > (uint64_t) kFillPerTile * r.w * r.h)
+				whole = true, a.tile_count = full_x * full_y;        // (also a rectangle so small that its tiles could not fill the rest: a cheap frame anyway)
+			else
+				a.fill_tiles = full_x * full_y - r.w * r.h, a.rect_tx0 = r.x0, a.rect_ty0 = r.y0, a.rect_th = r.h;
+		}
+		a.tiles_x = whole ? full_x : r.w;
 		a.org_x = whole ? 0u : r.x0 * a.tile_w, a.org_y = whole ? 0u : r.y0 * a.tile_h;
+		whole_schedule = whole;
 	}
-	a.tile_first = P->tiles.tile_first, a.tile_stride = P->tiles.tile_stride, a.tile_count = P->tiles.tile_count, a.compact = P->tiles.compact;
 	a.blocks_per_tile_x = a.tile_w / 16;
 	a.blocks_per_tile   = a.blocks_per_tile_x * (a.tile_h / 16);
 	const uint64_t nb   = (uint64_t) a.blocks_per_tile * a.tile_count;
@@ -396,15 +410,12 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 	if (a.packed && T.address_tables != 0)
 		a.addr_lut = packed_addr_lut(ctx, a.W, a.H, a.D, &a.lut_y, &a.lut_z, &a.lut_words, s, setup);
 	screen_bound_of_box(a, T);
-	{
-		// centre first: of the image, or of the rectangle (the projected box) - the order of a rectangle depends on its size only, not on where
-		// it lies, so a camera that moves the rectangle about keeps its cached table
-		const VkvTileRect &r = P->tiles.rect;
-		const bool         whole = r.w == 0 || r.h == 0;
-		a.tile_order = T.tile_order_linear ? nullptr
-		                                   : tile_start_order(ctx, whole ? a.img_w : r.w * a.tile_w, whole ? a.img_h : r.h * a.tile_h, a.tile_w, a.tile_h, a.tile_first,
-		                                                      a.tile_stride, a.tile_count, s, setup);
-	}
+	// Start order.  Whole-image schedules: centre of the image first (a cached table per schedule shape).  Schedules over a tile rectangle start in
+	// plain order, row-major inside the rectangle (round 6): the rectangle holds few cheap tiles, and a table per rectangle SIZE - a camera that
+	// moves gives every frame in flight its own - cost more than the order gained (24 tables of 16 KB through the scalar cache: +2 ... 4 %
+	// per frame against no table, profiles/r6_rect_schedules.txt); a registered target's measured order still applies (apply_feedback).
+	a.tile_order = (T.tile_order_linear || !whole_schedule) ? nullptr
+	                                                         : tile_start_order(ctx, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count, s, setup);
 	for (int i = 0; i < 256; ++i)
 		a.alpha_lut[i] = alpha_lut[i];
 	return VKV_OK;
@@ -502,7 +513,7 @@ int launch_render(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut
 {
 	const VkvTuning T = tuning_of(ctx);
 	RayMarchArgs a;
-	const int    rc = fill_render_args(ctx, P, alpha_lut, a, s, T, false);
+	const int    rc = fill_render_args(ctx, P, alpha_lut, a, s, T, false, false);
 	if (rc != VKV_OK || a.nblocks == 0)
 		return rc;
 
@@ -532,7 +543,9 @@ int prepare_render(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, hipStream
 	for (uint32_t i = 0; i < n; ++i)
 	{
 		RayMarchArgs a;
-		const int    rc = fill_render_args(ctx, &P[i], lut, a, s, T, true);
+		int rc = fill_render_args(ctx, &P[i], lut, a, s, T, true, false);
+		if (rc == VKV_OK && P[i].tiles.fill_outside)        // (a fill_outside schedule starts its tiles in another order in a batch launch: both tables)
+			rc = fill_render_args(ctx, &P[i], lut, a, s, T, true, true);
 		if (rc != VKV_OK)
 			return rc;
 		load_render_code(P[i].options.skipping_type, P[i].options.early_ray_termination != 0);
@@ -554,7 +567,7 @@ int launch_render_batch(vkv_ctx *ctx, const VkvRenderParams *P, uint32_t n, cons
 	std::vector<RayMarchArgs> host(n);
 	for (uint32_t i = 0; i < n; ++i)
 	{
-		const int rc = fill_render_args(ctx, &P[i], alpha_luts + (size_t) i * 256, host[i], s, T, false);
+		const int rc = fill_render_args(ctx, &P[i], alpha_luts + (size_t) i * 256, host[i], s, T, false, true);
 		if (rc != VKV_OK)
 			return rc;
 		if (!host[i].packed)

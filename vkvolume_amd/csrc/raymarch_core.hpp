@@ -25,6 +25,7 @@
 using namespace vkv;
 
 constexpr int kTraceWords = 10;        // u64 words per wave of the diagnostic trace buffer
+constexpr uint32_t kFillPerTile = 3;   // VkvTileSchedule.fill_outside: outside tiles a rendering tile fills at most (lean_block)
 
 struct RayMarchArgs
 {
@@ -53,6 +54,9 @@ struct RayMarchArgs
 	uint32_t        depth_attachment, blend;
 	uint32_t        img_w, img_h, tile_w, tile_h, tiles_x, tile_first, tile_stride, tile_count, compact;        // tiles_x: tile columns of the schedule's rectangle
 	uint32_t        org_x, org_y;   // first pixel column / row of the schedule's tile rectangle (VkvTileSchedule.rect; 0, 0 = the whole image)
+	// VkvTileSchedule.fill_outside (k_raymarch_lean*): fill_tiles = tiles of the image OUTSIDE the rectangle (0 = nothing to fill); the rendering
+	// workgroups write the no-fragment result there, schedule entry k the outside tiles k, k + tile_count, ...
+	uint32_t        fill_tiles, img_tiles_x, rect_tx0, rect_ty0, rect_th;
 	uint32_t        blocks_per_tile_x, blocks_per_tile, nblocks;
 	int             test;
 	unsigned long long *trace;      // diagnostic (tools/wave_trace.py): kTraceWords x u64 per wave {t_start, t_end, iterations, unit, phase sums}, or null
@@ -1662,7 +1666,9 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 }
 
 // the body of one workgroup: 16x16 pixels of the frame described by A; `bid` is the workgroup's id inside that frame's grid
-template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF, int WPB = 4>
+// FILL: the batch kernel's workgroups also fill the tiles outside a fill_outside schedule's rectangle (the single-frame kernel takes its argument
+// block by value, and this code in it made the compiler keep the whole 1.8 KB block in scratch: its launcher renders the whole-image schedule instead)
+template <int SKIP, bool ERT, int GRAD, bool PACKED, uint32_t LF, int WPB = 4, bool FILL = false>
 __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, RmLds &L)
 {
 	// Hardware deals workgroup ids round-robin over the 8 XCDs (own L2 each).  XCD x = id & 7 marches the schedule's tiles
@@ -1685,6 +1691,43 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t       px, py, o;
 	const uint32_t rb = (part * WPB + wave) * 64u + lane;        // ray of the block this lane marches: the lane's own pixel of its 8x8 quadrant
+	if (FILL && A.fill_tiles != 0u)
+	{
+		// VkvTileSchedule.fill_outside: the tiles of the image outside the schedule's rectangle get the no-fragment result from the workgroups that
+		// render (no workgroup per empty tile: half of a C3 frame's tiles, 4 % of its time).  Outside tile j, row-major over the image with the
+		// rectangle left out: the rows above it, the parts left and right of it, the rows below.  Wave-uniform arithmetic, once per workgroup.
+		// (at most kFillPerTile outside tiles per rendering tile: the launcher renders the whole-image schedule when the rectangle is smaller than that;
+		// a loop of unknown length here keeps the single-frame kernels' by-value argument block in scratch)
+#pragma unroll
+		for (uint32_t it = 0; it < kFillPerTile; ++it)
+		{
+			const uint32_t j = k + it * A.tile_count;
+			if (j >= A.fill_tiles)
+				break;
+			const uint32_t top = A.rect_ty0 * A.img_tiles_x, per_row = A.img_tiles_x - A.tiles_x, mid = A.rect_th * per_row;
+			uint32_t       tx, ty;
+			if (j < top)
+				ty = j / A.img_tiles_x, tx = j % A.img_tiles_x;
+			else if (j - top < mid)
+			{
+				const uint32_t q = j - top, c = q % per_row;
+				ty = A.rect_ty0 + q / per_row, tx = c < A.rect_tx0 ? c : c + A.tiles_x;
+			}
+			else
+			{
+				const uint32_t q = j - top - mid;
+				ty = A.rect_ty0 + A.rect_th + q / A.img_tiles_x, tx = q % A.img_tiles_x;
+			}
+			const uint32_t fx = tx * A.tile_w + (sb % A.blocks_per_tile_x) * 16u + (rb & 15u), fy = ty * A.tile_h + (sb / A.blocks_per_tile_x) * 16u + (rb >> 4);
+			if (fx < A.img_w && fy < A.img_h)
+			{
+				Ray F;
+				ray_clear(F);
+				F.o = fy * A.img_w + fx;
+				ray_finish(A, F, false);
+			}
+		}
+	}
 	const bool     inside = block_pixel<1>(A, k * A.blocks_per_tile + sb, rb, px, py, o);
 	Ray R;
 	R.o = o;
@@ -1815,7 +1858,7 @@ __global__ void __launch_bounds__(256) VKV_NO_PACKED_FP32 __attribute__((amdgpu_
 	const uint32_t f = groups_per_frame == 0 ? g % n : g / groups_per_frame, gi = groups_per_frame == 0 ? g / n : g % groups_per_frame;
 	// (the anisotropic kernels that keep the per-pixel counters have no room under the 64-VGPR cap for the second march loop: they would spill)
 	constexpr uint32_t kLfBatch = (SKIP == VKV_SKIP_ANISOTROPIC_DISTANCE && (LF & kLeanNoCounts) == 0) ? (LF & ~kLeanSafe) : LF;
-	lean_block<SKIP, ERT, GRAD, true, kLfBatch>(frames[f], (gi << 3) | (blockIdx.x & 7u), L);
+	lean_block<SKIP, ERT, GRAD, true, kLfBatch, 4, true>(frames[f], (gi << 3) | (blockIdx.x & 7u), L);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1932,5 +1975,5 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 namespace vkv
 {
 // raymarch.hip: VkvRenderParams -> kernel arguments (shared with tools/lab)
-int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, RayMarchArgs &a, hipStream_t s, const VkvTuning &T, bool setup);
+int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_lut, RayMarchArgs &a, hipStream_t s, const VkvTuning &T, bool setup, bool batch);
 }        // namespace vkv

@@ -332,7 +332,7 @@ int main(int argc, char **argv)
 				for (int s = 0; s < kLaunchStreams; ++s)
 				{
 					dc.stream = lstreams[s];
-					subpass.prepare_targets(ltargets[s]);
+					subpass.prepare_targets(ltargets[s], nullptr, true);
 				}
 			else
 				for (int i = 0; i < fif; ++i)

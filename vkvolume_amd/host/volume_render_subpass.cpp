@@ -58,15 +58,24 @@ VkvTileSchedule VolumeRenderSubpass::rank_schedule(Volume &volume, const RenderT
 	return VkvTileSchedule{t, t, rank, n_ranks, total > rank ? (total - rank + n_ranks - 1) / n_ranks : 0u, 1u, rect};
 }
 
-void VolumeRenderSubpass::prepare_targets(const std::vector<RenderTarget> &targets, const VkvTileSchedule *tiles)
+VkvTileSchedule VolumeRenderSubpass::frame_schedule(Volume &volume, const RenderTarget &target) const
 {
+	VkvTileSchedule s = rank_schedule(volume, target, 0, 1);
+	s.compact = 0, s.fill_outside = 1;
+	return s;
+}
+
+void VolumeRenderSubpass::prepare_targets(const std::vector<RenderTarget> &targets, const VkvTileSchedule *tiles, bool for_batch)
+{
+	const bool own_schedule = !tiles && for_batch && volumes.size() == 1;        // what draw_batch(targets) will pass
 	for (const RenderTarget &t : targets)
 	{
 		for (Volume *volume : volumes)
 		{
 			if (!volume->get_packed_volume())
 				volume->pack(dc);
-			const VkvRenderParams p = make_params(*volume, t, tiles, false);
+			const VkvTileSchedule fs = own_schedule ? frame_schedule(*volume, t) : VkvTileSchedule{};
+			const VkvRenderParams p  = make_params(*volume, t, own_schedule ? &fs : tiles, false);
 			if (vkv_prepare_render(dc.ctx, &p, 1, dc.stream) != VKV_OK)
 				throw std::runtime_error(std::string("VolumeRenderSubpass::prepare_targets: ") + vkv_last_error(dc.ctx));
 			const void *id = p.d_out_rgba8 ? (const void *) p.d_out_rgba8 : (const void *) p.d_out_color;
@@ -111,7 +120,10 @@ void VolumeRenderSubpass::draw_batch(const std::vector<RenderTarget> &targets, c
 	std::vector<VkvRenderParams> params;
 	params.reserve(targets.size());
 	for (const RenderTarget &t : targets)
-		params.push_back(make_params(*volume, t, tiles, t.blend));
+	{
+		const VkvTileSchedule fs = tiles ? *tiles : frame_schedule(*volume, t);
+		params.push_back(make_params(*volume, t, &fs, t.blend));
+	}
 	if (vkv_render_batch(dc.ctx, params.data(), (uint32_t) params.size(), dc.stream) != VKV_OK)
 		throw std::runtime_error(std::string("VolumeRenderSubpass::draw_batch: ") + vkv_last_error(dc.ctx));
 }

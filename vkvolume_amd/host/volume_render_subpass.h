@@ -65,7 +65,8 @@ class VolumeRenderSubpass
 	// Set-up for the targets this subpass will draw into on the context's current stream (the counterpart of the reference building its
 	// per-swap-chain-image resources, src/volume_render_subpass.cpp:95-157): vkv_prepare_render + vkv_register_target, so that draw() /
 	// draw_batch() afterwards only enqueue (no allocation, no wait).  forget_targets() before the buffers are freed.
-	void prepare_targets(const std::vector<RenderTarget> &targets, const VkvTileSchedule *tiles = nullptr);
+	// for_batch: the targets will be drawn with draw_batch(targets) and no schedule of the caller's: registered for draw_batch's own schedule
+	void prepare_targets(const std::vector<RenderTarget> &targets, const VkvTileSchedule *tiles = nullptr, bool for_batch = false);
 	void forget_targets(const std::vector<RenderTarget> &targets);
 
 	// src/volume_render_subpass.cpp:159-294: per volume, build the uniforms and march.  `tiles` selects the screen tiles of
@@ -75,7 +76,13 @@ class VolumeRenderSubpass
 	// Several frames of the same subpass in ONE launch (vkv_render_batch): the reference keeps a few swap-chain images in flight
 	// (per-image command buffers); here their ray-marches share a grid, so the long tail of one frame is covered by the others.
 	// One volume, up to VKV_MAX_BATCH targets with distinct output buffers; falls back to draw() per target otherwise.
+	// tiles == nullptr: every frame through frame_schedule() - the tiles of its screen rectangle, the rest of the frame filled by the same launch.
 	void draw_batch(const std::vector<RenderTarget> &targets, const VkvTileSchedule *tiles = nullptr);
+
+	// The schedule of a whole frame on one GPU (round 6): the 16x16 tiles of the rectangle the clipped box projects into (vkv_screen_tile_rect: the
+	// rasteriser of the reference only shades the box's faces, :262-293) with VkvTileSchedule.fill_outside - the launch's workgroups write the
+	// no-fragment result everywhere else, so the frame is complete without a workgroup per empty tile (C3: half of the frame's tiles, 2.7 % of its time).
+	VkvTileSchedule frame_schedule(Volume &volume, const RenderTarget &target) const;
 
 	// the parameter block of one volume (what draw() binds), exposed for tests / the multi-GPU driver
 	VkvRenderParams make_params(Volume &volume, const RenderTarget &target, const VkvTileSchedule *tiles, bool blend = false) const;
