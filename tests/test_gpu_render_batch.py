@@ -294,6 +294,19 @@ def test_fill_outside_schedules_complete_the_frame(ctx, seed):
     assert np.array_equal(fill[0][2].cpu().numpy().astype(np.uint32), ref.counts), what
     assert float(np.abs(fill[0][0].cpu().numpy() - ref.color).max()) <= COLOR_TOL, what
     assert np.array_equal(fill[0][1].cpu().numpy(), ref.rgba8), what
+    if not blend:
+        # the production frame: RGBA8 only (the outside tiles are then cleared with 16-byte stores when the image rows allow it)
+        only = [torch.full((size[1], size[0], 4), 0xC3, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        qs = []
+        for i, t in enumerate(only):
+            q = bound(pf, (None, t, None, None)) if False else sp.bind(pf)
+            q.d_out_color, q.d_out_rgba8, q.d_out_counts, q.d_out_depth = None, t.data_ptr(), None, None
+            q.d_in_depth, q.blend_over_target = (depth_keep[5].data_ptr() if in_depth is not None else None), 0
+            qs.append(q)
+        ctx.render_batch(qs, st)
+        torch.cuda.synchronize()
+        for t in only:
+            assert torch.equal(t, whole[0][1]), "%s: RGBA8-only frame of the fill_outside schedule differs from the whole-image schedule's" % what
     # argument checks: fill_outside wants the whole rectangle, image-indexed
     bad = bound(pf, targets())
     bad.tiles.tile_count = max(0, rect.tiles - 1)

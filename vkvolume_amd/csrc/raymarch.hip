@@ -355,6 +355,7 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 	a.img_w = P->image_width, a.img_h = P->image_height;
 	a.tile_w = P->tiles.tile_width, a.tile_h = P->tiles.tile_height;
 	a.tile_first = P->tiles.tile_first, a.tile_stride = P->tiles.tile_stride, a.tile_count = P->tiles.tile_count, a.compact = P->tiles.compact;
+	a.fill_rgba8_rows = (a.out_rgba8 && !a.out_color && !a.out_counts && !a.out_depth && !a.blend && (a.img_w & 3u) == 0 && (((uintptr_t) a.out_rgba8) & 15u) == 0) ? 1u : 0u;
 	bool whole_schedule;        // every tile of the image is scheduled (no rectangle, or a fill_outside rectangle handed to a resident-wave scheduler)
 	{        // the schedule's tile rectangle (all zero: the whole image); tiles are numbered row-major inside it
 		const VkvTileRect &r = P->tiles.rect;

@@ -57,6 +57,7 @@ struct RayMarchArgs
 	// VkvTileSchedule.fill_outside (k_raymarch_lean*): fill_tiles = tiles of the image OUTSIDE the rectangle (0 = nothing to fill); the rendering
 	// workgroups write the no-fragment result there, schedule entry k the outside tiles k, k + tile_count, ...
 	uint32_t        fill_tiles, img_tiles_x, rect_tx0, rect_ty0, rect_th;
+	uint32_t        fill_rgba8_rows;        // != 0: the only output is RGBA8, nothing is blended, image rows are 16-byte aligned - outside tiles are cleared with 16-byte stores
 	uint32_t        blocks_per_tile_x, blocks_per_tile, nblocks;
 	int             test;
 	unsigned long long *trace;      // diagnostic (tools/wave_trace.py): kTraceWords x u64 per wave {t_start, t_end, iterations, unit, phase sums}, or null
@@ -1718,13 +1719,28 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 				const uint32_t q = j - top - mid;
 				ty = A.rect_ty0 + A.rect_th + q / A.img_tiles_x, tx = q % A.img_tiles_x;
 			}
-			const uint32_t fx = tx * A.tile_w + (sb % A.blocks_per_tile_x) * 16u + (rb & 15u), fy = ty * A.tile_h + (sb / A.blocks_per_tile_x) * 16u + (rb >> 4);
-			if (fx < A.img_w && fy < A.img_h)
+			const uint32_t bx0 = tx * A.tile_w + (sb % A.blocks_per_tile_x) * 16u, by0 = ty * A.tile_h + (sb / A.blocks_per_tile_x) * 16u;        // the block's first pixel
+			if (A.fill_rgba8_rows != 0u && bx0 + 16u <= A.img_w)
 			{
-				Ray F;
-				ray_clear(F);
-				F.o = fy * A.img_w + fx;
-				ray_finish(A, F, false);
+				// the production frame (RGBA8 only, no blend state, rows of the image 16-byte aligned: the launcher's flag): a 16-pixel row of the block
+				// is four 16-byte stores, the block one store instruction of its first wave instead of four
+				if (rb < 64u && by0 + (rb >> 2) < A.img_h)
+				{
+					typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+					const v4u zero = {0u, 0u, 0u, 0u};
+					__builtin_nontemporal_store(zero, reinterpret_cast<v4u *>(A.out_rgba8 + ((size_t) (by0 + (rb >> 2)) * A.img_w + bx0 + (rb & 3u) * 4u) * 4u));
+				}
+			}
+			else
+			{
+				const uint32_t fx = bx0 + (rb & 15u), fy = by0 + (rb >> 4);
+				if (fx < A.img_w && fy < A.img_h)
+				{
+					Ray F;
+					ray_clear(F);
+					F.o = fy * A.img_w + fx;
+					ray_finish(A, F, false);
+				}
 			}
 		}
 	}
