@@ -36,6 +36,33 @@ def test_occupied_voxel_count_parity(ctx, opts, use_map, shape):
     assert int(d_count.item()) == O.occupied_voxel_count(vol, grad, tf)
 
 
+@pytest.mark.parametrize("imin", [-0.2, 0.0, 1.0 / 255.0, 0.3, 127.0 / 255.0, 0.5, 128.5 / 255.0, 0.75, 254.0 / 255.0, 1.0, 1.5])
+@pytest.mark.parametrize("use_map", [True, False])
+@pytest.mark.parametrize("shape", [(64, 24, 20), (37, 29, 23), (258, 9, 7)])
+def test_occupied_voxel_count_thresholds(ctx, imin, use_map, shape):
+    """The count kernel skips the gradient rows of a batch whose every intensity byte lies below the lowest byte with alpha (round 6): every
+    threshold position - none (imin < 0), both halves of the byte range (the SWAR compare treats bit 7 separately), all (imin >= 1) - on volumes
+    that are mostly below it, with a few bytes above in otherwise skipped batches."""
+    rng = np.random.default_rng(int(imin * 1000) % 997 + shape[0])
+    lo = int(np.clip(imin * 255.0, 0, 255))
+    vol = rng.integers(0, max(lo, 1), size=shape[::-1], dtype=np.uint8)          # below the threshold ...
+    hot = rng.random(vol.shape) < 0.002
+    vol[hot] = rng.integers(0, 256, size=int(hot.sum()), dtype=np.uint8)         # ... but for a few voxels anywhere in the range
+    vol[shape[2] // 2] = rng.integers(0, 256, size=vol.shape[1:], dtype=np.uint8)  # and one slice of plain noise
+    opt = abi.VolumeOptions(use_precomputed_gradient=use_map, intensity_min=imin, intensity_max=imin + 0.2, gradient_min=0.02, gradient_max=0.3)
+    tf = lib.transfer_function_uniform(opt)
+    grad = O.gradient_map(vol, tf) if use_map else None
+    d_vol = torch.from_numpy(vol).cuda()
+    d_grad = torch.from_numpy(grad).cuda() if grad is not None else None
+    d_count = torch.full((1,), 12345, dtype=torch.int64, device="cuda")
+    ctx.occupied_voxel_count(d_vol.data_ptr(), None if d_grad is None else d_grad.data_ptr(), tf, abi.Extent3D(*shape), d_count.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream)
+    expect = O.occupied_voxel_count(vol, grad, tf)
+    assert int(d_count.item()) == expect
+    if imin >= 1.0:
+        assert expect == 0
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("VKV_TEST_FUZZ_SEEDS", "16"))))
 def test_device_loader_conversion_fuzz(ctx, tmp_path, seed):
     """vkv_convert_volume against the oracle's CPU loader (src/load_volume.cpp:112-172) on random files: voxel type, byte order, extent
