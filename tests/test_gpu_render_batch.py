@@ -313,3 +313,61 @@ def test_fill_outside_schedules_complete_the_frame(ctx, seed):
     if rect.tiles > 1 and (rect.w, rect.h) != (-(-size[0] // 16), -(-size[1] // 16)):
         assert ctx.render_rc(bad, st) == abi.VKV_E_INVALID_ARGUMENT
     del keep
+
+
+RING_RECTS = [(0, 0, 1, 1), (3, 2, 1, 5), (2, 3, 7, 1), (1, 0, 2, 7), (0, 1, 9, 2), (4, 2, 3, 3), (1, 1, 5, 4), (0, 0, 10, 7), (2, 0, 8, 7), (0, 0, 10, 6),
+              (3, 1, 6, 5), (5, 0, 4, 7)]
+
+
+@pytest.mark.parametrize("rect", RING_RECTS, ids=lambda r: "%dx%d@%d,%d" % (r[2], r[3], r[0], r[1]))
+def test_computed_start_order_reaches_every_tile_of_a_rectangle(ctx, rect):
+    """A schedule that holds every tile of a tile rectangle starts its tiles ring by ring from the rectangle's middle (start_entry in
+    raymarch_core.hpp: computed in the kernel, no table).  Every rectangle shape - one tile, one row, one column, two rows, odd and even sides,
+    the whole image - renders exactly its tiles: inside equal to the whole-image frame, outside untouched (image-indexed) / every slot of the
+    compact buffer written; the plain order (VkvTuning.tile_order_linear) gives the same bytes."""
+    from tests.test_gpu_parity import fuzz_case
+    scene, v, params, _, label = fuzz_case(ctx, 311)
+    size = (160, 112)  # 10 x 7 tiles
+    view, proj = T.orbit(35.0, image_size=size)
+    sp = V.VolumeRenderSubpass(ctx, v, params.options, size)
+    p = sp.make_params(view, proj, abi.full_frame_tiles(size[0], size[1]))
+    st = torch.cuda.current_stream().cuda_stream
+    r = abi.TileRect(*rect)
+
+    def run(tiles, compact_pixels=None, n=2):
+        outs, qs = [], []
+        for _ in range(n):
+            shape = (compact_pixels, 4) if compact_pixels else (size[1], size[0], 4)
+            rgba8 = torch.full(shape, 0x5A, dtype=torch.uint8, device="cuda")
+            counts = torch.full(shape[:-1] + (3,), 77, dtype=torch.int32, device="cuda")
+            q = abi.RenderParams.from_buffer_copy(p)
+            q.tiles = tiles
+            q.d_out_color, q.d_out_rgba8, q.d_out_counts, q.d_out_depth, q.d_in_depth, q.blend_over_target = None, rgba8.data_ptr(), counts.data_ptr(), None, None, 0
+            outs.append((rgba8, counts))
+            qs.append(q)
+        ctx.render_batch(qs, st)
+        torch.cuda.synchronize()
+        return outs
+
+    whole = run(abi.full_frame_tiles(size[0], size[1]))[0]
+    assert int(whole[0][..., 3].max()) > 0, label
+    inside = torch.zeros((size[1], size[0]), dtype=torch.bool, device="cuda")
+    inside[rect[1] * 16:(rect[1] + rect[3]) * 16, rect[0] * 16:(rect[0] + rect[2]) * 16] = True
+    results = {}
+    for linear in (0, 1):
+        ctx.set_tuning(tile_order_linear=linear)
+        try:
+            img = run(abi.full_frame_tiles(size[0], size[1], rect=r))
+            cmp = run(abi.full_frame_tiles(size[0], size[1], rect=r, compact=True), compact_pixels=rect[2] * rect[3] * 256)
+        finally:
+            ctx.set_tuning(tile_order_linear=0)
+        for rgba8, counts in img:
+            assert torch.equal(rgba8[inside], whole[0][inside]) and torch.equal(counts[inside], whole[1][inside]), "rect %s, linear %d" % (rect, linear)
+            assert bool((rgba8[~inside] == 0x5A).all()) and bool((counts[~inside] == 77).all()), "rect %s, linear %d: wrote outside the rectangle" % (rect, linear)
+        # the compact buffer: tile k of the rectangle (row-major) in slot k, every slot written
+        tiles = whole[0][rect[1] * 16:(rect[1] + rect[3]) * 16, rect[0] * 16:(rect[0] + rect[2]) * 16].reshape(rect[3], 16, rect[2], 16, 4).permute(0, 2, 1, 3, 4).reshape(-1, 4)
+        for rgba8, counts in cmp:
+            assert torch.equal(rgba8, tiles), "rect %s, linear %d: compact buffer" % (rect, linear)
+            assert bool((counts != 77).any(dim=-1).all())
+        results[linear] = img[0][0]
+    assert torch.equal(results[0], results[1])

@@ -411,12 +411,16 @@ int fill_render_args(vkv_ctx *ctx, const VkvRenderParams *P, const float *alpha_
 	if (a.packed && T.address_tables != 0)
 		a.addr_lut = packed_addr_lut(ctx, a.W, a.H, a.D, &a.lut_y, &a.lut_z, &a.lut_words, s, setup);
 	screen_bound_of_box(a, T);
-	// Start order.  Whole-image schedules: centre of the image first (a cached table per schedule shape).  Schedules over a tile rectangle start in
-	// plain order, row-major inside the rectangle (round 6): the rectangle holds few cheap tiles, and a table per rectangle SIZE - a camera that
-	// moves gives every frame in flight its own - cost more than the order gained (24 tables of 16 KB through the scalar cache: +2 ... 4 %
-	// per frame against no table, profiles/r6_rect_schedules.txt); a registered target's measured order still applies (apply_feedback).
+	// Start order.  Whole-image schedules: centre of the image first (a cached table per schedule shape).  A schedule that holds every tile of a
+	// tile rectangle computes the same kind of order in the kernel (start_entry: the rectangle's rings from the innermost outwards) - a table per
+	// rectangle SIZE does not pay when the camera moves (every frame in flight its own 16 KB table through the scalar cache: +2 ... 4 % per frame
+	// with 24 in flight, profiles/r6_rect_schedules.txt).  A rank's share of a rectangle (tile_stride > 1) starts in plain order.  A registered
+	// target's measured order applies to all of them (apply_feedback).
 	a.tile_order = (T.tile_order_linear || !whole_schedule) ? nullptr
 	                                                         : tile_start_order(ctx, a.img_w, a.img_h, a.tile_w, a.tile_h, a.tile_first, a.tile_stride, a.tile_count, s, setup);
+	a.order_h = 0;
+	if (!whole_schedule && !T.tile_order_linear && a.tile_first == 0 && a.tile_stride == 1 && (uint64_t) a.tile_count == (uint64_t) a.tiles_x * P->tiles.rect.h)
+		a.order_h = P->tiles.rect.h;
 	for (int i = 0; i < 256; ++i)
 		a.alpha_lut[i] = alpha_lut[i];
 	return VKV_OK;

@@ -70,6 +70,9 @@ struct RayMarchArgs
 	uint32_t        cull_x0, cull_x1, cull_y0, cull_y1;        // k_raymarch_lean: pixels outside [x0, x1] x [y0, y1] cannot see the volume's box
 	                                                           // (conservative screen bound from the launcher); 0, ~0, 0, ~0 = no bound
 	const uint32_t *tile_order;     // k_raymarch_lean: the r-th tile to be started is schedule entry tile_order[r] (centre of the image first), or null
+	// no tile_order and order_h != 0: the start order is computed (start_entry) - the rings of the schedule's tiles_x x order_h rectangle of tiles from the
+	// innermost outwards (schedules that hold every tile of their rectangle)
+	uint32_t        order_h;
 	uint32_t *      queue_heads;        // persistent scheduler: 8 tile-queue heads (one per XCD label), zeroed per launch
 	// start-order feedback (raymarch.hip, TileFeedback): every marching wave leaves max(its iteration count) in tile_cost[schedule entry];
 	// before the next frame into the same target k_tile_order_from_cost turns the costs into a longest-first order (order_out = the
@@ -1666,6 +1669,40 @@ __device__ __forceinline__ void lean_march(const RayMarchArgs &A, Ray &R, const 
 		R.r = grey, R.g = grey, R.b = grey;
 }
 
+// Computed start order of a schedule over a tile rectangle (RayMarchArgs.order_h; wave-uniform, once per workgroup, no table): which schedule
+// entry is started r-th.  Ring by ring from the innermost ring of the w x h rectangle to its border (ring j = the tiles with j tiles between them
+// and the nearest border; the rectangle inside ring j holds (w - 2j)(h - 2j) tiles, so the ring of rank r follows from a square root), inside a
+// ring clockwise from its top left tile.  The volume's silhouette and the empty corners of the rectangle start last, as with the centre-first
+// table of a whole-image schedule - but a rectangle's size changes with the camera, and a table per size does not pay (a camera that moves
+// gives every frame in flight its own: profiles/r6_rect_schedules.txt).  Launches of 2 - 4 frames on one stream: -11 % against the plain order.
+__device__ __forceinline__ uint32_t start_entry(const RayMarchArgs &A, uint32_t r)
+{
+	const int w = (int) A.tiles_x, h = (int) A.order_h, rings = (min(w, h) + 1) >> 1;
+	auto      inner = [&](int j) { return (w - 2 * j > 0 && h - 2 * j > 0) ? (uint32_t) ((w - 2 * j) * (h - 2 * j)) : 0u; };        // tiles inside ring j - 1
+	const float d = (float) (w - h);
+	int         j = (int) (((float) (w + h) - __builtin_sqrtf(d * d + 4.0f * (float) r)) * 0.25f);
+	j             = max(0, min(j, rings - 1));
+#pragma unroll
+	for (int it = 0; it < 2; ++it)        // the float estimate is off by one at most
+	{
+		if (j + 1 < rings && inner(j + 1) > r)
+			++j;
+		if (j > 0 && inner(j) <= r)
+			--j;
+	}
+	const int wj = w - 2 * j, hj = h - 2 * j;
+	int       q = (int) (r - inner(j + 1)), tx, ty;
+	if (hj == 1 || q < wj)
+		tx = j + q, ty = j;        // top edge, left to right (all of a one-row ring)
+	else if ((q -= wj) < hj - 1)
+		tx = j + wj - 1, ty = j + 1 + q;        // right edge, downwards
+	else if ((q -= hj - 1) < wj - 1)
+		tx = j + wj - 2 - q, ty = j + hj - 1;        // bottom edge, right to left
+	else
+		q -= wj - 1, tx = j, ty = j + hj - 2 - q;        // left edge, upwards
+	return (uint32_t) __builtin_amdgcn_readfirstlane(ty * w + tx);
+}
+
 // the body of one workgroup: 16x16 pixels of the frame described by A; `bid` is the workgroup's id inside that frame's grid
 // FILL: the batch kernel's workgroups also fill the tiles outside a fill_outside schedule's rectangle (the single-frame kernel takes its argument
 // block by value, and this code in it made the compiler keep the whole 1.8 KB block in scratch: its launcher renders the whole-image schedule instead)
@@ -1686,7 +1723,7 @@ __device__ __forceinline__ void lean_block(const RayMarchArgs &A, uint32_t bid, 
 	// frame; on C3 this one shortens a single frame's launch from 0.324 to 0.306 ms and the tail of an 8-frame launch from 0.18 to
 	// 0.03 ms (bench.py).  Several single-frame launches in flight on their own streams prefer the plain order
 	// (VKV_RAYMARCH_TILE_ORDER=linear: 0.157 vs 0.167 ms per frame with three in flight) - their heavy centres then do not coincide.
-	const uint32_t k = A.tile_order ? A.tile_order[rank] : rank;
+	const uint32_t k = A.tile_order ? A.tile_order[rank] : (A.order_h ? start_entry(A, rank) : rank);
 	if (k >= A.tile_count)
 		return;        // never with a well-formed order; keeps a damaged one (a target shared by two streams without an event) from becoming a wild address
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
