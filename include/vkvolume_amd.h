@@ -408,7 +408,7 @@ int vkv_render_batch(vkv_ctx *ctx, const VkvRenderParams *params, uint32_t count
  * vertices of the clipped box are solved through the ray generator (p - camera_pos_tex = g (dir00 + fx ddx + fy ddy)), and the pixel
  * bound of the (fx, fy), widened by two pixels, is rounded outwards to whole tiles and then to multiples of `align_tiles` tiles
  * (0 or 1: no alignment; a renderer whose camera moves aligns to e.g. 4 tiles so that the rectangle - and with it the feedback state of a
- * registered target - changes less often; schedules over a rectangle start in plain order, no table is cached per rectangle).  A pixel outside the rectangle cannot have a fragment, whatever
+ * registered target - changes less often; a schedule over a whole rectangle computes its start order in the kernel, no table is cached per rectangle).  A pixel outside the rectangle cannot have a fragment, whatever
  * the depth test does afterwards.  The rectangle is never empty: a box that is off screen gives the 1 x 1 rectangle of tile (0, 0)
  * (a fixed, minimal exchange); a vertex at or behind the camera plane, or a degenerate generator, gives the whole image. */
 int vkv_screen_tile_rect(const VkvRayCastUniform *ray_cast, const VkvRayGen *ray_gen, uint32_t image_width, uint32_t image_height,
