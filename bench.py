@@ -265,6 +265,8 @@ def main():
     ap.add_argument("--tile-rect", default="on", choices=["on", "off"], help="N > 1 / --virtual-rank / --force-gather: schedule and exchange only the tiles of each "
                     "frame's screen rectangle (vkv_screen_tile_rect: the clipped box's projection, derived by every rank from the uniforms; default) or every "
                     "tile of the frame (off: rounds 1-5)")
+    ap.add_argument("--rect-align", type=int, default=1, help="tile rectangles rounded outwards to multiples of this many tiles (vkv_screen_tile_rect's align_tiles): "
+                    "a camera that moves then changes the rectangle - and the start-order feedback state keyed by it - less often")
     ap.add_argument("--exchange", default="torch", choices=["native", "torch"], help="N > 1: the tile gather through torch.distributed.gather (default: "
                     "0.170 ms per step in the one-rank pipeline test) or through the C ABI (vkv_gather_tiles / vkv_scatter_tiles: ncclGather on a "
                     "communicator of our own, no torch.distributed on the data path; 0.190 ms per step in the same test)")
@@ -522,7 +524,7 @@ def job(args, env):
     for view, proj in views:
         p = sp.make_params(view, proj, whole_tiles)
         params_whole.append(abi.RenderParams.from_buffer_copy(p))  # the whole-image schedule: counter pre-pass, single-frame launches, CPU check
-        r = lib.screen_tile_rect(p.ray_cast, p.ray_gen, (fw, fh), (TILE, TILE)) if (use_rect or use_fill) else whole_rect
+        r = lib.screen_tile_rect(p.ray_cast, p.ray_gen, (fw, fh), (TILE, TILE), max(1, getattr(args, "rect_align", 1))) if (use_rect or use_fill) else whole_rect
         if use_fill:
             t = abi.full_frame_tiles(fw, fh, TILE, TILE, rect=r, fill_outside=True)
         else:
