@@ -65,6 +65,8 @@ def main():
         "fetch_size_kib_avg": fetch, "write_size_kib_avg": write,
         "traffic_bytes_per_launch": int((fetch * 2 + write) * 1024) if fetch and write else None,
         "valu_issue_frac": round(issue, 4) if issue else None, "wait_frac": round(wait, 4) if wait else None,
+        "valu_issue_frac_note": (None if workload == "c3" else "priced with the per-class instruction costs of C3's march loop (the distance-map variant <2, true, 1, 55>); this workload "
+                                 "runs another variant of the same loop, the model is good to about +-15 %: a figure near or above 1 says that VALU issue is the limit, not by how much"),
         "waves_per_simd": round(waves, 2) if waves else None, "valu_active_lanes": round(lanes, 2) if lanes else None, "valu_issue_cost_model": model,
         "counters_avg": {k: round(v, 1) for k, v in sorted(avg.items())}, "launches_averaged": n,
         "kernel_source_sha256": digest, "commit": commit,
